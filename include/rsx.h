@@ -1,0 +1,176 @@
+/*
+ * rsx.h — C-ABI of the MI355X-native vectorised rSoccer step engine (librsx_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of robocin/rSoccer: it takes the place of the
+ * third-party `robosim` module (rc-robosim / rSim) that the reference binds in
+ * rsoccer_gym/Simulators/rsim.py.  Every entry point cites the reference call site it replaces.
+ * Plain pointers and sizes only; no torch / C++ types cross this boundary.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, <0 = error (text via rsx_last_error(), thread-local);
+ *     no exception crosses the ABI.
+ *   - "host" pointers are ordinary CPU memory owned by the caller (the reference wire format:
+ *     float64, C-contiguous, rows = blue ids then yellow ids — rsim.py:92-101,129-153).
+ *   - "dev" pointers are HIP device memory owned by the handle (valid until rsx_destroy); all
+ *     device work is stream-ordered on the hipStream_t passed as `void* stream` (NULL = the
+ *     null stream) and never synchronises implicitly, except the host-format calls
+ *     (rsx_step / rsx_get_state / rsx_reset / rsx_set_state / rsx_read_metrics) which must
+ *     return results to the host and therefore synchronise that stream.
+ *   - a handle is not thread-safe; distinct handles are independent.
+ *   - there is NO CPU fallback: creation fails (RSX_ERR_NO_DEVICE) without a gfx950 device.
+ *
+ * Units (Entities/Frame.py:8): m, m/s, degrees, degrees/s.  VSS commands are wheel rad/s
+ * (vss_gym.py:250-252); SSL commands are robot-local m/s and rad/s or wheel rad/s
+ * (rsim.py:137-153).
+ */
+#ifndef RSX_H
+#define RSX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSX_ABI_VERSION 1
+
+/* kind: which robosim class the handle stands for (rsim.py:116 robosim.VSS, :169 robosim.SSL) */
+#define RSX_KIND_VSS 0
+#define RSX_KIND_SSL 1
+
+/* fused task epilogues (obs / reward / done / OU noise / auto-reset computed on device) */
+#define RSX_TASK_NONE                 0 /* raw simulator only                                         */
+#define RSX_TASK_VSS_V0               1 /* rsoccer_gym/vss/env_vss/vss_gym.py:13  (obs 40, act 2)     */
+#define RSX_TASK_SSL_STATIC_DEFENDERS 2 /* ssl/ssl_hw_challenge/static_defenders.py:12 (obs 24, act 5)*/
+
+/* error codes */
+#define RSX_OK              0
+#define RSX_ERR_ARG        -1
+#define RSX_ERR_NO_DEVICE  -2
+#define RSX_ERR_HIP        -3
+#define RSX_ERR_STATE      -4
+
+/* number of entries of get_field_params(), in the order of Entities/Field.py:5-21 */
+#define RSX_FIELD_PARAMS 17
+/* metrics vector length (int64 each; see rsx_read_metrics) */
+#define RSX_METRICS 8
+
+typedef struct rsx_sim rsx_sim; /* opaque */
+
+/* Device-side views, zero-copy.  SoA: row f of an [F][B] array is the contiguous run
+ * base + f*num_envs (one float per env).  state rows 0..state_dim-1 are exactly the reference's
+ * get_state() layout (Entities/Frame.py:20-47 VSS, :55-92 SSL) transposed; row state_dim holds
+ * the ball's vertical velocity (internal, needed to checkpoint a chipped ball). */
+typedef struct rsx_dev_view {
+    int32_t num_envs;    /* B                                                                */
+    int32_t n_robots;    /* N = n_blue + n_yellow                                            */
+    int32_t state_dim;   /* 5 + 6N (VSS) | 5 + 11N (SSL)                                     */
+    int32_t cmd_dim;     /* C: 2 (VSS) | 8 (SSL)  — per robot                                */
+    float*  state;       /* [state_dim + 1][B] f32 SoA                                       */
+    float*  cmds;        /* [N*C][B] f32 SoA, row = robot*C + col; read by rsx_step_dev      */
+} rsx_dev_view;
+
+typedef struct rsx_task_view {
+    int32_t  task;
+    int32_t  obs_dim;       /* 40 | 24                                                       */
+    int32_t  act_dim;       /* 2 | 5                                                         */
+    int32_t  info_dim;      /* 6 | 8 : cumulative reward-shaping terms, order of the
+                               reference's reward_shaping_total dict                         */
+    int32_t  max_episode_steps;
+    float*   obs;           /* [B][obs_dim] f32 row-major (what a policy consumes)           */
+    float*   reward;        /* [B] f32                                                       */
+    uint8_t* terminated;    /* [B] u8 — task `done` of the step just taken                   */
+    uint8_t* truncated;     /* [B] u8 — TimeLimit hit (rsoccer_gym/__init__.py:4,11)         */
+    float*   info;          /* [info_dim][B] f32 SoA, values AFTER the step, BEFORE any
+                               auto-reset clears them                                        */
+    float*   final_obs;     /* [B][obs_dim] f32: terminal observation, written only for envs
+                               whose episode ended in this step                              */
+    int32_t* steps;         /* [B] i32: steps taken in the current episode                   */
+    float*   actions;       /* [B][act_dim] f32: staging buffer callers may fill and pass to
+                               rsx_task_step (any device pointer of that shape works)        */
+} rsx_task_view;
+
+/* ---- diagnostics ---------------------------------------------------------------------- */
+int         rsx_abi_version(void);
+const char* rsx_last_error(void);
+/* number of visible HIP devices (0 when none); never fails */
+int         rsx_device_count(void);
+
+/* ---- robosim.VSS / robosim.SSL replacement (batched) ------------------------------------ */
+
+/* ctor — replaces robosim.VSS(...) rsim.py:116-124 and robosim.SSL(...) rsim.py:169-177.
+ * field_type: VSS 0 = 3v3, 1 = 5v5; SSL 0 = div-B, 1 = div-A 11v11, 2 = hardware-challenge.
+ * num_envs independent copies live on device `device_id`.  Initial poses are the adapter's
+ * dummy line-up (rsim.py:20-24): ball at origin, blue at x = -0.2*(i+1), yellow x = +0.2*(i+1). */
+int rsx_create(rsx_sim** out, int kind, int field_type, int n_blue, int n_yellow,
+               int time_step_ms, int num_envs, int device_id);
+/* destructor — replaces `del self.simulator` rsim.py:41 */
+int rsx_destroy(rsx_sim* h);
+
+/* get_field_params() — rsim.py:50; out[17] in the order of Entities/Field.py:5-21 */
+int rsx_get_field_params(const rsx_sim* h, double out[RSX_FIELD_PARAMS]);
+
+/* reset(ball, blue, yellow) — rsim.py:38,52-75.  Host f64: ball [B][4] = x,y,vx,vy;
+ * blue [B][n_blue][3], yellow [B][n_yellow][3] = x,y,theta(deg) (NULL allowed when that team
+ * is empty).  env_mask [B] u8 or NULL (= all): only envs with a non-zero mask are teleported.
+ * Robot velocities, wheel speeds, infrared and ball height are zeroed. */
+int rsx_reset(rsx_sim* h, const double* ball, const double* blue, const double* yellow,
+              const uint8_t* env_mask, void* stream);
+
+/* step(cmds) — rsim.py:102 (VSS, [B][N][2]) and rsim.py:155 (SSL, [B][N][8]); host f64. */
+int rsx_step(rsx_sim* h, const double* cmds, void* stream);
+
+/* get_state() — rsim.py:105,158; out [B][state_dim] host f64 */
+int rsx_get_state(rsx_sim* h, double* out, void* stream);
+
+/* full-state restore (checkpoint/resume, also used by parity tests): state [B][state_dim+1]
+ * host f64 = get_state() layout + ball vertical velocity. rsx_get_state_full is its inverse. */
+int rsx_set_state(rsx_sim* h, const double* state, void* stream);
+int rsx_get_state_full(rsx_sim* h, double* out, void* stream);
+
+/* ---- device-resident path (no host copies) -------------------------------------------- */
+int rsx_dev_view_get(rsx_sim* h, rsx_dev_view* out);
+/* advance all envs by time_step_ms using the commands currently in view.cmds */
+int rsx_step_dev(rsx_sim* h, void* stream);
+
+/* ---- fused task epilogues -------------------------------------------------------------- */
+
+/* Attach a task to a handle whose kind / robot counts match it (VSS_V0: VSS 3v3;
+ * STATIC_DEFENDERS: SSL 1v6).  seed + (env_id_base + local env index) key every random draw,
+ * so results do not depend on batch size, batch position or sharding.
+ * max_episode_steps <= 0 selects the registry value (1200 / 1000). */
+int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base,
+                    int max_episode_steps);
+int rsx_task_view_get(rsx_sim* h, rsx_task_view* out);
+
+/* reset(): new random placement for every env (vss_gym.py:194-233, static_defenders.py:214-254),
+ * episode counters cleared, obs written. */
+int rsx_task_reset(rsx_sim* h, void* stream);
+/* reset() onto an explicit placement (same arrays as rsx_reset); obs written. */
+int rsx_task_reset_to(rsx_sim* h, const double* ball, const double* blue, const double* yellow,
+                      const uint8_t* env_mask, void* stream);
+
+/* step(action): actions_dev [B][act_dim] f32 device memory, or NULL = uniform random actions
+ * drawn on device (the "random actions" benchmark configuration).  One kernel launch does
+ * action -> commands (+ OU noise for the non-agent robots), physics, observation, reward,
+ * done, TimeLimit and same-step auto-reset. */
+int rsx_task_step(rsx_sim* h, const float* actions_dev, void* stream);
+/* n consecutive random-action steps (n kernel launches replayed from a hipGraph). */
+int rsx_task_step_n(rsx_sim* h, int n, void* stream);
+/* n consecutive random-action steps inside ONE launch (state stays in registers between
+ * steps; obs / reward / done buffers hold the values of the last step). */
+int rsx_task_rollout(rsx_sim* h, int n, void* stream);
+
+/* metrics, int64[RSX_METRICS], accumulated on device since attach (payload of the multi-GPU
+ * all-reduce): 0 env_steps, 1 episodes, 2 goals_for (blue), 3 goals_against (yellow),
+ * 4 sum of episode returns in 2^-20 fixed point, 5 sum of episode lengths,
+ * 6 truncated episodes, 7 reserved.  Synchronises `stream`. */
+int rsx_read_metrics(rsx_sim* h, int64_t out[RSX_METRICS], void* stream);
+/* device pointer of the same vector (for an in-place RCCL all-reduce of a copy) */
+int rsx_metrics_dev(rsx_sim* h, int64_t** out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSX_H */

@@ -1,0 +1,765 @@
+/*
+ * rsx_oracle_impl.h — body of the CPU oracle, instantiated for R = float and R = double by
+ * rsx_oracle.c.  TEST INFRASTRUCTURE (see rsx_oracle.c header).  One env at a time, plain
+ * loops; the ORDER of floating-point operations below is the specification that the HIP
+ * kernels reproduce bit-for-bit in the float instantiation.
+ *
+ * State vector (wire format of robosim.get_state(), Entities/Frame.py:20-47 / :55-92):
+ *   [0..4]  ball x, y, z, vx, vy         robot k at 5 + RS*k: x, y, theta(deg), vx, vy,
+ *   omega(deg/s) [, infrared, v_wheel0..3 (rad/s)]   RS = 6 (VSS) | 11 (SSL)
+ *   [state_dim] ball vertical velocity (internal).
+ */
+
+#define RC(x) ((R)(x))
+#define MAXROB 22
+#define MAXBOD 23
+
+typedef struct SUF(rsxo_env) {
+    rsxo_cfg cfg;
+    int RS, state_dim;
+    /* typed constants */
+    R h, half_len, half_wid, ghw, gd, margin, r_robot, r_ball;
+    R rs_rr, rs_rr2, rs_rb, rs_rb2;
+    R w_rr, w_rb_r, w_rb_b, ope_rr, ope_rb, e_wb, e_wr, beta;
+    R w_max, half_rw, rw_2b, inv_rw, r_wheel;
+    R a_lin_h, a_lin_h2, a_lat_h, a_ang_h, mu_g_h, g_h, e_ground, vz_min, robot_h;
+    R dck_rb, half_kw, ir_tol, drib_gain, drib_vmax, drib_vmax2;
+    R ws[4], wc[4], pinv[3][4];
+    R deg2rad, rad2deg, pi, two_pi;
+    R state[5 + 11 * MAXROB + 1];
+    /* ---- task ---- */
+    int task, obs_dim, act_dim, info_dim, max_steps;
+    uint32_t key[2], env_id, episode;
+    int steps;
+    R max_pos, inv_max_pos, max_v, inv_max_v, inv_max_w, deadzone;
+    R ou[MAXROB][2];
+    R prev_pot, ep_ret;
+    R info[8];
+    R obs[64], final_obs[64], reward;
+    R last_cmds[MAXROB * 8];
+    uint8_t terminated, truncated;
+    int64_t metrics[8];
+    /* task constants */
+    R hl_goal, inv_len_cm, inv_dt;
+    R pen_x, half_pen_wid, inv_bd_scale, inv_bg_scale, inv_en_scale;
+    R pl_xlo, pl_xspan, pl_ylo, pl_yspan, pl_min_d2;
+    R ou_theta_dt, ou_sig_sqdt;
+} SUF(rsxo_env);
+
+static inline R SUF(clampr)(R v, R lo, R hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* ------------------------------------------------------------------------------------------ */
+void* SUF(rsxo_create)(int kind, int field_type, int nb, int ny, int ts_ms) {
+    SUF(rsxo_env)* e = (SUF(rsxo_env)*)calloc(1, sizeof(SUF(rsxo_env)));
+    if (!e) return NULL;
+    if (rsxo_cfg_init(&e->cfg, kind, field_type, nb, ny, ts_ms)) { free(e); return NULL; }
+    const rsxo_cfg* c = &e->cfg;
+    e->RS = kind == 0 ? 6 : 11;
+    e->state_dim = 5 + e->RS * c->n_robots;
+    e->h = RC(c->h);
+    e->half_len = RC(c->half_len); e->half_wid = RC(c->half_wid);
+    e->ghw = RC(c->goal_half_wid); e->gd = RC(c->goal_depth); e->margin = RC(c->margin);
+    e->r_robot = RC(c->r_robot); e->r_ball = RC(c->r_ball);
+    e->rs_rr = RC(2.0 * c->r_robot); e->rs_rr2 = RC((2.0 * c->r_robot) * (2.0 * c->r_robot));
+    e->rs_rb = RC(c->r_robot + c->r_ball);
+    e->rs_rb2 = RC((c->r_robot + c->r_ball) * (c->r_robot + c->r_ball));
+    double imr = 1.0 / c->m_robot, imb = 1.0 / c->m_ball;
+    e->w_rr = RC(0.5); e->w_rb_r = RC(imr / (imr + imb)); e->w_rb_b = RC(imb / (imr + imb));
+    e->ope_rr = RC(1.0 + c->e_rr); e->ope_rb = RC(1.0 + c->e_rb);
+    e->e_wb = RC(c->e_wall_ball); e->e_wr = RC(c->e_wall_robot); e->beta = RC(c->beta);
+    e->w_max = RC(c->w_max); e->r_wheel = RC(c->r_wheel);
+    e->half_rw = RC(c->r_wheel * 0.5); e->rw_2b = RC(c->r_wheel / (2.0 * c->lever));
+    e->inv_rw = RC(1.0 / c->r_wheel);
+    e->a_lin_h = RC(c->a_lin * c->h); e->a_lin_h2 = RC((c->a_lin * c->h) * (c->a_lin * c->h));
+    e->a_lat_h = RC(c->a_lat * c->h); e->a_ang_h = RC(c->a_ang * c->h);
+    e->mu_g_h = RC(c->mu_g * c->h); e->g_h = RC(c->grav * c->h);
+    e->e_ground = RC(c->e_ground); e->vz_min = RC(c->vz_min); e->robot_h = RC(c->robot_h);
+    e->dck_rb = RC(c->dck + c->r_ball); e->half_kw = RC(c->half_kw); e->ir_tol = RC(c->ir_tol);
+    e->drib_gain = RC(c->h > 0 ? 0.5 / c->h : 0.0);
+    e->drib_vmax = RC(c->drib_vmax); e->drib_vmax2 = RC(c->drib_vmax * c->drib_vmax);
+    for (int k = 0; k < 4; ++k) { e->ws[k] = RC(sin(c->wheel_ang[k])); e->wc[k] = RC(cos(c->wheel_ang[k])); }
+    for (int i = 0; i < 3; ++i) for (int k = 0; k < 4; ++k) e->pinv[i][k] = RC(c->pinv[i][k]);
+    e->deg2rad = RC(RSXO_PI / 180.0); e->rad2deg = RC(180.0 / RSXO_PI);
+    e->pi = RC(RSXO_PI); e->two_pi = RC(2.0 * RSXO_PI);
+    /* adapter's dummy line-up, rsim.py:20-24 */
+    e->state[2] = e->r_ball;
+    for (int k = 0; k < c->n_robots; ++k) {
+        int i = k < nb ? k + 1 : k - nb + 1;
+        e->state[5 + e->RS * k] = RC((k < nb ? -0.2 : 0.2) * i);
+    }
+    return e;
+}
+void SUF(rsxo_destroy)(void* p) { free(p); }
+int SUF(rsxo_state_dim)(void* p) { return ((SUF(rsxo_env)*)p)->state_dim; }
+
+void SUF(rsxo_field_params)(void* p, double out[17]) {
+    memcpy(out, ((SUF(rsxo_env)*)p)->cfg.field, 17 * sizeof(double));
+}
+
+/* robosim.reset(ball, blue, yellow) — rsim.py:38,52-75 */
+void SUF(rsxo_reset)(void* p, const double* ball, const double* blue, const double* yellow) {
+    SUF(rsxo_env)* e = (SUF(rsxo_env)*)p;
+    const rsxo_cfg* c = &e->cfg;
+    R* s = e->state;
+    memset(s, 0, sizeof(e->state));
+    s[0] = RC(ball[0]); s[1] = RC(ball[1]); s[2] = e->r_ball; s[3] = RC(ball[2]); s[4] = RC(ball[3]);
+    for (int k = 0; k < c->n_robots; ++k) {
+        const double* src = k < c->n_blue ? blue + 3 * k : yellow + 3 * (k - c->n_blue);
+        R* r = s + 5 + e->RS * k;
+        r[0] = RC(src[0]); r[1] = RC(src[1]); r[2] = RC(src[2]);
+    }
+}
+void SUF(rsxo_get_state)(void* p, double* out) {
+    SUF(rsxo_env)* e = (SUF(rsxo_env)*)p;
+    for (int i = 0; i < e->state_dim; ++i) out[i] = (double)e->state[i];
+}
+void SUF(rsxo_get_state_full)(void* p, double* out) {
+    SUF(rsxo_env)* e = (SUF(rsxo_env)*)p;
+    for (int i = 0; i <= e->state_dim; ++i) out[i] = (double)e->state[i];
+}
+void SUF(rsxo_set_state_full)(void* p, const double* in) {
+    SUF(rsxo_env)* e = (SUF(rsxo_env)*)p;
+    for (int i = 0; i <= e->state_dim; ++i) e->state[i] = RC(in[i]);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * walls: clamp a circle of radius r into the playable region; e = restitution
+ * ---------------------------------------------------------------------------------------- */
+static void SUF(walls)(const SUF(rsxo_env)* e, R r, R rest, R* px, R* py, R* pvx, R* pvy) {
+    R x = *px, y = *py, vx = *pvx, vy = *pvy;
+    R ax = R_FABS(x), ay = R_FABS(y);
+    R sx = x < RC(0) ? RC(-1) : RC(1), sy = y < RC(0) ? RC(-1) : RC(1);
+    if (e->cfg.kind == 0) {
+        if (ax > e->half_len) { /* centre inside a goal box */
+            R yl = e->ghw - r;
+            if (ay > yl) { y = sy * yl; if (vy * sy > RC(0)) vy = -rest * vy; }
+            R xl = (e->half_len + e->gd) - r;
+            if (ax > xl) { x = sx * xl; if (vx * sx > RC(0)) vx = -rest * vx; }
+        } else {
+            R yl = e->half_wid - r;
+            if (ay > yl) { y = sy * yl; if (vy * sy > RC(0)) vy = -rest * vy; }
+            R xl = e->half_len - r;
+            if (ax > xl && ay > e->ghw - r) { x = sx * xl; if (vx * sx > RC(0)) vx = -rest * vx; }
+        }
+    } else {
+        R yl = (e->half_wid + e->margin) - r;
+        if (ay > yl) { y = sy * yl; if (vy * sy > RC(0)) vy = -rest * vy; ay = yl; }
+        R xl = (e->half_len + e->margin) - r;
+        if (ax > xl) { x = sx * xl; if (vx * sx > RC(0)) vx = -rest * vx; ax = xl; }
+        if (ax > e->half_len) {
+            R back = e->half_len + e->gd;
+            if (ay < e->ghw) {
+                if (ax < back) { /* inside the goal */
+                    if (ax > back - r) { x = sx * (back - r); if (vx * sx > RC(0)) vx = -rest * vx; }
+                    if (ay > e->ghw - r) { y = sy * (e->ghw - r); if (vy * sy > RC(0)) vy = -rest * vy; }
+                } else if (ax < back + r) { /* behind the back wall */
+                    x = sx * (back + r); if (vx * sx < RC(0)) vx = -rest * vx;
+                }
+            } else if (ay < e->ghw + r && ax < back) { /* outside, touching a side wall */
+                y = sy * (e->ghw + r); if (vy * sy < RC(0)) vy = -rest * vy;
+            }
+        }
+    }
+    *px = x; *py = y; *pvx = vx; *pvy = vy;
+}
+
+/* per-body working record */
+typedef struct SUF(body) {
+    R x, y, vx, vy;        /* all */
+    R th, om, c, s;        /* robots: heading (rad), rate, cos/sin(th) */
+    R t0, t1, t2;          /* VSS: (v_target, om_target, -) | SSL: (vtx, vty, om_target) */
+    R kick_x, kick_z; int drib, ir;
+    R z, vz;               /* ball */
+} SUF(body);
+
+/* robot(a) - ball(b) contact geometry: normal n (a -> b), penetration, mouth flag */
+static inline int SUF(rb_geom)(const SUF(rsxo_env)* e, const SUF(body)* a, const SUF(body)* b,
+                               R* nx, R* ny, R* pen, int* mouth) {
+    R dx = b->x - a->x, dy = b->y - a->y;
+    *mouth = 0;
+    if (b->z >= e->robot_h) { *pen = RC(-1); *nx = RC(0); *ny = RC(0); return 0; }
+    if (e->cfg.kind == 1) {
+        R lx = dx * a->c + dy * a->s, ly = dy * a->c - dx * a->s;
+        if (R_FABS(ly) < e->half_kw && lx > RC(0)) {
+            *mouth = 1; *pen = e->dck_rb - lx; *nx = a->c; *ny = a->s;
+            return *pen > RC(0);
+        }
+    }
+    R d2 = dx * dx + dy * dy;
+    if (d2 < e->rs_rb2 && d2 > RC(0)) {
+        R d = R_SQRT(d2), inv = RC(1) / d;
+        *nx = dx * inv; *ny = dy * inv; *pen = e->rs_rb - d;
+        return 1;
+    }
+    *pen = RC(-1); *nx = RC(0); *ny = RC(0);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * robosim.step(cmds) — rsim.py:102 (VSS [N][2]) / rsim.py:155 (SSL [N][8]); cmds already R
+ * ---------------------------------------------------------------------------------------- */
+static void SUF(step_core)(SUF(rsxo_env)* e, const R* cmds) {
+    const rsxo_cfg* c = &e->cfg;
+    const int N = c->n_robots, M = N + 1, RS = e->RS, ssl = c->kind == 1;
+    SUF(body) b[MAXBOD];
+    memset(b, 0, sizeof(b));
+    R* s = e->state;
+    /* ---- load + per-step command processing ---- */
+    for (int k = 0; k < N; ++k) {
+        const R* r = s + 5 + RS * k;
+        SUF(body)* o = &b[k];
+        o->x = r[0]; o->y = r[1]; o->th = r[2] * e->deg2rad; o->vx = r[3]; o->vy = r[4];
+        o->om = r[5] * e->deg2rad;
+        R_SINCOS(o->th, &o->s, &o->c);
+        if (!ssl) {
+            R wl = SUF(clampr)(cmds[2 * k], -e->w_max, e->w_max);
+            R wr = SUF(clampr)(cmds[2 * k + 1], -e->w_max, e->w_max);
+            o->t0 = (wl + wr) * e->half_rw;
+            o->t1 = (wr - wl) * e->rw_2b;
+        } else {
+            const R* q = cmds + 8 * k;
+            R vtx, vty, omt;
+            if (q[0] != RC(0)) {
+                R w[4];
+                for (int i = 0; i < 4; ++i) w[i] = SUF(clampr)(q[1 + i], -e->w_max, e->w_max);
+                vtx = (((e->pinv[0][0] * w[0] + e->pinv[0][1] * w[1]) + e->pinv[0][2] * w[2]) + e->pinv[0][3] * w[3]) * e->r_wheel;
+                vty = (((e->pinv[1][0] * w[0] + e->pinv[1][1] * w[1]) + e->pinv[1][2] * w[2]) + e->pinv[1][3] * w[3]) * e->r_wheel;
+                omt = (((e->pinv[2][0] * w[0] + e->pinv[2][1] * w[1]) + e->pinv[2][2] * w[2]) + e->pinv[2][3] * w[3]) * e->r_wheel;
+            } else {
+                vtx = q[1]; vty = q[2]; omt = q[3];
+                R m = RC(0);
+                for (int i = 0; i < 4; ++i) {
+                    R wi = ((vty * e->wc[i] - vtx * e->ws[i]) + omt * e->r_robot) * e->inv_rw;
+                    R a = R_FABS(wi);
+                    if (a > m) m = a;
+                }
+                if (m > e->w_max) { R sc = e->w_max / m; vtx = vtx * sc; vty = vty * sc; omt = omt * sc; }
+            }
+            o->t0 = vtx; o->t1 = vty; o->t2 = omt;
+            o->kick_x = q[5]; o->kick_z = q[6]; o->drib = q[7] != RC(0);
+        }
+    }
+    SUF(body)* ball = &b[N];
+    ball->x = s[0]; ball->y = s[1]; ball->z = s[2] - e->r_ball; ball->vx = s[3]; ball->vy = s[4];
+    ball->vz = s[e->state_dim];
+
+    for (int sub = 0; sub < c->n_sub; ++sub) {
+        /* ---- A: actuation + integration ---- */
+        for (int k = 0; k < N; ++k) {
+            SUF(body)* o = &b[k];
+            R vf = o->vx * o->c + o->vy * o->s;
+            R vl = o->vy * o->c - o->vx * o->s;
+            if (!ssl) {
+                vf = vf + SUF(clampr)(o->t0 - vf, -e->a_lin_h, e->a_lin_h);
+                vl = vl - SUF(clampr)(vl, -e->a_lat_h, e->a_lat_h);
+                o->om = o->om + SUF(clampr)(o->t1 - o->om, -e->a_ang_h, e->a_ang_h);
+            } else {
+                R dx = o->t0 - vf, dy = o->t1 - vl;
+                R d2 = dx * dx + dy * dy;
+                if (d2 > e->a_lin_h2) { R sc = e->a_lin_h / R_SQRT(d2); dx = dx * sc; dy = dy * sc; }
+                vf = vf + dx; vl = vl + dy;
+                o->om = o->om + SUF(clampr)(o->t2 - o->om, -e->a_ang_h, e->a_ang_h);
+            }
+            o->vx = vf * o->c - vl * o->s;
+            o->vy = vf * o->s + vl * o->c;
+            o->x = o->x + o->vx * e->h;
+            o->y = o->y + o->vy * e->h;
+            o->th = o->th + o->om * e->h;
+            if (o->th > e->pi) o->th = o->th - e->two_pi;
+            else if (o->th < -e->pi) o->th = o->th + e->two_pi;
+            R_SINCOS(o->th, &o->s, &o->c);
+        }
+        if (ball->z > RC(0) || ball->vz > RC(0)) {
+            ball->vz = ball->vz - e->g_h;
+            ball->z = ball->z + ball->vz * e->h;
+            if (ball->z <= RC(0)) {
+                ball->z = RC(0);
+                ball->vz = -ball->vz * e->e_ground;
+                if (ball->vz < e->vz_min) ball->vz = RC(0);
+            }
+        } else {
+            R sp2 = ball->vx * ball->vx + ball->vy * ball->vy;
+            if (sp2 > RC(0)) {
+                R sp = R_SQRT(sp2), ns = sp - e->mu_g_h;
+                if (ns < RC(0)) ns = RC(0);
+                R k = ns / sp;
+                ball->vx = ball->vx * k; ball->vy = ball->vy * k;
+            }
+        }
+        ball->x = ball->x + ball->vx * e->h;
+        ball->y = ball->y + ball->vy * e->h;
+
+        /* ---- B: contacts, Jacobi over the post-integration snapshot ---- */
+        R dvx[MAXBOD], dvy[MAXBOD], dpx[MAXBOD], dpy[MAXBOD];
+        int ovr = 0; R ovx = RC(0), ovy = RC(0), ovz = RC(0); int okick = 0;
+        for (int i = 0; i < M; ++i) {
+            R avx = RC(0), avy = RC(0), apx = RC(0), apy = RC(0);
+            for (int j = 0; j < M; ++j) {
+                if (j == i) continue;
+                if (i < N && j < N) { /* robot - robot */
+                    R dx = b[j].x - b[i].x, dy = b[j].y - b[i].y;
+                    R d2 = dx * dx + dy * dy;
+                    if (d2 < e->rs_rr2 && d2 > RC(0)) {
+                        R d = R_SQRT(d2), inv = RC(1) / d;
+                        R nx = dx * inv, ny = dy * inv, pen = e->rs_rr - d;
+                        R vn = (b[j].vx - b[i].vx) * nx + (b[j].vy - b[i].vy) * ny;
+                        if (vn < RC(0)) { R q = e->ope_rr * vn * e->w_rr; avx = avx + q * nx; avy = avy + q * ny; }
+                        R pc = e->beta * pen * e->w_rr;
+                        apx = apx - pc * nx; apy = apy - pc * ny;
+                    }
+                } else if (i < N) { /* robot i, ball j */
+                    R nx, ny, pen; int mouth;
+                    int touch = SUF(rb_geom)(e, &b[i], ball, &nx, &ny, &pen, &mouth);
+                    if (touch) {
+                        R vn = (ball->vx - b[i].vx) * nx + (ball->vy - b[i].vy) * ny;
+                        if (vn < RC(0)) { R q = e->ope_rb * vn * e->w_rb_r; avx = avx + q * nx; avy = avy + q * ny; }
+                        R pc = e->beta * pen * e->w_rb_r;
+                        apx = apx - pc * nx; apy = apy - pc * ny;
+                    }
+                    b[i].ir = mouth && pen > -e->ir_tol;
+                } else { /* ball i, robot j */
+                    R nx, ny, pen; int mouth;
+                    int touch = SUF(rb_geom)(e, &b[j], ball, &nx, &ny, &pen, &mouth);
+                    if (touch) {
+                        R vn = (ball->vx - b[j].vx) * nx + (ball->vy - b[j].vy) * ny;
+                        if (vn < RC(0)) { R q = e->ope_rb * vn * e->w_rb_b; avx = avx - q * nx; avy = avy - q * ny; }
+                        R pc = e->beta * pen * e->w_rb_b;
+                        apx = apx + pc * nx; apy = apy + pc * ny;
+                    }
+                    if (mouth && pen > -e->ir_tol) { /* infrared: kicker / dribbler act */
+                        if (b[j].kick_x > RC(0) || b[j].kick_z > RC(0)) {
+                            ovr = 1; okick = 1;
+                            ovx = b[j].vx + b[j].kick_x * b[j].c;
+                            ovy = b[j].vy + b[j].kick_x * b[j].s;
+                            ovz = b[j].kick_z;
+                        } else if (b[j].drib) {
+                            R hx = b[j].x + e->dck_rb * b[j].c, hy = b[j].y + e->dck_rb * b[j].s;
+                            R cvx = (hx - ball->x) * e->drib_gain, cvy = (hy - ball->y) * e->drib_gain;
+                            R m2 = cvx * cvx + cvy * cvy;
+                            if (m2 > e->drib_vmax2) { R sc = e->drib_vmax / R_SQRT(m2); cvx = cvx * sc; cvy = cvy * sc; }
+                            ovr = 1; okick = 0;
+                            ovx = (b[j].vx - b[j].om * e->dck_rb * b[j].s) + cvx;
+                            ovy = (b[j].vy + b[j].om * e->dck_rb * b[j].c) + cvy;
+                        }
+                    }
+                }
+            }
+            dvx[i] = avx; dvy[i] = avy; dpx[i] = apx; dpy[i] = apy;
+        }
+        for (int i = 0; i < M; ++i) {
+            b[i].vx = b[i].vx + dvx[i]; b[i].vy = b[i].vy + dvy[i];
+            b[i].x = b[i].x + dpx[i]; b[i].y = b[i].y + dpy[i];
+        }
+        if (ovr) {
+            ball->vx = ovx; ball->vy = ovy;
+            if (okick && ovz > RC(0)) ball->vz = ovz;
+        }
+        /* ---- C: walls ---- */
+        for (int k = 0; k < N; ++k) SUF(walls)(e, e->r_robot, e->e_wr, &b[k].x, &b[k].y, &b[k].vx, &b[k].vy);
+        SUF(walls)(e, e->r_ball, e->e_wb, &ball->x, &ball->y, &ball->vx, &ball->vy);
+    }
+    /* ---- store ---- */
+    s[0] = ball->x; s[1] = ball->y; s[2] = e->r_ball + ball->z; s[3] = ball->vx; s[4] = ball->vy;
+    s[e->state_dim] = ball->vz;
+    for (int k = 0; k < N; ++k) {
+        R* r = s + 5 + RS * k;
+        const SUF(body)* o = &b[k];
+        r[0] = o->x; r[1] = o->y; r[2] = o->th * e->rad2deg; r[3] = o->vx; r[4] = o->vy;
+        r[5] = o->om * e->rad2deg;
+        if (ssl) {
+            r[6] = c->n_sub ? (o->ir ? RC(1) : RC(0)) : r[6];
+            R vf = o->vx * o->c + o->vy * o->s;
+            R vl = o->vy * o->c - o->vx * o->s;
+            for (int i = 0; i < 4; ++i)
+                r[7 + i] = ((vl * e->wc[i] - vf * e->ws[i]) + o->om * e->r_robot) * e->inv_rw;
+        }
+    }
+}
+
+void SUF(rsxo_step)(void* p, const double* cmds) {
+    SUF(rsxo_env)* e = (SUF(rsxo_env)*)p;
+    R q[MAXROB * 8];
+    int n = e->cfg.n_robots * (e->cfg.kind == 0 ? 2 : 8);
+    for (int i = 0; i < n; ++i) q[i] = RC(cmds[i]);
+    SUF(step_core)(e, q);
+}
+
+/* ==========================================================================================
+ * TASKS
+ * ======================================================================================== */
+static inline R SUF(u01)(uint32_t x) { return RC(x >> 8) * RC(5.9604644775390625e-08); }
+
+static void SUF(draw)(const SUF(rsxo_env)* e, uint32_t tick, uint32_t dom, uint32_t out[4]) {
+    uint32_t ctr[4] = {e->env_id, e->episode, tick, dom};
+    rsxo_philox4x32_10(ctr, e->key, out);
+}
+
+int SUF(rsxo_task_attach)(void* p, int task, uint64_t seed, uint64_t env_id, int max_steps) {
+    SUF(rsxo_env)* e = (SUF(rsxo_env)*)p;
+    const rsxo_cfg* c = &e->cfg;
+    const double* f = c->field;
+    if (task == 1) {
+        if (c->kind != 0 || c->n_blue < 1) return -1;
+        e->obs_dim = 4 + 7 * c->n_blue + 5 * c->n_yellow; e->act_dim = 2; e->info_dim = 6;
+        e->max_steps = max_steps > 0 ? max_steps : 1200;
+    } else if (task == 2) {
+        if (c->kind != 1 || c->n_blue != 1) return -1;
+        e->obs_dim = 4 + 8 * c->n_blue + 2 * c->n_yellow; e->act_dim = 5; e->info_dim = 8;
+        e->max_steps = max_steps > 0 ? max_steps : 1000;
+    } else return -1;
+    e->task = task;
+    e->key[0] = (uint32_t)seed; e->key[1] = (uint32_t)(seed >> 32);
+    e->env_id = (uint32_t)env_id; e->episode = 0; e->steps = 0;
+    /* normalisers — vss_gym_base.py:52-58 / ssl_gym_base.py:53-59 */
+    double max_pos = fmax(f[1] / 2, f[0] / 2 + f[2]);
+    double max_v = (f[16] / 60.0) * 2.0 * RSXO_PI * f[15];
+    double max_w = (max_v / (c->kind == 0 ? 0.04 : 0.095)) * (180.0 / RSXO_PI);
+    if (task == 2) { max_v = 2.5; max_w = 10.0; } /* static_defenders.py:76-77 */
+    e->max_pos = RC(max_pos); e->inv_max_pos = RC(1.0 / max_pos);
+    e->max_v = RC(max_v); e->inv_max_v = RC(1.0 / max_v); e->inv_max_w = RC(1.0 / max_w);
+    e->deadzone = RC(0.05);
+    double dt = c->time_step_ms * 0.001;
+    e->hl_goal = RC(f[0] / 2.0 + f[5]); e->inv_len_cm = RC(1.0 / (f[0] * 100.0));
+    e->inv_dt = RC(dt > 0 ? 1.0 / dt : 0.0);
+    e->pen_x = RC(f[0] / 2 - f[2]); e->half_pen_wid = RC(f[3] / 2);
+    e->inv_bd_scale = RC(1.0 / sqrt(f[1] * f[1] + (f[0] / 2) * (f[0] / 2)));
+    e->inv_bg_scale = RC(1.0 / (sqrt((f[1] / 2) * (f[1] / 2) + (f[0] / 2) * (f[0] / 2)) / 4.0));
+    e->inv_en_scale = RC(1.0 / (160.0 * 4.0 * 1000.0));
+    if (task == 1) { /* vss_gym.py:199-206 */
+        e->pl_xlo = RC(-(f[0] / 2) + 0.1); e->pl_xspan = RC((f[0] / 2 - 0.1) - (-(f[0] / 2) + 0.1));
+        e->pl_min_d2 = RC(0.1 * 0.1);
+    } else {         /* static_defenders.py:221-225 */
+        e->pl_xlo = RC(0.2); e->pl_xspan = RC((f[0] / 2 - 0.1) - 0.2);
+        e->pl_min_d2 = RC(0.2 * 0.2);
+    }
+    e->pl_ylo = RC(-(f[1] / 2) + 0.1); e->pl_yspan = RC((f[1] / 2 - 0.1) - (-(f[1] / 2) + 0.1));
+    e->ou_theta_dt = RC(0.17 * dt);          /* Utils.py:6,17 */
+    e->ou_sig_sqdt = RC(0.5 * sqrt(dt));     /* Utils.py:8,18 */
+    memset(e->metrics, 0, sizeof(e->metrics));
+    return 0;
+}
+
+/* ---- observations: vss_gym.py:93-117 / static_defenders.py:90-112 ---- */
+static void SUF(task_obs)(const SUF(rsxo_env)* e, R* o) {
+    const rsxo_cfg* c = &e->cfg;
+    const R* s = e->state;
+    const R lo = RC(-1.2), hi = RC(1.2);
+    int n = 0;
+    o[n++] = SUF(clampr)(s[0] * e->inv_max_pos, lo, hi);
+    o[n++] = SUF(clampr)(s[1] * e->inv_max_pos, lo, hi);
+    o[n++] = SUF(clampr)(s[3] * e->inv_max_v, lo, hi);
+    o[n++] = SUF(clampr)(s[4] * e->inv_max_v, lo, hi);
+    for (int k = 0; k < c->n_blue; ++k) {
+        const R* r = s + 5 + e->RS * k;
+        R sn, cs;
+        R_SINCOS(r[2] * e->deg2rad, &sn, &cs);
+        o[n++] = SUF(clampr)(r[0] * e->inv_max_pos, lo, hi);
+        o[n++] = SUF(clampr)(r[1] * e->inv_max_pos, lo, hi);
+        o[n++] = sn; o[n++] = cs;
+        o[n++] = SUF(clampr)(r[3] * e->inv_max_v, lo, hi);
+        o[n++] = SUF(clampr)(r[4] * e->inv_max_v, lo, hi);
+        o[n++] = SUF(clampr)(r[5] * e->inv_max_w, lo, hi);
+        if (e->task == 2) o[n++] = r[6] != RC(0) ? RC(1) : RC(0);
+    }
+    for (int k = c->n_blue; k < c->n_robots; ++k) {
+        const R* r = s + 5 + e->RS * k;
+        o[n++] = SUF(clampr)(r[0] * e->inv_max_pos, lo, hi);
+        o[n++] = SUF(clampr)(r[1] * e->inv_max_pos, lo, hi);
+        if (e->task == 1) {
+            o[n++] = SUF(clampr)(r[3] * e->inv_max_v, lo, hi);
+            o[n++] = SUF(clampr)(r[4] * e->inv_max_v, lo, hi);
+            o[n++] = SUF(clampr)(r[5] * e->inv_max_w, lo, hi);
+        }
+    }
+}
+
+/* ---- commands ---- */
+/* vss_gym.py:235-254 */
+static inline R SUF(vss_wheel)(const SUF(rsxo_env)* e, R a) {
+    R v = a * e->max_v;
+    v = SUF(clampr)(v, -e->max_v, e->max_v);
+    if (-e->deadzone < v && v < e->deadzone) v = RC(0);
+    return v * e->inv_rw;
+}
+/* per-robot actions [N][2] -> cmds [N][2] */
+static void SUF(vss_cmds)(const SUF(rsxo_env)* e, const R* act, R* cmds) {
+    for (int k = 0; k < e->cfg.n_robots; ++k) {
+        cmds[2 * k] = SUF(vss_wheel)(e, act[2 * k]);
+        cmds[2 * k + 1] = SUF(vss_wheel)(e, act[2 * k + 1]);
+    }
+}
+/* static_defenders.py:114-148; theta_deg = pre-step heading of blue 0 */
+static void SUF(sd_cmds)(const SUF(rsxo_env)* e, const R* a, R theta_deg, R* cmds) {
+    memset(cmds, 0, sizeof(R) * 8 * e->cfg.n_robots);
+    R sn, cs;
+    R_SINCOS(theta_deg * e->deg2rad, &sn, &cs);
+    R gx = a[0] * e->max_v, gy = a[1] * e->max_v, vth = a[2] * RC(10.0);
+    R lx = gx * cs + gy * sn, ly = gy * cs - gx * sn;
+    R nrm = R_SQRT(lx * lx + ly * ly);
+    if (!(nrm < e->max_v)) { R sc = e->max_v / nrm; lx = lx * sc; ly = ly * sc; }
+    cmds[1] = lx; cmds[2] = ly; cmds[3] = vth;
+    cmds[5] = a[3] > RC(0) ? RC(5.0) : RC(0);
+    cmds[7] = a[4] > RC(0) ? RC(1) : RC(0);
+}
+
+/* ---- reward / done; `last` = pre-step state (the reference's last_frame) ---- */
+static void SUF(task_reward)(SUF(rsxo_env)* e, const R* last, const R* cmds, int first_step) {
+    const R* s = e->state;
+    R reward = RC(0); int done = 0;
+    if (e->task == 1) { /* vss_gym.py:144-192,256-311 */
+        R bx = s[0], by = s[1];
+        if (bx > e->half_len) { e->info[0] += RC(1); e->info[4] += RC(1); reward = RC(10); done = 1; }
+        else if (bx < -e->half_len) { e->info[0] -= RC(1); e->info[5] += RC(1); reward = RC(-10); done = 1; }
+        else {
+            R dx_d = (e->hl_goal + bx) * RC(100), dx_a = (e->hl_goal - bx) * RC(100), dy = by * RC(100);
+            R dy2 = RC(2) * (dy * dy);
+            R dist_1 = -R_SQRT(dx_a * dx_a + dy2), dist_2 = R_SQRT(dx_d * dx_d + dy2);
+            R pot = ((dist_1 + dist_2) * e->inv_len_cm - RC(1)) * RC(0.5);
+            R grad = RC(0);
+            if (!first_step) grad = SUF(clampr)((pot - e->prev_pot) * RC(3) * e->inv_dt, RC(-5), RC(5));
+            e->prev_pot = pot;
+            const R* r0 = s + 5;
+            R rbx = bx - r0[0], rby = by - r0[1];
+            R nrm = R_SQRT(rbx * rbx + rby * rby);
+            R mv = (rbx / nrm) * r0[3] + (rby / nrm) * r0[4];
+            R move = SUF(clampr)(mv * RC(2.5), RC(-5), RC(5));
+            R energy = -(R_FABS(cmds[0]) + R_FABS(cmds[1]));
+            R t_move = RC(0.2) * move, t_grad = RC(0.8) * grad, t_en = RC(2e-4) * energy;
+            reward = (t_move + t_grad) + t_en;
+            e->info[1] += t_move; e->info[2] += t_grad; e->info[3] += t_en;
+        }
+    } else { /* static_defenders.py:150-212,256-322 */
+        const R* r0 = s + 5;
+        R bx = s[0], by = s[1], rx = r0[0], ry = r0[1];
+        if (rx < RC(-0.2) || R_FABS(ry) > e->half_wid) { done = 1; e->info[4] += RC(1); }
+        else if (rx > e->pen_x && R_FABS(ry) < e->half_pen_wid) { done = 1; e->info[1] += RC(1); }
+        else if (bx < RC(0) || R_FABS(by) > e->half_wid) { done = 1; e->info[2] += RC(1); }
+        else if (bx > e->half_len) {
+            done = 1;
+            if (R_FABS(by) < e->ghw) { reward = RC(5); e->info[0] += RC(1); }
+            else e->info[3] += RC(1);
+        } else {
+            const R* l0 = last + 5;
+            R lbx = last[0], lby = last[1];
+            R ldx = l0[0] - lbx, ldy = l0[1] - lby;
+            R cdx = rx - bx, cdy = ry - by;
+            R bd = SUF(clampr)(R_SQRT(ldx * ldx + ldy * ldy) - R_SQRT(cdx * cdx + cdy * cdy), RC(-1), RC(1)) * e->inv_bd_scale;
+            R lgx = e->half_len - lbx, cgx = e->half_len - bx;
+            R bg = SUF(clampr)(R_SQRT(lgx * lgx + lby * lby) - R_SQRT(cgx * cgx + by * by), RC(-1), RC(1)) * e->inv_bg_scale;
+            R en = -(((R_FABS(r0[7]) + R_FABS(r0[8])) + R_FABS(r0[9])) + R_FABS(r0[10])) * e->inv_en_scale;
+            e->info[5] += bd; e->info[6] += bg; e->info[7] += en;
+            reward = (bd + bg) + en;
+        }
+    }
+    e->reward = reward; e->terminated = (uint8_t)done;
+}
+
+/* ---- placement: vss_gym.py:194-233 / static_defenders.py:214-254 with Philox draws ---- */
+static void SUF(task_place)(SUF(rsxo_env)* e) {
+    const rsxo_cfg* c = &e->cfg;
+    R* s = e->state;
+    memset(s, 0, sizeof(e->state));
+    s[2] = e->r_ball;
+    uint32_t n = 0, u[4];
+    R px[MAXBOD], py[MAXBOD]; int np = 0;
+    int first = 0;
+    if (e->task == 2) { /* blue 0 fixed at the origin */
+        for (int t = 0; t < 64; ++t) {
+            SUF(draw)(e, n++, RSXO_DOM_PLACE, u);
+            s[0] = e->pl_xlo + e->pl_xspan * SUF(u01)(u[0]);
+            s[1] = e->pl_ylo + e->pl_yspan * SUF(u01)(u[1]);
+            if (!(s[0] > e->pen_x && R_FABS(s[1]) < e->half_pen_wid)) break;
+        }
+        px[np] = s[0]; py[np] = s[1]; ++np;
+        px[np] = RC(0); py[np] = RC(0); ++np;
+        first = 1;
+    } else {
+        SUF(draw)(e, n++, RSXO_DOM_PLACE, u);
+        s[0] = e->pl_xlo + e->pl_xspan * SUF(u01)(u[0]);
+        s[1] = e->pl_ylo + e->pl_yspan * SUF(u01)(u[1]);
+        px[np] = s[0]; py[np] = s[1]; ++np;
+    }
+    for (int k = first; k < c->n_robots; ++k) {
+        R x = RC(0), y = RC(0);
+        for (int t = 0; t < 64; ++t) {
+            SUF(draw)(e, n++, RSXO_DOM_PLACE, u);
+            x = e->pl_xlo + e->pl_xspan * SUF(u01)(u[0]);
+            y = e->pl_ylo + e->pl_yspan * SUF(u01)(u[1]);
+            int ok = 1;
+            for (int q = 0; q < np; ++q) {
+                R dx = x - px[q], dy = y - py[q];
+                if (dx * dx + dy * dy < e->pl_min_d2) ok = 0;
+            }
+            if (ok) break;
+        }
+        SUF(draw)(e, n++, RSXO_DOM_PLACE, u);
+        R* r = s + 5 + e->RS * k;
+        r[0] = x; r[1] = y; r[2] = RC(360) * SUF(u01)(u[0]);
+        px[np] = x; py[np] = y; ++np;
+    }
+}
+
+static void SUF(task_begin_episode)(SUF(rsxo_env)* e) {
+    e->steps = 0;
+    memset(e->ou, 0, sizeof(e->ou));
+    SUF(task_obs)(e, e->obs);
+}
+
+void SUF(rsxo_task_reset)(void* p) {
+    SUF(rsxo_env)* e = (SUF(rsxo_env)*)p;
+    SUF(task_place)(e);
+    memset(e->info, 0, sizeof(e->info)); e->ep_ret = RC(0); e->prev_pot = RC(0);
+    SUF(task_begin_episode)(e);
+}
+void SUF(rsxo_task_reset_to)(void* p, const double* ball, const double* blue, const double* yellow) {
+    SUF(rsxo_env)* e = (SUF(rsxo_env)*)p;
+    SUF(rsxo_reset)(p, ball, blue, yellow);
+    memset(e->info, 0, sizeof(e->info)); e->ep_ret = RC(0); e->prev_pot = RC(0);
+    SUF(task_begin_episode)(e);
+}
+
+/* one fused step; action [act_dim] float or NULL = random */
+void SUF(rsxo_task_step)(void* p, const float* action) {
+    SUF(rsxo_env)* e = (SUF(rsxo_env)*)p;
+    const rsxo_cfg* c = &e->cfg;
+    const int N = c->n_robots;
+    uint32_t u[4];
+    const uint32_t t = (uint32_t)e->steps;
+    const int first_step = e->steps == 0;
+    if (first_step) { memset(e->info, 0, sizeof(e->info)); e->ep_ret = RC(0); }
+    R a[8];
+    if (action) for (int i = 0; i < e->act_dim; ++i) a[i] = RC(action[i]);
+    else {
+        SUF(draw)(e, t, RSXO_DOM_ACT, u);
+        for (int i = 0; i < 4 && i < e->act_dim; ++i) a[i] = SUF(u01)(u[i]) * RC(2) - RC(1);
+        if (e->act_dim > 4) {
+            SUF(draw)(e, t, RSXO_DOM_ACT | (1u << 8), u);
+            a[4] = SUF(u01)(u[0]) * RC(2) - RC(1);
+        }
+    }
+    R cmds[MAXROB * 8];
+    R last[5 + 11 * MAXROB + 1];
+    memcpy(last, e->state, sizeof(last));
+    if (e->task == 1) {
+        R act[MAXROB * 2];
+        act[0] = a[0]; act[1] = a[1];
+        for (int k = 1; k < N; ++k) { /* Utils.py:14-21, Box-Muller on Philox */
+            SUF(draw)(e, t, RSXO_DOM_OU | ((uint32_t)k << 8), u);
+            R u1 = RC((u[0] >> 8) + 1u) * RC(5.9604644775390625e-08);
+            R ang = (SUF(u01)(u[1]) - RC(0.5)) * e->two_pi;
+            R rad = R_SQRT(RC(-2) * R_LOG(u1));
+            R sn, cs;
+            R_SINCOS(ang, &sn, &cs);
+            R n0 = rad * cs, n1 = rad * sn;
+            e->ou[k][0] = (e->ou[k][0] + e->ou_theta_dt * (RC(0) - e->ou[k][0])) + e->ou_sig_sqdt * n0;
+            e->ou[k][1] = (e->ou[k][1] + e->ou_theta_dt * (RC(0) - e->ou[k][1])) + e->ou_sig_sqdt * n1;
+            act[2 * k] = e->ou[k][0]; act[2 * k + 1] = e->ou[k][1];
+        }
+        SUF(vss_cmds)(e, act, cmds);
+    } else {
+        SUF(sd_cmds)(e, a, e->state[5 + 2], cmds);
+    }
+    memcpy(e->last_cmds, cmds, sizeof(R) * N * (c->kind == 0 ? 2 : 8));
+    SUF(step_core)(e, cmds);
+    SUF(task_obs)(e, e->obs);
+    SUF(task_reward)(e, last, cmds, first_step);
+    e->steps += 1;
+    e->ep_ret = e->ep_ret + e->reward;
+    e->truncated = (uint8_t)(e->steps >= e->max_steps);
+    e->metrics[0] += 1;
+    if (e->terminated || e->truncated) {
+        memcpy(e->final_obs, e->obs, sizeof(e->obs));
+        e->metrics[1] += 1;
+        if (e->task == 1) { e->metrics[2] += e->info[4] > RC(0); e->metrics[3] += e->info[5] > RC(0); }
+        else e->metrics[2] += e->info[0] > RC(0);
+        e->metrics[4] += (int64_t)llrint((double)(e->ep_ret * RC(1048576.0)));
+        e->metrics[5] += e->steps;
+        e->metrics[6] += e->truncated && !e->terminated;
+        e->episode += 1;
+        SUF(task_place)(e);
+        SUF(task_begin_episode)(e);
+    }
+}
+
+/* outputs (any pointer may be NULL) */
+void SUF(rsxo_task_out)(void* p, double* obs, double* reward, uint8_t* term, uint8_t* trunc,
+                        double* info, double* final_obs, int* steps, int64_t* metrics) {
+    SUF(rsxo_env)* e = (SUF(rsxo_env)*)p;
+    if (obs) for (int i = 0; i < e->obs_dim; ++i) obs[i] = (double)e->obs[i];
+    if (final_obs) for (int i = 0; i < e->obs_dim; ++i) final_obs[i] = (double)e->final_obs[i];
+    if (reward) *reward = (double)e->reward;
+    if (term) *term = e->terminated;
+    if (trunc) *trunc = e->truncated;
+    if (info) for (int i = 0; i < e->info_dim; ++i) info[i] = (double)e->info[i];
+    if (steps) *steps = e->steps;
+    if (metrics) memcpy(metrics, e->metrics, sizeof(e->metrics));
+}
+void SUF(rsxo_task_last_cmds)(void* p, double* out) {
+    SUF(rsxo_env)* e = (SUF(rsxo_env)*)p;
+    int n = e->cfg.n_robots * (e->cfg.kind == 0 ? 2 : 8);
+    for (int i = 0; i < n; ++i) out[i] = (double)e->last_cmds[i];
+}
+
+/* ---- pure task functions exposed for the golden-vector tests ---- */
+/* observation of the CURRENT state */
+void SUF(rsxo_task_obs_eval)(void* p, double* out) {
+    SUF(rsxo_env)* e = (SUF(rsxo_env)*)p;
+    R o[64];
+    SUF(task_obs)(e, o);
+    for (int i = 0; i < e->obs_dim; ++i) out[i] = (double)o[i];
+}
+/* VSS: per-robot actions [N][2] -> cmds [N][2];  SD: action[5] + heading(deg) -> cmds [N][8] */
+void SUF(rsxo_task_cmds_eval)(void* p, const double* act, double theta_deg, double* out) {
+    SUF(rsxo_env)* e = (SUF(rsxo_env)*)p;
+    R a[MAXROB * 2], q[MAXROB * 8];
+    int N = e->cfg.n_robots;
+    if (e->task == 1) {
+        for (int i = 0; i < 2 * N; ++i) a[i] = RC(act[i]);
+        SUF(vss_cmds)(e, a, q);
+        for (int i = 0; i < 2 * N; ++i) out[i] = (double)q[i];
+    } else {
+        for (int i = 0; i < 5; ++i) a[i] = RC(act[i]);
+        SUF(sd_cmds)(e, a, RC(theta_deg), q);
+        for (int i = 0; i < 8 * N; ++i) out[i] = (double)q[i];
+    }
+}
+/* reward/done of the transition last -> CURRENT state with sent commands cmds; updates the
+ * cumulative info and the ball-potential memory exactly as a step would */
+void SUF(rsxo_task_reward_eval)(void* p, const double* last, const double* cmds, int first_step,
+                                double* reward, int* done) {
+    SUF(rsxo_env)* e = (SUF(rsxo_env)*)p;
+    R l[5 + 11 * MAXROB + 1], q[MAXROB * 8];
+    int N = e->cfg.n_robots, C = e->cfg.kind == 0 ? 2 : 8;
+    for (int i = 0; i < e->state_dim; ++i) l[i] = RC(last[i]);
+    for (int i = 0; i < N * C; ++i) q[i] = RC(cmds[i]);
+    if (first_step) { memset(e->info, 0, sizeof(e->info)); }
+    SUF(task_reward)(e, l, q, first_step);
+    *reward = (double)e->reward; *done = e->terminated;
+}
+/* OU update with supplied normals (Utils.py:14-21): x <- x + theta*(0-x)*dt + sigma*sqrt(dt)*n */
+void SUF(rsxo_ou_eval)(void* p, double* x, const double* nrm, int n) {
+    SUF(rsxo_env)* e = (SUF(rsxo_env)*)p;
+    for (int i = 0; i < n; ++i) {
+        R xi = RC(x[i]);
+        xi = (xi + e->ou_theta_dt * (RC(0) - xi)) + e->ou_sig_sqdt * RC(nrm[i]);
+        x[i] = (double)xi;
+    }
+}
+void SUF(rsxo_task_norms)(void* p, double out[3]) {
+    SUF(rsxo_env)* e = (SUF(rsxo_env)*)p;
+    out[0] = 1.0 / (double)e->inv_max_pos; out[1] = (double)e->max_v; out[2] = 1.0 / (double)e->inv_max_w;
+}
+/* elementary functions, for direct comparison with the device versions */
+void SUF(rsxo_sincos_eval)(double a, double* s, double* c) { R ss, cc; R_SINCOS(RC(a), &ss, &cc); *s = ss; *c = cc; }
+double SUF(rsxo_log_eval)(double x) { return (double)R_LOG(RC(x)); }
+
+/* ---- batch helpers for the CPU baseline (bench.py cpu_baseline leg) ---- */
+void SUF(rsxo_vec_task_step)(void** envs, int n_envs, int n_steps) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n_envs; ++i)
+        for (int t = 0; t < n_steps; ++t) SUF(rsxo_task_step)(envs[i], NULL);
+}
+
+#undef RC
+#undef MAXROB
+#undef MAXBOD
