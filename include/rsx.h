@@ -167,8 +167,6 @@ int rsx_task_rollout(rsx_sim* h, int n, void* stream);
  * 4 sum of episode returns in 2^-20 fixed point, 5 sum of episode lengths,
  * 6 truncated episodes, 7 reserved.  Synchronises `stream`. */
 int rsx_read_metrics(rsx_sim* h, int64_t out[RSX_METRICS], void* stream);
-/* device pointer of the same vector (for an in-place RCCL all-reduce of a copy) */
-int rsx_metrics_dev(rsx_sim* h, int64_t** out);
 
 #ifdef __cplusplus
 }

@@ -409,7 +409,7 @@ int SUF(rsxo_task_attach)(void* p, int task, uint64_t seed, uint64_t env_id, int
     } else return -1;
     e->task = task;
     e->key[0] = (uint32_t)seed; e->key[1] = (uint32_t)(seed >> 32);
-    e->env_id = (uint32_t)env_id; e->episode = 0; e->steps = 0;
+    e->env_id = (uint32_t)env_id; e->episode = 0xFFFFFFFFu; e->steps = 0;
     /* normalisers — vss_gym_base.py:52-58 / ssl_gym_base.py:53-59 */
     double max_pos = fmax(f[1] / 2, f[0] / 2 + f[2]);
     double max_v = (f[16] / 60.0) * 2.0 * RSXO_PI * f[15];
@@ -607,12 +607,14 @@ static void SUF(task_begin_episode)(SUF(rsxo_env)* e) {
 
 void SUF(rsxo_task_reset)(void* p) {
     SUF(rsxo_env)* e = (SUF(rsxo_env)*)p;
+    e->episode += 1; /* every reset() opens a new episode id (first one: 0) */
     SUF(task_place)(e);
     memset(e->info, 0, sizeof(e->info)); e->ep_ret = RC(0); e->prev_pot = RC(0);
     SUF(task_begin_episode)(e);
 }
 void SUF(rsxo_task_reset_to)(void* p, const double* ball, const double* blue, const double* yellow) {
     SUF(rsxo_env)* e = (SUF(rsxo_env)*)p;
+    e->episode += 1;
     SUF(rsxo_reset)(p, ball, blue, yellow);
     memset(e->info, 0, sizeof(e->info)); e->ep_ret = RC(0); e->prev_pot = RC(0);
     SUF(task_begin_episode)(e);

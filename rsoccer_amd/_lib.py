@@ -1,0 +1,267 @@
+"""ctypes binding of librsx_hip.so — the C-ABI declared in include/rsx.h.
+
+This is the binding the reference would hold in place of ``import robosim``
+(rsoccer_gym/Simulators/rsim.py:2).  It fails loudly when the HIP library is missing or no
+GPU is visible: the product has no CPU path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librsx_hip.so")
+
+KIND_VSS, KIND_SSL = 0, 1
+TASK_NONE, TASK_VSS_V0, TASK_SSL_STATIC_DEFENDERS = 0, 1, 2
+FIELD_KEYS = (
+    "length", "width", "penalty_length", "penalty_width", "goal_width", "goal_depth",
+    "ball_radius", "rbt_distance_center_kicker", "rbt_kicker_thickness", "rbt_kicker_width",
+    "rbt_wheel0_angle", "rbt_wheel1_angle", "rbt_wheel2_angle", "rbt_wheel3_angle",
+    "rbt_radius", "rbt_wheel_radius", "rbt_motor_max_rpm",
+)  # Entities/Field.py:5-21
+N_METRICS = 8
+METRIC_NAMES = ("env_steps", "episodes", "goals_for", "goals_against", "return_sum_q20",
+                "episode_len_sum", "truncated_episodes", "reserved")
+
+# every symbol include/rsx.h declares (tests check the library exports each one)
+SYMBOLS = (
+    "rsx_abi_version", "rsx_last_error", "rsx_device_count", "rsx_create", "rsx_destroy",
+    "rsx_get_field_params", "rsx_reset", "rsx_step", "rsx_get_state", "rsx_set_state",
+    "rsx_get_state_full", "rsx_dev_view_get", "rsx_step_dev", "rsx_task_attach",
+    "rsx_task_view_get", "rsx_task_reset", "rsx_task_reset_to", "rsx_task_step",
+    "rsx_task_step_n", "rsx_task_rollout", "rsx_read_metrics",
+)
+
+
+class RsxError(RuntimeError):
+    pass
+
+
+class DevView(C.Structure):
+    _fields_ = [("num_envs", C.c_int32), ("n_robots", C.c_int32), ("state_dim", C.c_int32),
+                ("cmd_dim", C.c_int32), ("state", C.c_void_p), ("cmds", C.c_void_p)]
+
+
+class TaskView(C.Structure):
+    _fields_ = [("task", C.c_int32), ("obs_dim", C.c_int32), ("act_dim", C.c_int32),
+                ("info_dim", C.c_int32), ("max_episode_steps", C.c_int32),
+                ("obs", C.c_void_p), ("reward", C.c_void_p), ("terminated", C.c_void_p),
+                ("truncated", C.c_void_p), ("info", C.c_void_p), ("final_obs", C.c_void_p),
+                ("steps", C.c_void_p), ("actions", C.c_void_p)]
+
+
+_lib = None
+
+
+def load():
+    """Load librsx_hip.so (once).  torch is imported first so that the HIP runtime already in
+    the process (torch ships its own libamdhip64.so.7) is the one the library binds to —
+    device pointers and streams are then shared with torch tensors."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RsxError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). rsoccer_amd has no CPU fallback.")
+    try:
+        import torch  # noqa: F401  (loads libamdhip64 with the right SONAME first)
+    except Exception:
+        pass
+    lib = C.CDLL(LIB_PATH)
+    lib.rsx_last_error.restype = C.c_char_p
+    vp, ip, dp = C.c_void_p, C.c_int, C.POINTER(C.c_double)
+    lib.rsx_create.argtypes = [C.POINTER(vp), ip, ip, ip, ip, ip, ip, ip]
+    lib.rsx_destroy.argtypes = [vp]
+    lib.rsx_get_field_params.argtypes = [vp, dp]
+    lib.rsx_reset.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.rsx_step.argtypes = [vp, vp, vp]
+    lib.rsx_get_state.argtypes = [vp, vp, vp]
+    lib.rsx_set_state.argtypes = [vp, vp, vp]
+    lib.rsx_get_state_full.argtypes = [vp, vp, vp]
+    lib.rsx_dev_view_get.argtypes = [vp, C.POINTER(DevView)]
+    lib.rsx_step_dev.argtypes = [vp, vp]
+    lib.rsx_task_attach.argtypes = [vp, ip, C.c_uint64, C.c_uint64, ip]
+    lib.rsx_task_view_get.argtypes = [vp, C.POINTER(TaskView)]
+    lib.rsx_task_reset.argtypes = [vp, vp]
+    lib.rsx_task_reset_to.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.rsx_task_step.argtypes = [vp, vp, vp]
+    lib.rsx_task_step_n.argtypes = [vp, ip, vp]
+    lib.rsx_task_rollout.argtypes = [vp, ip, vp]
+    lib.rsx_read_metrics.argtypes = [vp, vp, vp]
+    if lib.rsx_abi_version() != 1:
+        raise RsxError("librsx_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise RsxError(f"librsx_hip error {rc}: {load().rsx_last_error().decode()}")
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a, shape):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if a.size != int(np.prod(shape)):
+        raise ValueError(f"expected {shape} values, got {a.shape}")
+    return a.reshape(shape)
+
+
+class _DevArray:
+    """Minimal __cuda_array_interface__ carrier so torch can wrap library-owned memory."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.__cuda_array_interface__ = {
+            "shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2,
+            "strides": None,
+        }
+        self._owner = owner  # keeps the handle alive while a tensor views its memory
+
+
+class Sim:
+    """A batch of ``num_envs`` simulator instances on one GPU (C handle ``rsx_sim``)."""
+
+    def __init__(self, kind, field_type, n_blue, n_yellow, time_step_ms=25, num_envs=1,
+                 device_id=0):
+        self._lib = load()
+        h = C.c_void_p()
+        _chk(self._lib.rsx_create(C.byref(h), kind, field_type, n_blue, n_yellow,
+                                  int(time_step_ms), int(num_envs), int(device_id)))
+        self._h = h
+        self.kind, self.field_type = kind, field_type
+        self.n_blue, self.n_yellow = n_blue, n_yellow
+        self.num_envs, self.device_id = int(num_envs), int(device_id)
+        v = DevView()
+        _chk(self._lib.rsx_dev_view_get(self._h, C.byref(v)))
+        self.n_robots, self.state_dim, self.cmd_dim = v.n_robots, v.state_dim, v.cmd_dim
+        self._view = v
+        self._tview = None
+        self.task = TASK_NONE
+
+    # ---- lifetime ----
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rsx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _stream(stream):
+        if stream is None:
+            return None
+        return C.c_void_p(int(stream))
+
+    # ---- robosim surface (host f64 wire format) ----
+    def get_field_params(self):
+        out = (C.c_double * 17)()
+        _chk(self._lib.rsx_get_field_params(self._h, out))
+        return dict(zip(FIELD_KEYS, [float(x) for x in out]))
+
+    def reset(self, ball, blue, yellow, env_mask=None, stream=None):
+        B = self.num_envs
+        ball = _f64(ball, (B, 4))
+        blue = _f64(blue, (B, self.n_blue, 3)) if self.n_blue else None
+        yellow = _f64(yellow, (B, self.n_yellow, 3)) if self.n_yellow else None
+        m = None if env_mask is None else np.ascontiguousarray(env_mask, dtype=np.uint8)
+        _chk(self._lib.rsx_reset(self._h, _ptr(ball), _ptr(blue), _ptr(yellow), _ptr(m),
+                                 self._stream(stream)))
+
+    def step(self, cmds, stream=None):
+        cmds = _f64(cmds, (self.num_envs, self.n_robots, self.cmd_dim))
+        _chk(self._lib.rsx_step(self._h, _ptr(cmds), self._stream(stream)))
+
+    def get_state(self, stream=None):
+        out = np.empty((self.num_envs, self.state_dim), dtype=np.float64)
+        _chk(self._lib.rsx_get_state(self._h, _ptr(out), self._stream(stream)))
+        return out
+
+    def get_state_full(self, stream=None):
+        out = np.empty((self.num_envs, self.state_dim + 1), dtype=np.float64)
+        _chk(self._lib.rsx_get_state_full(self._h, _ptr(out), self._stream(stream)))
+        return out
+
+    def set_state(self, state, stream=None):
+        s = _f64(state, (self.num_envs, self.state_dim + 1))
+        _chk(self._lib.rsx_set_state(self._h, _ptr(s), self._stream(stream)))
+
+    # ---- device-resident path ----
+    def step_dev(self, stream=None):
+        _chk(self._lib.rsx_step_dev(self._h, self._stream(stream)))
+
+    def _tensor(self, ptr, shape, typestr):
+        import torch
+        return torch.as_tensor(_DevArray(ptr, shape, typestr, self),
+                               device=torch.device("cuda", self.device_id))
+
+    def state_tensor(self):
+        """[state_dim+1, B] float32, zero-copy view of the SoA state."""
+        return self._tensor(self._view.state, (self.state_dim + 1, self.num_envs), "<f4")
+
+    def cmds_tensor(self):
+        """[N*C, B] float32, zero-copy view of the SoA command buffer read by step_dev()."""
+        return self._tensor(self._view.cmds, (self.n_robots * self.cmd_dim, self.num_envs), "<f4")
+
+    # ---- fused tasks ----
+    def task_attach(self, task, seed=0, env_id_base=0, max_episode_steps=0):
+        _chk(self._lib.rsx_task_attach(self._h, task, seed, env_id_base, max_episode_steps))
+        t = TaskView()
+        _chk(self._lib.rsx_task_view_get(self._h, C.byref(t)))
+        self._tview = t
+        self.task = task
+        self.obs_dim, self.act_dim, self.info_dim = t.obs_dim, t.act_dim, t.info_dim
+        self.max_episode_steps = t.max_episode_steps
+
+    def task_tensors(self):
+        t, B = self._tview, self.num_envs
+        return dict(
+            obs=self._tensor(t.obs, (B, t.obs_dim), "<f4"),
+            reward=self._tensor(t.reward, (B,), "<f4"),
+            terminated=self._tensor(t.terminated, (B,), "|u1"),
+            truncated=self._tensor(t.truncated, (B,), "|u1"),
+            info=self._tensor(t.info, (t.info_dim, B), "<f4"),
+            final_obs=self._tensor(t.final_obs, (B, t.obs_dim), "<f4"),
+            steps=self._tensor(t.steps, (B,), "<i4"),
+            actions=self._tensor(t.actions, (B, t.act_dim), "<f4"),
+        )
+
+    def task_reset(self, stream=None):
+        _chk(self._lib.rsx_task_reset(self._h, self._stream(stream)))
+
+    def task_reset_to(self, ball, blue, yellow, env_mask=None, stream=None):
+        B = self.num_envs
+        ball = _f64(ball, (B, 4))
+        blue = _f64(blue, (B, self.n_blue, 3)) if self.n_blue else None
+        yellow = _f64(yellow, (B, self.n_yellow, 3)) if self.n_yellow else None
+        m = None if env_mask is None else np.ascontiguousarray(env_mask, dtype=np.uint8)
+        _chk(self._lib.rsx_task_reset_to(self._h, _ptr(ball), _ptr(blue), _ptr(yellow), _ptr(m),
+                                         self._stream(stream)))
+
+    def task_step(self, actions_ptr=None, stream=None):
+        """actions_ptr: device address of a [B][act_dim] float32 array, or None = random."""
+        p = None if actions_ptr is None else C.c_void_p(int(actions_ptr))
+        _chk(self._lib.rsx_task_step(self._h, p, self._stream(stream)))
+
+    def task_step_n(self, n, stream=None):
+        _chk(self._lib.rsx_task_step_n(self._h, int(n), self._stream(stream)))
+
+    def task_rollout(self, n, stream=None):
+        _chk(self._lib.rsx_task_rollout(self._h, int(n), self._stream(stream)))
+
+    def read_metrics(self, stream=None):
+        out = np.zeros(N_METRICS, dtype=np.int64)
+        _chk(self._lib.rsx_read_metrics(self._h, _ptr(out), self._stream(stream)))
+        return out
+
+
+def device_count():
+    return int(load().rsx_device_count())

@@ -1,0 +1,426 @@
+// rsx_api.hip — host side of librsx_hip.so: the C-ABI declared in include/rsx.h.
+//
+// Stands where the pybind11 module `robosim` stands in the reference (constructed at
+// rsoccer_gym/Simulators/rsim.py:116-124,169-177; stepped at :102,:155; read at :105,:158;
+// reset at :38; field at :50; destroyed at :41).  HIP only: there is no CPU path in this library.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "rsx.h"
+#include "rsx_kernels.hpp"
+
+using namespace rsx;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess)                                                              \
+            return fail(RSX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));   \
+    } while (0)
+
+}  // namespace
+
+struct rsx_sim {
+    Params P;
+    HostModel M;
+    int device = 0;
+    int L = 8;  // lanes per env
+    float* d_state = nullptr;
+    float* d_cmds = nullptr;
+    // task buffers
+    float *d_obs = nullptr, *d_reward = nullptr, *d_info = nullptr, *d_final_obs = nullptr;
+    float *d_ou = nullptr, *d_prev_pot = nullptr, *d_ep_ret = nullptr, *d_actions = nullptr;
+    uint8_t *d_term = nullptr, *d_trunc = nullptr;
+    int* d_steps = nullptr;
+    uint32_t* d_episode = nullptr;
+    unsigned long long* d_metrics = nullptr;
+    long long env_steps = 0;
+    hipStream_t cap_stream = nullptr;
+    std::map<int, hipGraphExec_t> graphs;
+    std::vector<float> h_f32;
+};
+
+namespace {
+
+int pick_lanes(int n_bodies) {
+    int L = n_bodies <= 8 ? 8 : n_bodies <= 16 ? 16 : 32;
+    // RSX_LANES_PER_ENV=64 forces the "one wavefront per env" layout (for A/B measurements)
+    if (const char* s = std::getenv("RSX_LANES_PER_ENV")) {
+        int v = std::atoi(s);
+        if ((v == 8 || v == 16 || v == 32 || v == 64) && v >= L) L = v;
+    }
+    return L;
+}
+
+dim3 grid_for(const rsx_sim* h) {
+    const int G = 64 / h->L;
+    const int tiles = (h->P.num_envs + G - 1) / G;
+    return dim3((unsigned)(((tiles + 7) / 8) * 8));
+}
+
+Buffers buffers_of(const rsx_sim* h, const float* actions) {
+    Buffers b;
+    b.state = h->d_state; b.cmds = h->d_cmds; b.actions = actions;
+    b.obs = h->d_obs; b.reward = h->d_reward; b.terminated = h->d_term; b.truncated = h->d_trunc;
+    b.info = h->d_info; b.final_obs = h->d_final_obs; b.steps = h->d_steps; b.episode = h->d_episode;
+    b.ou = h->d_ou; b.prev_pot = h->d_prev_pot; b.ep_ret = h->d_ep_ret; b.metrics = h->d_metrics;
+    return b;
+}
+
+template <int KIND>
+void launch_sim_L(const rsx_sim* h, hipStream_t s) {
+    const dim3 grid = grid_for(h);
+    const Buffers b = buffers_of(h, nullptr);
+    switch (h->L) {
+        case 8: hipLaunchKernelGGL((sim_step_kernel<KIND, 8>), grid, dim3(64), 0, s, h->P, b); break;
+        case 16: hipLaunchKernelGGL((sim_step_kernel<KIND, 16>), grid, dim3(64), 0, s, h->P, b); break;
+        case 32: hipLaunchKernelGGL((sim_step_kernel<KIND, 32>), grid, dim3(64), 0, s, h->P, b); break;
+        default: hipLaunchKernelGGL((sim_step_kernel<KIND, 64>), grid, dim3(64), 0, s, h->P, b); break;
+    }
+}
+
+void launch_sim(const rsx_sim* h, hipStream_t s) {
+    if (h->P.kind == RSX_KIND_VSS) launch_sim_L<RSX_KIND_VSS>(h, s);
+    else launch_sim_L<RSX_KIND_SSL>(h, s);
+}
+
+template <int KIND, int TASK>
+void launch_task_L(const rsx_sim* h, const float* actions, int n_steps, int mode, hipStream_t s) {
+    const dim3 grid = grid_for(h);
+    const Buffers b = buffers_of(h, actions);
+    switch (h->L) {
+        case 8: hipLaunchKernelGGL((task_step_kernel<KIND, 8, TASK>), grid, dim3(64), 0, s, h->P, b, n_steps, mode); break;
+        case 16: hipLaunchKernelGGL((task_step_kernel<KIND, 16, TASK>), grid, dim3(64), 0, s, h->P, b, n_steps, mode); break;
+        case 32: hipLaunchKernelGGL((task_step_kernel<KIND, 32, TASK>), grid, dim3(64), 0, s, h->P, b, n_steps, mode); break;
+        default: hipLaunchKernelGGL((task_step_kernel<KIND, 64, TASK>), grid, dim3(64), 0, s, h->P, b, n_steps, mode); break;
+    }
+}
+
+void launch_task(const rsx_sim* h, const float* actions, int n_steps, int mode, hipStream_t s) {
+    if (h->P.task == RSX_TASK_VSS_V0) launch_task_L<RSX_KIND_VSS, RSX_TASK_VSS_V0>(h, actions, n_steps, mode, s);
+    else launch_task_L<RSX_KIND_SSL, RSX_TASK_SSL_STATIC_DEFENDERS>(h, actions, n_steps, mode, s);
+}
+
+int check(const rsx_sim* h) {
+    if (!h) return fail(RSX_ERR_ARG, "null handle");
+    hipError_t e = hipSetDevice(h->device);
+    if (e != hipSuccess) return fail(RSX_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    return RSX_OK;
+}
+
+int check_task(const rsx_sim* h) {
+    if (int rc = check(h)) return rc;
+    if (h->P.task == RSX_TASK_NONE) return fail(RSX_ERR_STATE, "no task attached (rsx_task_attach)");
+    return RSX_OK;
+}
+
+// host f64 AoS [B][S'] <-> device f32 SoA [S'][B]
+int upload_state(rsx_sim* h, const std::vector<float>& soa, hipStream_t s) {
+    HIP_TRY(hipMemcpyAsync(h->d_state, soa.data(), soa.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return RSX_OK;
+}
+int download_state(rsx_sim* h, std::vector<float>& soa, hipStream_t s) {
+    soa.resize((size_t)(h->P.state_dim + 1) * h->P.num_envs);
+    HIP_TRY(hipMemcpyAsync(soa.data(), h->d_state, soa.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return RSX_OK;
+}
+
+// write the teleport of rsim.py:52-75 into a host SoA copy
+void apply_reset(const rsx_sim* h, std::vector<float>& soa, const double* ball, const double* blue,
+                 const double* yellow, const uint8_t* mask) {
+    const Params& P = h->P;
+    const size_t B = (size_t)P.num_envs;
+    for (size_t e = 0; e < B; ++e) {
+        if (mask && !mask[e]) continue;
+        for (int f = 0; f <= P.state_dim; ++f) soa[(size_t)f * B + e] = 0.0f;
+        const double* bl = ball + 4 * e;
+        soa[0 * B + e] = (float)bl[0]; soa[1 * B + e] = (float)bl[1]; soa[2 * B + e] = P.r_ball;
+        soa[3 * B + e] = (float)bl[2]; soa[4 * B + e] = (float)bl[3];
+        for (int k = 0; k < P.n_robots; ++k) {
+            const double* src = k < P.n_blue ? blue + ((size_t)e * P.n_blue + k) * 3
+                                             : yellow + ((size_t)e * P.n_yellow + (k - P.n_blue)) * 3;
+            const size_t r = (size_t)(5 + P.rs * k);
+            soa[(r + 0) * B + e] = (float)src[0];
+            soa[(r + 1) * B + e] = (float)src[1];
+            soa[(r + 2) * B + e] = (float)src[2];
+        }
+    }
+}
+
+void free_all(rsx_sim* h) {
+    for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
+    h->graphs.clear();
+    if (h->cap_stream) hipStreamDestroy(h->cap_stream);
+    void* ptrs[] = {h->d_state, h->d_cmds, h->d_obs, h->d_reward, h->d_info, h->d_final_obs, h->d_ou,
+                    h->d_prev_pot, h->d_ep_ret, h->d_actions, h->d_term, h->d_trunc, h->d_steps,
+                    h->d_episode, h->d_metrics};
+    for (void* p : ptrs) if (p) hipFree(p);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rsx_abi_version(void) { return RSX_ABI_VERSION; }
+const char* rsx_last_error(void) { return g_err.c_str(); }
+
+int rsx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rsx_create(rsx_sim** out, int kind, int field_type, int n_blue, int n_yellow, int time_step_ms,
+               int num_envs, int device_id) {
+    if (!out) return fail(RSX_ERR_ARG, "out is null");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(RSX_ERR_NO_DEVICE, "no HIP device visible: librsx_hip has no CPU path");
+    if (device_id < 0 || device_id >= ndev) return fail(RSX_ERR_ARG, "device_id out of range");
+    rsx_sim* h = new rsx_sim();
+    if (derive_model(kind, field_type, n_blue, n_yellow, time_step_ms, num_envs, h->P, h->M)) {
+        delete h;
+        return fail(RSX_ERR_ARG, "bad simulator configuration (kind / field_type / robot counts / time step / num_envs)");
+    }
+    h->device = device_id;
+    h->L = pick_lanes(h->P.n_robots + 1);
+    auto bail = [&](hipError_t e, const char* what) {
+        std::string m = std::string(what) + ": " + hipGetErrorString(e);
+        free_all(h); delete h;
+        return fail(RSX_ERR_HIP, m);
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(device_id)) != hipSuccess) return bail(e, "hipSetDevice");
+    const size_t B = (size_t)num_envs;
+    const size_t sbytes = (size_t)(h->P.state_dim + 1) * B * sizeof(float);
+    const size_t cbytes = (size_t)h->P.n_robots * h->P.cmd_dim * B * sizeof(float);
+    if ((e = hipMalloc(&h->d_state, sbytes)) != hipSuccess) return bail(e, "hipMalloc(state)");
+    if ((e = hipMalloc(&h->d_cmds, cbytes)) != hipSuccess) return bail(e, "hipMalloc(cmds)");
+    if ((e = hipMemset(h->d_cmds, 0, cbytes)) != hipSuccess) return bail(e, "hipMemset(cmds)");
+    if ((e = hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    // the adapter's dummy line-up, rsim.py:20-24
+    std::vector<float> soa((size_t)(h->P.state_dim + 1) * B, 0.0f);
+    for (size_t i = 0; i < B; ++i) {
+        soa[2 * B + i] = h->P.r_ball;
+        for (int k = 0; k < h->P.n_robots; ++k) {
+            const int j = k < n_blue ? k + 1 : k - n_blue + 1;
+            soa[(size_t)(5 + h->P.rs * k) * B + i] = (float)((k < n_blue ? -0.2 : 0.2) * j);
+        }
+    }
+    if ((e = hipMemcpy(h->d_state, soa.data(), sbytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(state)");
+    *out = h;
+    return RSX_OK;
+}
+
+int rsx_destroy(rsx_sim* h) {
+    if (!h) return RSX_OK;
+    hipSetDevice(h->device);
+    free_all(h);
+    delete h;
+    return RSX_OK;
+}
+
+int rsx_get_field_params(const rsx_sim* h, double out[RSX_FIELD_PARAMS]) {
+    if (!h || !out) return fail(RSX_ERR_ARG, "null argument");
+    std::memcpy(out, h->M.field, sizeof(double) * RSX_FIELD_PARAMS);
+    return RSX_OK;
+}
+
+int rsx_reset(rsx_sim* h, const double* ball, const double* blue, const double* yellow,
+              const uint8_t* env_mask, void* stream) {
+    if (int rc = check(h)) return rc;
+    if (!ball || (h->P.n_blue && !blue) || (h->P.n_yellow && !yellow)) return fail(RSX_ERR_ARG, "null placement array");
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<float> soa;
+    if (env_mask) { if (int rc = download_state(h, soa, s)) return rc; }
+    else soa.assign((size_t)(h->P.state_dim + 1) * h->P.num_envs, 0.0f);
+    apply_reset(h, soa, ball, blue, yellow, env_mask);
+    return upload_state(h, soa, s);
+}
+
+int rsx_step(rsx_sim* h, const double* cmds, void* stream) {
+    if (int rc = check(h)) return rc;
+    if (!cmds) return fail(RSX_ERR_ARG, "cmds is null");
+    hipStream_t s = (hipStream_t)stream;
+    const Params& P = h->P;
+    const size_t B = (size_t)P.num_envs, NC = (size_t)P.n_robots * P.cmd_dim;
+    h->h_f32.resize(NC * B);
+    for (size_t e = 0; e < B; ++e)
+        for (size_t j = 0; j < NC; ++j) h->h_f32[j * B + e] = (float)cmds[e * NC + j];
+    HIP_TRY(hipMemcpyAsync(h->d_cmds, h->h_f32.data(), NC * B * sizeof(float), hipMemcpyHostToDevice, s));
+    launch_sim(h, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    return RSX_OK;
+}
+
+static int get_state_impl(rsx_sim* h, double* out, int rows, hipStream_t s) {
+    std::vector<float> soa;
+    if (int rc = download_state(h, soa, s)) return rc;
+    const size_t B = (size_t)h->P.num_envs;
+    for (size_t e = 0; e < B; ++e)
+        for (int f = 0; f < rows; ++f) out[e * rows + f] = (double)soa[(size_t)f * B + e];
+    return RSX_OK;
+}
+
+int rsx_get_state(rsx_sim* h, double* out, void* stream) {
+    if (int rc = check(h)) return rc;
+    if (!out) return fail(RSX_ERR_ARG, "out is null");
+    return get_state_impl(h, out, h->P.state_dim, (hipStream_t)stream);
+}
+
+int rsx_get_state_full(rsx_sim* h, double* out, void* stream) {
+    if (int rc = check(h)) return rc;
+    if (!out) return fail(RSX_ERR_ARG, "out is null");
+    return get_state_impl(h, out, h->P.state_dim + 1, (hipStream_t)stream);
+}
+
+int rsx_set_state(rsx_sim* h, const double* state, void* stream) {
+    if (int rc = check(h)) return rc;
+    if (!state) return fail(RSX_ERR_ARG, "state is null");
+    const size_t B = (size_t)h->P.num_envs;
+    const int rows = h->P.state_dim + 1;
+    std::vector<float> soa((size_t)rows * B);
+    for (size_t e = 0; e < B; ++e)
+        for (int f = 0; f < rows; ++f) soa[(size_t)f * B + e] = (float)state[e * rows + f];
+    return upload_state(h, soa, (hipStream_t)stream);
+}
+
+int rsx_dev_view_get(rsx_sim* h, rsx_dev_view* out) {
+    if (!h || !out) return fail(RSX_ERR_ARG, "null argument");
+    out->num_envs = h->P.num_envs; out->n_robots = h->P.n_robots;
+    out->state_dim = h->P.state_dim; out->cmd_dim = h->P.cmd_dim;
+    out->state = h->d_state; out->cmds = h->d_cmds;
+    return RSX_OK;
+}
+
+int rsx_step_dev(rsx_sim* h, void* stream) {
+    if (int rc = check(h)) return rc;
+    launch_sim(h, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return RSX_OK;
+}
+
+int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, int max_episode_steps) {
+    if (int rc = check(h)) return rc;
+    if (h->P.task != RSX_TASK_NONE) return fail(RSX_ERR_STATE, "a task is already attached");
+    Params P = h->P;
+    if (derive_task(task, seed, env_id_base, max_episode_steps, h->M, P))
+        return fail(RSX_ERR_ARG, "task does not match the simulator (VSS_V0: kind VSS, n_blue >= 1; STATIC_DEFENDERS: kind SSL, n_blue == 1)");
+    if (P.obs_dim > 64) return fail(RSX_ERR_ARG, "observation wider than 64 floats is not supported");
+    const size_t B = (size_t)P.num_envs;
+    struct A { void** p; size_t n; };
+    const A allocs[] = {
+        {(void**)&h->d_obs, B * P.obs_dim * sizeof(float)}, {(void**)&h->d_final_obs, B * P.obs_dim * sizeof(float)},
+        {(void**)&h->d_reward, B * sizeof(float)}, {(void**)&h->d_info, B * P.info_dim * sizeof(float)},
+        {(void**)&h->d_ou, B * 2 * P.n_robots * sizeof(float)}, {(void**)&h->d_prev_pot, B * sizeof(float)},
+        {(void**)&h->d_ep_ret, B * sizeof(float)}, {(void**)&h->d_actions, B * P.act_dim * sizeof(float)},
+        {(void**)&h->d_term, B}, {(void**)&h->d_trunc, B}, {(void**)&h->d_steps, B * sizeof(int)},
+        {(void**)&h->d_episode, B * sizeof(uint32_t)}, {(void**)&h->d_metrics, RSX_METRICS * sizeof(unsigned long long)},
+    };
+    for (const A& a : allocs) {
+        HIP_TRY(hipMalloc(a.p, a.n));
+        HIP_TRY(hipMemset(*a.p, 0, a.n));
+    }
+    // episode ids start at 0xFFFFFFFF so that the first reset() opens episode 0
+    HIP_TRY(hipMemset(h->d_episode, 0xFF, B * sizeof(uint32_t)));
+    h->P = P;
+    h->env_steps = 0;
+    return RSX_OK;
+}
+
+int rsx_task_view_get(rsx_sim* h, rsx_task_view* out) {
+    if (!h || !out) return fail(RSX_ERR_ARG, "null argument");
+    if (h->P.task == RSX_TASK_NONE) return fail(RSX_ERR_STATE, "no task attached (rsx_task_attach)");
+    out->task = h->P.task; out->obs_dim = h->P.obs_dim; out->act_dim = h->P.act_dim;
+    out->info_dim = h->P.info_dim; out->max_episode_steps = h->P.max_steps;
+    out->obs = h->d_obs; out->reward = h->d_reward; out->terminated = h->d_term; out->truncated = h->d_trunc;
+    out->info = h->d_info; out->final_obs = h->d_final_obs; out->steps = h->d_steps; out->actions = h->d_actions;
+    return RSX_OK;
+}
+
+int rsx_task_reset(rsx_sim* h, void* stream) {
+    if (int rc = check_task(h)) return rc;
+    launch_task(h, nullptr, 1, 1, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return RSX_OK;
+}
+
+int rsx_task_reset_to(rsx_sim* h, const double* ball, const double* blue, const double* yellow,
+                      const uint8_t* env_mask, void* stream) {
+    if (int rc = check_task(h)) return rc;
+    if (int rc = rsx_reset(h, ball, blue, yellow, env_mask, stream)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t B = (size_t)h->P.num_envs;
+    // the kernel takes the env mask through the `truncated` buffer (cleared again below)
+    if (env_mask) HIP_TRY(hipMemcpyAsync(h->d_trunc, env_mask, B, hipMemcpyHostToDevice, s));
+    else HIP_TRY(hipMemsetAsync(h->d_trunc, 1, B, s));
+    launch_task(h, nullptr, 1, 2, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(h->d_trunc, 0, B, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return RSX_OK;
+}
+
+int rsx_task_step(rsx_sim* h, const float* actions_dev, void* stream) {
+    if (int rc = check_task(h)) return rc;
+    launch_task(h, actions_dev, 1, 0, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    h->env_steps += h->P.num_envs;
+    return RSX_OK;
+}
+
+int rsx_task_step_n(rsx_sim* h, int n, void* stream) {
+    if (int rc = check_task(h)) return rc;
+    if (n < 1) return fail(RSX_ERR_ARG, "n must be >= 1");
+    auto it = h->graphs.find(n);
+    if (it == h->graphs.end()) {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        HIP_TRY(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < n; ++i) launch_task(h, nullptr, 1, 0, h->cap_stream);
+        HIP_TRY(hipStreamEndCapture(h->cap_stream, &graph));
+        HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        hipGraphDestroy(graph);
+        it = h->graphs.emplace(n, exec).first;
+    }
+    HIP_TRY(hipGraphLaunch(it->second, (hipStream_t)stream));
+    h->env_steps += (long long)n * h->P.num_envs;
+    return RSX_OK;
+}
+
+int rsx_task_rollout(rsx_sim* h, int n, void* stream) {
+    if (int rc = check_task(h)) return rc;
+    if (n < 1) return fail(RSX_ERR_ARG, "n must be >= 1");
+    launch_task(h, nullptr, n, 0, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    h->env_steps += (long long)n * h->P.num_envs;
+    return RSX_OK;
+}
+
+int rsx_read_metrics(rsx_sim* h, int64_t out[RSX_METRICS], void* stream) {
+    if (int rc = check_task(h)) return rc;
+    if (!out) return fail(RSX_ERR_ARG, "out is null");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(out, h->d_metrics, RSX_METRICS * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    out[0] = h->env_steps;
+    return RSX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+// rsx_math.hpp — device-side elementary functions with a FIXED operation order.
+//
+// The step engine promises results that are bit-identical to the scalar model in fp32, on any
+// batch size / lane mapping.  libm-style device functions (ocml sinf/cosf/logf) carry no such
+// promise, so the few transcendental functions the model needs are spelled out here as plain
+// mul/add sequences (Cephes single-precision coefficients).  The translation unit is compiled
+// with -ffp-contract=off: no multiply-add is ever fused behind the source's back; IEEE sqrt and
+// divide are correctly rounded by hipcc's default expansion.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rsx {
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) {
+    return v < lo ? lo : (v > hi ? hi : v);
+}
+
+// sin and cos of an angle already reduced to about [-pi, pi] (any |a| < 1e4 works).
+__device__ __forceinline__ void sincos_f32(float a, float& s, float& c) {
+    float t = a * 0.636619772f;                       // 2/pi
+    int k = (int)(t + (t >= 0.0f ? 0.5f : -0.5f));    // nearest quadrant
+    float fk = (float)k;
+    // three-term Cody-Waite reduction by pi/2
+    float r = ((a - fk * 1.5703125f) - fk * 4.837512969970703125e-4f) - fk * 7.54978995489188e-8f;
+    float z = r * r;
+    float ps = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+    float pc = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f)
+                   * z * z - 0.5f * z + 1.0f;
+    int q = k & 3;
+    float ss = (q & 1) ? pc : ps;
+    float cc = (q & 1) ? ps : pc;
+    s = (q & 2) ? -ss : ss;
+    c = (q == 1 || q == 2) ? -cc : cc;
+}
+
+// natural log for x in [2^-24, 1]
+__device__ __forceinline__ float log_f32(float x) {
+    uint32_t ix = __float_as_uint(x);
+    int e = (int)(ix >> 23) - 127;
+    float m = __uint_as_float((ix & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421356f) { m = m * 0.5f; e = e + 1; }
+    float f = m - 1.0f, z = f * f;
+    float p = ((((((((7.0376836292e-2f * f - 1.1514610310e-1f) * f + 1.1676998740e-1f) * f
+                    - 1.2420140846e-1f) * f + 1.4249322787e-1f) * f - 1.6668057665e-1f) * f
+                 + 2.0000714765e-1f) * f - 2.4999993993e-1f) * f + 3.3333331174e-1f) * f * z;
+    float fe = (float)e;
+    p = p + fe * -2.12194440e-4f;
+    p = p - 0.5f * z;
+    float r = f + p;
+    r = r + fe * 0.693359375f;
+    return r;
+}
+
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw — SC'11).  counter = (global env id, episode,
+// tick, domain), key = (seed lo, seed hi): a draw depends only on WHAT it is for, never on the
+// thread that computes it, so results are invariant to batch size, batch position and sharding.
+struct u32x4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                               uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return u32x4{c0, c1, c2, c3};
+}
+
+constexpr uint32_t DOM_ACT = 1u, DOM_OU = 2u, DOM_PLACE = 3u;
+
+// 24-bit uniform in [0, 1)
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }
+
+}  // namespace rsx

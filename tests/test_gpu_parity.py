@@ -1,0 +1,257 @@
+"""GPU <-> CPU-oracle parity through the C-ABI (librsx_hip.so).  Bit-exact in fp32.
+
+The oracle (oracle/rsx_oracle.c, float instantiation) and the HIP kernels are two independent
+implementations of the step model; every comparison below is exact equality of float32 bit
+patterns, over whole trajectories (collisions, goals, auto-resets, RNG included).
+"""
+import numpy as np
+import pytest
+
+from helpers import f32_equal, mismatch_report, random_placement
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from rsoccer_amd import _lib
+    return _lib
+
+
+def _mk_oracles(O, kind, ft, nb, ny, B, ts=25):
+    return [O.OracleEnv(kind, ft, nb, ny, ts, "f32") for _ in range(B)]
+
+
+CASES = [
+    # kind, field_type, nb, ny, B, steps, spread
+    (0, 0, 3, 3, 67, 60, 0.5),     # VSS 3v3 (ragged batch: 67 is not a multiple of 8)
+    (0, 1, 5, 5, 33, 40, 0.5),     # VSS 5v5 -> 16 lanes per env
+    (1, 2, 1, 6, 41, 60, 0.4),     # SSL 1v6
+    (1, 1, 11, 11, 19, 40, 0.25),  # SSL 11v11 -> 32 lanes per env, crowded
+    (1, 0, 2, 0, 5, 30, 0.2),      # SSL 2v0 (empty yellow team)
+]
+
+
+@pytest.mark.parametrize("kind,ft,nb,ny,B,steps,spread", CASES)
+def test_raw_step_bitexact(oracle_mod, kind, ft, nb, ny, B, steps, spread):
+    L = _lib()
+    O = oracle_mod
+    rng = np.random.default_rng(1234 + kind * 10 + nb)
+    sim = L.Sim(kind, ft, nb, ny, 25, B)
+    fp = sim.get_field_params()
+    refs = _mk_oracles(O, kind, ft, nb, ny, B)
+    assert np.allclose(list(fp.values()), refs[0].field_params())
+    N = nb + ny
+    # dummy line-up right after construction
+    st = sim.get_state()
+    for e in range(B):
+        assert f32_equal(st[e], refs[e].get_state())
+    min_d = 2.2 * fp["rbt_radius"]
+    ball, blue, yellow = random_placement(rng, B, nb, ny, fp["length"] / 2, fp["width"] / 2, min_d, spread)
+    sim.reset(ball, blue, yellow if ny else None)
+    for e in range(B):
+        refs[e].reset(ball[e], blue[e], yellow[e] if ny else np.zeros(0))
+    C = sim.cmd_dim
+    contacts = 0
+    for t in range(steps):
+        if kind == 0:
+            cmds = rng.uniform(-60, 60, (B, N, 2))
+        else:
+            cmds = np.zeros((B, N, 8))
+            use_wheels = rng.random((B, N)) < 0.3
+            cmds[..., 0] = use_wheels
+            cmds[..., 1:5] = np.where(use_wheels[..., None], rng.uniform(-120, 120, (B, N, 4)),
+                                      np.concatenate([rng.uniform(-3, 3, (B, N, 2)),
+                                                      rng.uniform(-12, 12, (B, N, 1)),
+                                                      np.zeros((B, N, 1))], -1))
+            cmds[..., 5] = np.where(rng.random((B, N)) < 0.3, 4.0, 0.0)
+            cmds[..., 6] = np.where(rng.random((B, N)) < 0.1, 2.0, 0.0)
+            cmds[..., 7] = rng.random((B, N)) < 0.5
+        sim.step(cmds)
+        got = sim.get_state_full()
+        for e in range(B):
+            refs[e].step(cmds[e])
+            want = refs[e].get_state_full()
+            assert f32_equal(got[e], want), mismatch_report(got[e], want, f"env {e} step {t}")
+    sim.close()
+
+
+def test_set_get_state_roundtrip():
+    L = _lib()
+    sim = L.Sim(1, 2, 1, 6, 25, 9)
+    rng = np.random.default_rng(0)
+    s = rng.normal(size=(9, sim.state_dim + 1)).astype(np.float32).astype(np.float64)
+    sim.set_state(s)
+    assert np.array_equal(sim.get_state_full(), s)
+    assert np.array_equal(sim.get_state(), s[:, :-1])
+    sim.close()
+
+
+def _cmp_task(sim, refs, tens, t, check_state=True):
+    import torch
+    torch.cuda.synchronize()
+    obs = tens["obs"].cpu().numpy()
+    rew = tens["reward"].cpu().numpy()
+    term = tens["terminated"].cpu().numpy()
+    trunc = tens["truncated"].cpu().numpy()
+    info = tens["info"].cpu().numpy()
+    steps = tens["steps"].cpu().numpy()
+    fin = tens["final_obs"].cpu().numpy()
+    state = sim.get_state_full() if check_state else None
+    for e, r in enumerate(refs):
+        o = r.task_out()
+        assert f32_equal(obs[e], o["obs"]), mismatch_report(obs[e], o["obs"], f"obs env {e} step {t}")
+        assert f32_equal(rew[e], o["reward"]), f"reward env {e} step {t}: {rew[e]} vs {o['reward']}"
+        assert term[e] == o["terminated"] and trunc[e] == o["truncated"], f"done env {e} step {t}"
+        assert f32_equal(info[:, e], o["info"]), mismatch_report(info[:, e], o["info"], f"info env {e} step {t}")
+        assert steps[e] == o["steps"]
+        if o["terminated"] or o["truncated"]:
+            assert f32_equal(fin[e], o["final_obs"]), f"final_obs env {e} step {t}"
+        if check_state:
+            w = r.get_state_full()
+            assert f32_equal(state[e], w), mismatch_report(state[e], w, f"state env {e} step {t}")
+
+
+TASKS = [
+    # task, kind, ft, nb, ny, B, steps, max_episode_steps
+    (1, 0, 0, 3, 3, 45, 260, 100),
+    (2, 1, 2, 1, 6, 37, 200, 60),
+]
+
+
+@pytest.mark.parametrize("task,kind,ft,nb,ny,B,steps,max_steps", TASKS)
+def test_task_random_actions_bitexact(oracle_mod, task, kind, ft, nb, ny, B, steps, max_steps):
+    """Whole fused rollouts with device-side random actions, OU noise, TimeLimit and auto-reset."""
+    L = _lib()
+    O = oracle_mod
+    seed, base = 0x1234567890ABCDEF, 1000
+    sim = L.Sim(kind, ft, nb, ny, 25, B)
+    sim.task_attach(task, seed, base, max_steps)
+    tens = sim.task_tensors()
+    refs = _mk_oracles(O, kind, ft, nb, ny, B)
+    for e, r in enumerate(refs):
+        r.task_attach(task, seed, base + e, max_steps)
+        r.task_reset()
+    sim.task_reset()
+    _cmp_task(sim, refs, {**tens, "reward": tens["reward"] * 0}, -1) if False else None
+    import torch
+    torch.cuda.synchronize()
+    obs = tens["obs"].cpu().numpy()
+    st = sim.get_state_full()
+    for e, r in enumerate(refs):
+        assert f32_equal(st[e], r.get_state_full()), mismatch_report(st[e], r.get_state_full(), f"reset state env {e}")
+        assert f32_equal(obs[e], r.task_out()["obs"])
+    for t in range(steps):
+        sim.task_step(None)
+        for r in refs:
+            r.task_step(None)
+        _cmp_task(sim, refs, tens, t)
+    got = sim.read_metrics()
+    want = sum(r.task_out()["metrics"] for r in refs)
+    assert np.array_equal(got, want), (got, want)
+    assert got[1] > 0  # episodes did end (TimeLimit at least)
+    sim.close()
+
+
+@pytest.mark.parametrize("task,kind,ft,nb,ny,B,steps,max_steps", TASKS)
+def test_task_fed_actions_and_modes_bitexact(oracle_mod, task, kind, ft, nb, ny, B, steps, max_steps):
+    """Host-chosen actions; step_n (hipGraph) and rollout (one launch) agree with single steps."""
+    import torch
+    L = _lib()
+    O = oracle_mod
+    seed, base = 7, 0
+    sim = L.Sim(kind, ft, nb, ny, 25, B)
+    sim.task_attach(task, seed, base, max_steps)
+    tens = sim.task_tensors()
+    refs = _mk_oracles(O, kind, ft, nb, ny, B)
+    for e, r in enumerate(refs):
+        r.task_attach(task, seed, base + e, max_steps)
+        r.task_reset()
+    sim.task_reset()
+    rng = np.random.default_rng(5)
+    A = sim.act_dim
+    for t in range(40):
+        a = rng.uniform(-1, 1, (B, A)).astype(np.float32)
+        tens["actions"].copy_(torch.from_numpy(a))
+        sim.task_step(tens["actions"].data_ptr())
+        for e, r in enumerate(refs):
+            r.task_step(a[e])
+        _cmp_task(sim, refs, tens, t)
+    sim.task_step_n(17)
+    for r in refs:
+        for _ in range(17):
+            r.task_step(None)
+    _cmp_task(sim, refs, tens, "graph")
+    sim.task_rollout(23)
+    for r in refs:
+        for _ in range(23):
+            r.task_step(None)
+    _cmp_task(sim, refs, tens, "rollout")
+    sim.close()
+
+
+def test_batch_position_and_shard_invariance():
+    """env i's trajectory depends only on (seed, global env id): not on batch size, position
+    in the batch, or how the batch is split over handles (= over GPUs)."""
+    import torch
+    L = _lib()
+    seed = 99
+    full = L.Sim(0, 0, 3, 3, 25, 64)
+    full.task_attach(1, seed, 0, 50)
+    full.task_reset()
+    full.task_step_n(120)
+    torch.cuda.synchronize()
+    want = full.get_state_full()
+    wobs = full.task_tensors()["obs"].cpu().numpy()
+    parts = []
+    for lo, n in ((0, 24), (24, 3), (27, 37)):
+        s = L.Sim(0, 0, 3, 3, 25, n)
+        s.task_attach(1, seed, lo, 50)
+        s.task_reset()
+        for _ in range(120):
+            s.task_step(None)
+        torch.cuda.synchronize()
+        parts.append((s.get_state_full(), s.task_tensors()["obs"].cpu().numpy(), s.read_metrics()))
+        s.close()
+    got = np.concatenate([p[0] for p in parts])
+    gobs = np.concatenate([p[1] for p in parts])
+    assert np.array_equal(got, want)
+    assert np.array_equal(gobs, wobs)
+    assert np.array_equal(sum(p[2] for p in parts), full.read_metrics())
+    full.close()
+
+
+def test_reset_to_matches_oracle(oracle_mod):
+    import torch
+    L = _lib()
+    O = oracle_mod
+    B = 12
+    sim = L.Sim(0, 0, 3, 3, 25, B)
+    sim.task_attach(1, 3, 0, 0)
+    refs = _mk_oracles(O, 0, 0, 3, 3, B)
+    for e, r in enumerate(refs):
+        r.task_attach(1, 3, e, 0)
+        r.task_reset()
+    sim.task_reset()
+    rng = np.random.default_rng(2)
+    ball, blue, yellow = random_placement(rng, B, 3, 3, 0.6, 0.5, 0.1)
+    mask = (rng.random(B) < 0.5).astype(np.uint8)
+    sim.task_step_n(5)
+    for r in refs:
+        for _ in range(5):
+            r.task_step(None)
+    sim.task_reset_to(ball, blue, yellow, mask)
+    for e, r in enumerate(refs):
+        if mask[e]:
+            r.task_reset_to(ball[e], blue[e], yellow[e])
+    tens = sim.task_tensors()
+    torch.cuda.synchronize()
+    obs = tens["obs"].cpu().numpy()
+    for e, r in enumerate(refs):
+        if mask[e]:
+            assert f32_equal(obs[e], r.task_out()["obs"])
+    for t in range(30):
+        sim.task_step(None)
+        for r in refs:
+            r.task_step(None)
+    _cmp_task(sim, refs, tens, "after reset_to")
+    sim.close()
