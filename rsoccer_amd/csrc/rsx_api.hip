@@ -36,15 +36,15 @@ struct rsx_sim {
     Params P;
     HostModel M;
     int device = 0;
-    int L = 8;  // lanes per env
+    int L = 8;   // lanes per env
+    int NR = 0;  // compile-time robot count of the selected kernel variant (0 = generic)
+    // one allocation per lifetime stage (few pages -> few TLB entries per launch)
+    char* arena_sim = nullptr;   // state | cmds
+    char* arena_task = nullptr;  // aux | obs | final_obs | flags | actions | metrics
     float* d_state = nullptr;
     float* d_cmds = nullptr;
-    // task buffers
-    float *d_obs = nullptr, *d_reward = nullptr, *d_info = nullptr, *d_final_obs = nullptr;
-    float *d_ou = nullptr, *d_prev_pot = nullptr, *d_ep_ret = nullptr, *d_actions = nullptr;
-    uint8_t *d_term = nullptr, *d_trunc = nullptr;
-    int* d_steps = nullptr;
-    uint32_t* d_episode = nullptr;
+    float *d_aux = nullptr, *d_obs = nullptr, *d_final_obs = nullptr, *d_actions = nullptr;
+    uint8_t* d_flags = nullptr;
     unsigned long long* d_metrics = nullptr;
     long long env_steps = 0;
     hipStream_t cap_stream = nullptr;
@@ -72,45 +72,60 @@ dim3 grid_for(const rsx_sim* h) {
 
 Buffers buffers_of(const rsx_sim* h, const float* actions) {
     Buffers b;
-    b.state = h->d_state; b.cmds = h->d_cmds; b.actions = actions;
-    b.obs = h->d_obs; b.reward = h->d_reward; b.terminated = h->d_term; b.truncated = h->d_trunc;
-    b.info = h->d_info; b.final_obs = h->d_final_obs; b.steps = h->d_steps; b.episode = h->d_episode;
-    b.ou = h->d_ou; b.prev_pot = h->d_prev_pot; b.ep_ret = h->d_ep_ret; b.metrics = h->d_metrics;
+    b.state = h->d_state; b.aux = h->d_aux; b.obs = h->d_obs; b.final_obs = h->d_final_obs;
+    b.flags = h->d_flags; b.cmds = h->d_cmds; b.actions = actions; b.metrics = h->d_metrics;
     return b;
 }
 
+// Kernel variants: the common team sizes get the robot count as a template constant (pair
+// loops unrolled); anything else runs the generic variant of its lane-group width.
+void pick_variant(rsx_sim* h) {
+    const int N = h->P.n_robots;
+    h->NR = 0;
+    if (std::getenv("RSX_GENERIC_KERNELS")) return;
+    if (h->P.kind == RSX_KIND_VSS && N == 6 && h->L == 8) h->NR = 6;
+    if (h->P.kind == RSX_KIND_SSL && N == 7 && h->L == 8) h->NR = 7;
+    if (h->P.kind == RSX_KIND_SSL && N == 22 && h->L == 32) h->NR = 22;
+}
+
+#define RSX_LAUNCH(kernel, ...) hipLaunchKernelGGL((kernel), grid, dim3(64), 0, s, __VA_ARGS__)
+
 template <int KIND>
-void launch_sim_L(const rsx_sim* h, hipStream_t s) {
+void launch_sim_k(const rsx_sim* h, hipStream_t s) {
     const dim3 grid = grid_for(h);
     const Buffers b = buffers_of(h, nullptr);
+    if (KIND == RSX_KIND_VSS && h->NR == 6) { RSX_LAUNCH((sim_step_kernel<KIND, 8, (KIND == RSX_KIND_VSS ? 6 : 0)>), h->P, b); return; }
+    if (KIND == RSX_KIND_SSL && h->NR == 7) { RSX_LAUNCH((sim_step_kernel<KIND, 8, (KIND == RSX_KIND_SSL ? 7 : 0)>), h->P, b); return; }
+    if (KIND == RSX_KIND_SSL && h->NR == 22) { RSX_LAUNCH((sim_step_kernel<KIND, 32, (KIND == RSX_KIND_SSL ? 22 : 0)>), h->P, b); return; }
     switch (h->L) {
-        case 8: hipLaunchKernelGGL((sim_step_kernel<KIND, 8>), grid, dim3(64), 0, s, h->P, b); break;
-        case 16: hipLaunchKernelGGL((sim_step_kernel<KIND, 16>), grid, dim3(64), 0, s, h->P, b); break;
-        case 32: hipLaunchKernelGGL((sim_step_kernel<KIND, 32>), grid, dim3(64), 0, s, h->P, b); break;
-        default: hipLaunchKernelGGL((sim_step_kernel<KIND, 64>), grid, dim3(64), 0, s, h->P, b); break;
+        case 8: RSX_LAUNCH((sim_step_kernel<KIND, 8, 0>), h->P, b); break;
+        case 16: RSX_LAUNCH((sim_step_kernel<KIND, 16, 0>), h->P, b); break;
+        case 32: RSX_LAUNCH((sim_step_kernel<KIND, 32, 0>), h->P, b); break;
+        default: RSX_LAUNCH((sim_step_kernel<KIND, 64, 0>), h->P, b); break;
     }
 }
 
 void launch_sim(const rsx_sim* h, hipStream_t s) {
-    if (h->P.kind == RSX_KIND_VSS) launch_sim_L<RSX_KIND_VSS>(h, s);
-    else launch_sim_L<RSX_KIND_SSL>(h, s);
+    if (h->P.kind == RSX_KIND_VSS) launch_sim_k<RSX_KIND_VSS>(h, s);
+    else launch_sim_k<RSX_KIND_SSL>(h, s);
 }
 
-template <int KIND, int TASK>
-void launch_task_L(const rsx_sim* h, const float* actions, int n_steps, int mode, hipStream_t s) {
+template <int KIND, int TASK, int NRS>
+void launch_task_k(const rsx_sim* h, const float* actions, int n_steps, int mode, hipStream_t s) {
     const dim3 grid = grid_for(h);
     const Buffers b = buffers_of(h, actions);
+    if (h->NR == NRS && h->L == 8) { RSX_LAUNCH((task_step_kernel<KIND, 8, TASK, NRS>), h->P, b, n_steps, mode); return; }
     switch (h->L) {
-        case 8: hipLaunchKernelGGL((task_step_kernel<KIND, 8, TASK>), grid, dim3(64), 0, s, h->P, b, n_steps, mode); break;
-        case 16: hipLaunchKernelGGL((task_step_kernel<KIND, 16, TASK>), grid, dim3(64), 0, s, h->P, b, n_steps, mode); break;
-        case 32: hipLaunchKernelGGL((task_step_kernel<KIND, 32, TASK>), grid, dim3(64), 0, s, h->P, b, n_steps, mode); break;
-        default: hipLaunchKernelGGL((task_step_kernel<KIND, 64, TASK>), grid, dim3(64), 0, s, h->P, b, n_steps, mode); break;
+        case 8: RSX_LAUNCH((task_step_kernel<KIND, 8, TASK, 0>), h->P, b, n_steps, mode); break;
+        case 16: RSX_LAUNCH((task_step_kernel<KIND, 16, TASK, 0>), h->P, b, n_steps, mode); break;
+        case 32: RSX_LAUNCH((task_step_kernel<KIND, 32, TASK, 0>), h->P, b, n_steps, mode); break;
+        default: RSX_LAUNCH((task_step_kernel<KIND, 64, TASK, 0>), h->P, b, n_steps, mode); break;
     }
 }
 
 void launch_task(const rsx_sim* h, const float* actions, int n_steps, int mode, hipStream_t s) {
-    if (h->P.task == RSX_TASK_VSS_V0) launch_task_L<RSX_KIND_VSS, RSX_TASK_VSS_V0>(h, actions, n_steps, mode, s);
-    else launch_task_L<RSX_KIND_SSL, RSX_TASK_SSL_STATIC_DEFENDERS>(h, actions, n_steps, mode, s);
+    if (h->P.task == RSX_TASK_VSS_V0) launch_task_k<RSX_KIND_VSS, RSX_TASK_VSS_V0, 6>(h, actions, n_steps, mode, s);
+    else launch_task_k<RSX_KIND_SSL, RSX_TASK_SSL_STATIC_DEFENDERS, 7>(h, actions, n_steps, mode, s);
 }
 
 int check(const rsx_sim* h) {
@@ -148,12 +163,12 @@ void apply_reset(const rsx_sim* h, std::vector<float>& soa, const double* ball, 
         if (mask && !mask[e]) continue;
         for (int f = 0; f <= P.state_dim; ++f) soa[(size_t)f * B + e] = 0.0f;
         const double* bl = ball + 4 * e;
-        soa[0 * B + e] = (float)bl[0]; soa[1 * B + e] = (float)bl[1]; soa[2 * B + e] = P.r_ball;
+        soa[0 * B + e] = (float)bl[0]; soa[1 * B + e] = (float)bl[1]; soa[2 * B + e] = (float)h->M.field[6];
         soa[3 * B + e] = (float)bl[2]; soa[4 * B + e] = (float)bl[3];
         for (int k = 0; k < P.n_robots; ++k) {
             const double* src = k < P.n_blue ? blue + ((size_t)e * P.n_blue + k) * 3
                                              : yellow + ((size_t)e * P.n_yellow + (k - P.n_blue)) * 3;
-            const size_t r = (size_t)(5 + P.rs * k);
+            const size_t r = (size_t)(5 + h->M.rs * k);
             soa[(r + 0) * B + e] = (float)src[0];
             soa[(r + 1) * B + e] = (float)src[1];
             soa[(r + 2) * B + e] = (float)src[2];
@@ -162,14 +177,15 @@ void apply_reset(const rsx_sim* h, std::vector<float>& soa, const double* ball, 
 }
 
 void free_all(rsx_sim* h) {
-    for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
+    for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
     h->graphs.clear();
-    if (h->cap_stream) hipStreamDestroy(h->cap_stream);
-    void* ptrs[] = {h->d_state, h->d_cmds, h->d_obs, h->d_reward, h->d_info, h->d_final_obs, h->d_ou,
-                    h->d_prev_pot, h->d_ep_ret, h->d_actions, h->d_term, h->d_trunc, h->d_steps,
-                    h->d_episode, h->d_metrics};
-    for (void* p : ptrs) if (p) hipFree(p);
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    if (h->arena_sim) (void)hipFree(h->arena_sim);
+    if (h->arena_task) (void)hipFree(h->arena_task);
+    h->arena_sim = h->arena_task = nullptr;
 }
+
+size_t align_up(size_t n) { return (n + 255) & ~(size_t)255; }
 
 }  // namespace
 
@@ -199,6 +215,7 @@ int rsx_create(rsx_sim** out, int kind, int field_type, int n_blue, int n_yellow
     }
     h->device = device_id;
     h->L = pick_lanes(h->P.n_robots + 1);
+    pick_variant(h);
     auto bail = [&](hipError_t e, const char* what) {
         std::string m = std::string(what) + ": " + hipGetErrorString(e);
         free_all(h); delete h;
@@ -208,18 +225,19 @@ int rsx_create(rsx_sim** out, int kind, int field_type, int n_blue, int n_yellow
     if ((e = hipSetDevice(device_id)) != hipSuccess) return bail(e, "hipSetDevice");
     const size_t B = (size_t)num_envs;
     const size_t sbytes = (size_t)(h->P.state_dim + 1) * B * sizeof(float);
-    const size_t cbytes = (size_t)h->P.n_robots * h->P.cmd_dim * B * sizeof(float);
-    if ((e = hipMalloc(&h->d_state, sbytes)) != hipSuccess) return bail(e, "hipMalloc(state)");
-    if ((e = hipMalloc(&h->d_cmds, cbytes)) != hipSuccess) return bail(e, "hipMalloc(cmds)");
+    const size_t cbytes = (size_t)h->P.n_robots * h->M.cmd_dim * B * sizeof(float);
+    if ((e = hipMalloc((void**)&h->arena_sim, align_up(sbytes) + align_up(cbytes))) != hipSuccess) return bail(e, "hipMalloc(state+cmds)");
+    h->d_state = (float*)h->arena_sim;
+    h->d_cmds = (float*)(h->arena_sim + align_up(sbytes));
     if ((e = hipMemset(h->d_cmds, 0, cbytes)) != hipSuccess) return bail(e, "hipMemset(cmds)");
     if ((e = hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     // the adapter's dummy line-up, rsim.py:20-24
     std::vector<float> soa((size_t)(h->P.state_dim + 1) * B, 0.0f);
     for (size_t i = 0; i < B; ++i) {
-        soa[2 * B + i] = h->P.r_ball;
+        soa[2 * B + i] = (float)h->M.field[6];
         for (int k = 0; k < h->P.n_robots; ++k) {
             const int j = k < n_blue ? k + 1 : k - n_blue + 1;
-            soa[(size_t)(5 + h->P.rs * k) * B + i] = (float)((k < n_blue ? -0.2 : 0.2) * j);
+            soa[(size_t)(5 + h->M.rs * k) * B + i] = (float)((k < n_blue ? -0.2 : 0.2) * j);
         }
     }
     if ((e = hipMemcpy(h->d_state, soa.data(), sbytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(state)");
@@ -229,7 +247,7 @@ int rsx_create(rsx_sim** out, int kind, int field_type, int n_blue, int n_yellow
 
 int rsx_destroy(rsx_sim* h) {
     if (!h) return RSX_OK;
-    hipSetDevice(h->device);
+    (void)hipSetDevice(h->device);
     free_all(h);
     delete h;
     return RSX_OK;
@@ -258,7 +276,7 @@ int rsx_step(rsx_sim* h, const double* cmds, void* stream) {
     if (!cmds) return fail(RSX_ERR_ARG, "cmds is null");
     hipStream_t s = (hipStream_t)stream;
     const Params& P = h->P;
-    const size_t B = (size_t)P.num_envs, NC = (size_t)P.n_robots * P.cmd_dim;
+    const size_t B = (size_t)P.num_envs, NC = (size_t)P.n_robots * h->M.cmd_dim;
     h->h_f32.resize(NC * B);
     for (size_t e = 0; e < B; ++e)
         for (size_t j = 0; j < NC; ++j) h->h_f32[j * B + e] = (float)cmds[e * NC + j];
@@ -304,7 +322,7 @@ int rsx_set_state(rsx_sim* h, const double* state, void* stream) {
 int rsx_dev_view_get(rsx_sim* h, rsx_dev_view* out) {
     if (!h || !out) return fail(RSX_ERR_ARG, "null argument");
     out->num_envs = h->P.num_envs; out->n_robots = h->P.n_robots;
-    out->state_dim = h->P.state_dim; out->cmd_dim = h->P.cmd_dim;
+    out->state_dim = h->P.state_dim; out->cmd_dim = h->M.cmd_dim;
     out->state = h->d_state; out->cmds = h->d_cmds;
     return RSX_OK;
 }
@@ -324,21 +342,23 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
         return fail(RSX_ERR_ARG, "task does not match the simulator (VSS_V0: kind VSS, n_blue >= 1; STATIC_DEFENDERS: kind SSL, n_blue == 1)");
     if (P.obs_dim > 64) return fail(RSX_ERR_ARG, "observation wider than 64 floats is not supported");
     const size_t B = (size_t)P.num_envs;
-    struct A { void** p; size_t n; };
-    const A allocs[] = {
-        {(void**)&h->d_obs, B * P.obs_dim * sizeof(float)}, {(void**)&h->d_final_obs, B * P.obs_dim * sizeof(float)},
-        {(void**)&h->d_reward, B * sizeof(float)}, {(void**)&h->d_info, B * P.info_dim * sizeof(float)},
-        {(void**)&h->d_ou, B * 2 * P.n_robots * sizeof(float)}, {(void**)&h->d_prev_pot, B * sizeof(float)},
-        {(void**)&h->d_ep_ret, B * sizeof(float)}, {(void**)&h->d_actions, B * P.act_dim * sizeof(float)},
-        {(void**)&h->d_term, B}, {(void**)&h->d_trunc, B}, {(void**)&h->d_steps, B * sizeof(int)},
-        {(void**)&h->d_episode, B * sizeof(uint32_t)}, {(void**)&h->d_metrics, RSX_METRICS * sizeof(unsigned long long)},
-    };
-    for (const A& a : allocs) {
-        HIP_TRY(hipMalloc(a.p, a.n));
-        HIP_TRY(hipMemset(*a.p, 0, a.n));
-    }
+    const size_t n_aux = align_up((size_t)aux_rows(P.n_robots) * B * sizeof(float));
+    const size_t n_obs = align_up(B * P.obs_dim * sizeof(float));
+    const size_t n_flags = align_up(2 * B);
+    const size_t n_act = align_up(B * h->M.act_dim * sizeof(float));
+    const size_t n_met = align_up(RSX_METRICS * sizeof(unsigned long long));
+    const size_t total = n_aux + 2 * n_obs + n_flags + n_act + n_met;
+    HIP_TRY(hipMalloc((void**)&h->arena_task, total));
+    HIP_TRY(hipMemset(h->arena_task, 0, total));
+    char* p = h->arena_task;
+    h->d_aux = (float*)p; p += n_aux;
+    h->d_obs = (float*)p; p += n_obs;
+    h->d_final_obs = (float*)p; p += n_obs;
+    h->d_flags = (uint8_t*)p; p += n_flags;
+    h->d_actions = (float*)p; p += n_act;
+    h->d_metrics = (unsigned long long*)p;
     // episode ids start at 0xFFFFFFFF so that the first reset() opens episode 0
-    HIP_TRY(hipMemset(h->d_episode, 0xFF, B * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(h->d_aux + (size_t)ROW_EPISODE * B, 0xFF, B * sizeof(uint32_t)));
     h->P = P;
     h->env_steps = 0;
     return RSX_OK;
@@ -347,10 +367,13 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
 int rsx_task_view_get(rsx_sim* h, rsx_task_view* out) {
     if (!h || !out) return fail(RSX_ERR_ARG, "null argument");
     if (h->P.task == RSX_TASK_NONE) return fail(RSX_ERR_STATE, "no task attached (rsx_task_attach)");
-    out->task = h->P.task; out->obs_dim = h->P.obs_dim; out->act_dim = h->P.act_dim;
-    out->info_dim = h->P.info_dim; out->max_episode_steps = h->P.max_steps;
-    out->obs = h->d_obs; out->reward = h->d_reward; out->terminated = h->d_term; out->truncated = h->d_trunc;
-    out->info = h->d_info; out->final_obs = h->d_final_obs; out->steps = h->d_steps; out->actions = h->d_actions;
+    const size_t B = (size_t)h->P.num_envs;
+    out->task = h->P.task; out->obs_dim = h->P.obs_dim; out->act_dim = h->M.act_dim;
+    out->info_dim = h->M.info_dim; out->max_episode_steps = h->P.max_steps;
+    out->obs = h->d_obs; out->reward = h->d_aux + (size_t)ROW_REWARD * B;
+    out->terminated = h->d_flags; out->truncated = h->d_flags + B;
+    out->info = h->d_aux + (size_t)ROW_INFO * B; out->final_obs = h->d_final_obs;
+    out->steps = (int32_t*)(h->d_aux + (size_t)ROW_STEPS * B); out->actions = h->d_actions;
     return RSX_OK;
 }
 
@@ -368,11 +391,11 @@ int rsx_task_reset_to(rsx_sim* h, const double* ball, const double* blue, const 
     hipStream_t s = (hipStream_t)stream;
     const size_t B = (size_t)h->P.num_envs;
     // the kernel takes the env mask through the `truncated` buffer (cleared again below)
-    if (env_mask) HIP_TRY(hipMemcpyAsync(h->d_trunc, env_mask, B, hipMemcpyHostToDevice, s));
-    else HIP_TRY(hipMemsetAsync(h->d_trunc, 1, B, s));
+    if (env_mask) HIP_TRY(hipMemcpyAsync(h->d_flags + B, env_mask, B, hipMemcpyHostToDevice, s));
+    else HIP_TRY(hipMemsetAsync(h->d_flags + B, 1, B, s));
     launch_task(h, nullptr, 1, 2, s);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemsetAsync(h->d_trunc, 0, B, s));
+    HIP_TRY(hipMemsetAsync(h->d_flags + B, 0, B, s));
     HIP_TRY(hipStreamSynchronize(s));
     return RSX_OK;
 }
@@ -396,7 +419,7 @@ int rsx_task_step_n(rsx_sim* h, int n, void* stream) {
         for (int i = 0; i < n; ++i) launch_task(h, nullptr, 1, 0, h->cap_stream);
         HIP_TRY(hipStreamEndCapture(h->cap_stream, &graph));
         HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-        hipGraphDestroy(graph);
+        (void)hipGraphDestroy(graph);
         it = h->graphs.emplace(n, exec).first;
     }
     HIP_TRY(hipGraphLaunch(it->second, (hipStream_t)stream));

@@ -12,8 +12,25 @@
 
 namespace rsx {
 
+// clamp(v, lo, hi) for lo < hi, both non-zero: the median of three is exactly
+// `v < lo ? lo : (v > hi ? hi : v)` for every non-NaN v (one v_med3_f32, no VCC round trip —
+// on gfx950 a v_cmp -> v_cndmask pair costs two extra wait states).
 __device__ __forceinline__ float clampf(float v, float lo, float hi) {
-    return v < lo ? lo : (v > hi ? hi : v);
+    return __builtin_amdgcn_fmed3f(v, lo, hi);
+}
+// -1 for negative x, +1 otherwise (only ever used where x != 0)
+__device__ __forceinline__ float signf(float x) { return __builtin_copysignf(1.0f, x); }
+
+// Lane <-> lane exchange through LDS inside ONE wavefront (every kernel here runs 64-thread
+// workgroups).  The LDS unit executes a wave's DS instructions in issue order, so a ds_write is
+// visible to a later ds_read of any lane of the same wave; all that is needed is that the compiler
+// keeps the program order.  __syncthreads() would also do it, but its workgroup-scope fence
+// drains vmcnt: every exchange would wait for the wave's outstanding global loads AND stores
+// (a full HBM round trip per step in the fused kernels).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // sin and cos of an angle already reduced to about [-pi, pi] (any |a| < 1e4 works).
