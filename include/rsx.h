@@ -89,6 +89,8 @@ typedef struct rsx_task_view {
     int32_t* steps;         /* [B] i32: steps taken in the current episode                   */
     float*   actions;       /* [B][act_dim] f32: staging buffer callers may fill and pass to
                                rsx_task_step (any device pointer of that shape works)        */
+    int64_t* metrics;       /* [RSX_METRICS] i64 device counters (entry 0 is host-counted:
+                               read it through rsx_read_metrics)                             */
 } rsx_task_view;
 
 /* ---- diagnostics ---------------------------------------------------------------------- */
@@ -156,7 +158,9 @@ int rsx_task_reset_to(rsx_sim* h, const double* ball, const double* blue, const 
  * action -> commands (+ OU noise for the non-agent robots), physics, observation, reward,
  * done, TimeLimit and same-step auto-reset. */
 int rsx_task_step(rsx_sim* h, const float* actions_dev, void* stream);
-/* n consecutive random-action steps (n kernel launches replayed from a hipGraph). */
+/* n consecutive random-action steps = n kernel launches issued from C (no per-step FFI cost).
+ * With RSX_USE_GRAPH=1 in the environment they are replayed from a cached hipGraph instead
+ * (measured slower on MI355X / ROCm 7: ~2.7 us per graph node vs back-to-back eager launches). */
 int rsx_task_step_n(rsx_sim* h, int n, void* stream);
 /* n consecutive random-action steps inside ONE launch (state stays in registers between
  * steps; obs / reward / done buffers hold the values of the last step). */

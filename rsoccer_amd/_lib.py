@@ -48,7 +48,7 @@ class TaskView(C.Structure):
                 ("info_dim", C.c_int32), ("max_episode_steps", C.c_int32),
                 ("obs", C.c_void_p), ("reward", C.c_void_p), ("terminated", C.c_void_p),
                 ("truncated", C.c_void_p), ("info", C.c_void_p), ("final_obs", C.c_void_p),
-                ("steps", C.c_void_p), ("actions", C.c_void_p)]
+                ("steps", C.c_void_p), ("actions", C.c_void_p), ("metrics", C.c_void_p)]
 
 
 _lib = None
@@ -232,6 +232,7 @@ class Sim:
             final_obs=self._tensor(t.final_obs, (B, t.obs_dim), "<f4"),
             steps=self._tensor(t.steps, (B,), "<i4"),
             actions=self._tensor(t.actions, (B, t.act_dim), "<f4"),
+            metrics=self._tensor(t.metrics, (N_METRICS,), "<i8"),
         )
 
     def task_reset(self, stream=None):

@@ -374,6 +374,7 @@ int rsx_task_view_get(rsx_sim* h, rsx_task_view* out) {
     out->terminated = h->d_flags; out->truncated = h->d_flags + B;
     out->info = h->d_aux + (size_t)ROW_INFO * B; out->final_obs = h->d_final_obs;
     out->steps = (int32_t*)(h->d_aux + (size_t)ROW_STEPS * B); out->actions = h->d_actions;
+    out->metrics = (int64_t*)h->d_metrics;
     return RSX_OK;
 }
 
@@ -411,6 +412,13 @@ int rsx_task_step(rsx_sim* h, const float* actions_dev, void* stream) {
 int rsx_task_step_n(rsx_sim* h, int n, void* stream) {
     if (int rc = check_task(h)) return rc;
     if (n < 1) return fail(RSX_ERR_ARG, "n must be >= 1");
+    static const bool use_graph = std::getenv("RSX_USE_GRAPH") != nullptr;
+    if (!use_graph) {
+        for (int i = 0; i < n; ++i) launch_task(h, nullptr, 1, 0, (hipStream_t)stream);
+        HIP_TRY(hipGetLastError());
+        h->env_steps += (long long)n * h->P.num_envs;
+        return RSX_OK;
+    }
     auto it = h->graphs.find(n);
     if (it == h->graphs.end()) {
         hipGraph_t graph = nullptr;
