@@ -29,12 +29,32 @@ ALGO_BYTES_PER_ENV_STEP = 541   # VSS-v0 fused = 2*164 (state r/
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def usable_cores():
+    """CPUs this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(envs, budget_s=12.0):
     """Times the CPU oracle (oracle/, float instantiation, OpenMP over envs) on a bounded sample
     of the same workload.  This is the only place bench.py touches oracle/."""
     from oracle import oracle as O
     O.build()
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
+    O.set_threads(cores)
     es = []
     for i in range(envs):
         e = O.OracleEnv(0, 0, 3, 3, 25, "f32")
@@ -49,7 +69,7 @@ def cpu_baseline(envs, budget_s=12.0):
             es[0].task_step(None)
         n1 += 200
     one = n1 / (time.perf_counter() - t0)
-    chunk, done = 25, 0
+    chunk, done = 100, 0
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < budget_s:
         O.vec_task_step(es, chunk)
@@ -68,6 +88,7 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--mode", choices=["step", "rollout"], default="step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rollout", action="store_true", help="skip the extra one-launch rollout leg")
     args = ap.parse_args()
 
     import torch
@@ -136,7 +157,7 @@ def main():
         return wall, dev_ms
 
     wall, dev_ms = timed(args.mode)
-    wall_r, dev_ms_r = timed("rollout") if args.mode == "step" else (None, None)
+    wall_r, dev_ms_r = timed("rollout") if args.mode == "step" and not args.no_rollout else (None, None)
 
     metrics = sim.read_metrics()
     if distributed:

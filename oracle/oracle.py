@@ -211,6 +211,11 @@ def log(x, prec="f32"):
     return f(float(x))
 
 
+def set_threads(n):
+    """Number of OpenMP threads used by vec_task_step."""
+    lib().rsxo_set_threads(int(n))
+
+
 def vec_task_step(envs, n_steps, prec="f32"):
     """OpenMP over envs (cpu_baseline)."""
     arr = (C.c_void_p * len(envs))(*[e.h for e in envs])

@@ -196,6 +196,13 @@ static inline float rsxo_log_f32(float x) { /* x in [2^-24, 1] */
     return r;
 }
 
+#ifdef _OPENMP
+#include <omp.h>
+void rsxo_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+#else
+void rsxo_set_threads(int n) { (void)n; }
+#endif
+
 /* ---- instantiate: float ---- */
 #define R float
 #define SUF(n) n##_f32
