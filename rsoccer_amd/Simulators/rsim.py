@@ -1,0 +1,91 @@
+"""Simulator adapters: ``List[Robot]`` commands -> command array, state vector -> ``Frame``.
+
+Same five-method surface as the reference adapters (rsoccer_gym/Simulators/rsim.py):
+``reset(frame)`` (:36), ``send_commands(commands)`` (:91 / :128), ``get_frame()`` (:104 / :157),
+``get_field_params()`` (:49), ``stop()`` (:40).  The native object behind them is
+:mod:`rsoccer_amd.robosim` (HIP) unless another module with the robosim surface is injected
+through ``backend`` (the tests inject a CPU stand-in; the product never does).
+"""
+from typing import List
+
+import numpy as np
+
+from rsoccer_amd.Entities import Field, Frame, FrameSSL, FrameVSS, Robot
+
+
+class RSim:
+    _sim_class_name = None
+    _frame_class = Frame
+    _n_cmd = 0
+
+    def __init__(self, field_type: int, n_robots_blue: int, n_robots_yellow: int,
+                 time_step_ms: int, backend=None):
+        if backend is None:
+            from rsoccer_amd import robosim as backend  # HIP; raises if the library is missing
+        self.n_robots_blue = n_robots_blue
+        self.n_robots_yellow = n_robots_yellow
+        # poses only needed to construct the simulator (rsim.py:20-24)
+        line_up = lambda n, sign: [[sign * 0.2 * i, 0, 0] for i in range(1, n + 1)]
+        self.simulator = getattr(backend, self._sim_class_name)(
+            field_type, n_robots_blue, n_robots_yellow, time_step_ms,
+            [0, 0, 0, 0], line_up(n_robots_blue, -1.0), line_up(n_robots_yellow, 1.0))
+        self.field = self.get_field_params()
+
+    # ---- the five methods the base envs call ----
+    def reset(self, frame: Frame):
+        pos = self._placement_dict_from_frame(frame)
+        self.simulator.reset(pos["ball_pos"], pos["blue_robots_pos"], pos["yellow_robots_pos"])
+
+    def stop(self):
+        sim, self.simulator = self.simulator, None
+        if hasattr(sim, "close"):
+            sim.close()
+        del sim
+
+    def send_commands(self, commands: List[Robot]):
+        rows = np.zeros((self.n_robots_blue + self.n_robots_yellow, self._n_cmd), dtype=np.float64)
+        for cmd in commands:
+            self._fill_row(rows[self.n_robots_blue + cmd.id if cmd.yellow else cmd.id], cmd)
+        self.simulator.step(rows)
+
+    def get_frame(self) -> Frame:
+        return self._frame_class().parse(self.simulator.get_state(), self.n_robots_blue, self.n_robots_yellow)
+
+    def get_field_params(self) -> Field:
+        return Field(**self.simulator.get_field_params())
+
+    # ---- helpers ----
+    def _fill_row(self, row, cmd: Robot):
+        raise NotImplementedError
+
+    @staticmethod
+    def _placement_dict_from_frame(frame: Frame):
+        team = lambda robots: np.array([[r.x, r.y, r.theta] for r in robots.values()])
+        b = frame.ball
+        return {"ball_pos": np.array([b.x, b.y, b.v_x, b.v_y]),
+                "blue_robots_pos": team(frame.robots_blue),
+                "yellow_robots_pos": team(frame.robots_yellow)}
+
+
+class RSimVSS(RSim):
+    _sim_class_name = "VSS"
+    _frame_class = FrameVSS
+    _n_cmd = 2
+
+    def _fill_row(self, row, cmd):
+        row[0], row[1] = cmd.v_wheel0, cmd.v_wheel1
+
+
+class RSimSSL(RSim):
+    _sim_class_name = "SSL"
+    _frame_class = FrameSSL
+    _n_cmd = 8
+
+    def _fill_row(self, row, cmd):
+        # col 0 selects the meaning of cols 1..4 (rsim.py:137-153)
+        row[0] = cmd.wheel_speed
+        if cmd.wheel_speed:
+            row[1:5] = cmd.v_wheel0, cmd.v_wheel1, cmd.v_wheel2, cmd.v_wheel3
+        else:
+            row[1:4] = cmd.v_x, cmd.v_y, cmd.v_theta
+        row[5], row[6], row[7] = cmd.kick_v_x, cmd.kick_v_z, cmd.dribbler

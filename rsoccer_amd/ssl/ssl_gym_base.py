@@ -1,0 +1,13 @@
+"""Base class of the single-environment SSL tasks (RoboCup Small Size League).
+
+Same contract as the reference's ``SSLBaseEnv`` (rsoccer_gym/ssl/ssl_gym_base.py:20-220): it is
+the VSS template with the SSL adapter and the SSL lever arm (robot radius 0.09 + wheel
+thickness 0.005, :58-59).  See :mod:`rsoccer_amd.vss.vss_gym_base` for the hook contract.
+"""
+from rsoccer_amd.Simulators.rsim import RSimSSL
+from rsoccer_amd.vss.vss_gym_base import VSSBaseEnv
+
+
+class SSLBaseEnv(VSSBaseEnv):
+    _SIM_ADAPTER = RSimSSL
+    _LEVER_ARM = 0.095

@@ -1,0 +1,161 @@
+"""SSLStaticDefenders-v0: one holonomic robot with kicker and dribbler starts at the field
+centre and has to score past six static defenders.  Restates the task of
+rsoccer_gym/ssl/ssl_hw_challenge/static_defenders.py:12-322 on top of :class:`SSLBaseEnv`.
+
+Observation Box(24), bounds +-1.2 (:90-112): ball x, y, v_x, v_y; blue 0 x, y, sin, cos, v_x,
+v_y, v_theta, infrared; six yellow (x, y).
+Action Box(5): global v_x, global v_y, v_theta (fractions of 2.5 m/s / 10 rad/s), kick if > 0,
+dribbler if > 0.
+Episode ends (:172-197): robot leaves the attacking half (x < -0.2 or |y| > W/2), robot enters
+the goalkeeper area, ball leaves the attacking half, or ball crosses the goal line (+5 inside
+the goal).  Otherwise shaped reward: approach to the ball + ball progress to the goal - energy.
+"""
+import random
+
+import numpy as np
+
+from rsoccer_amd import gymshim as gym
+from rsoccer_amd.Entities import Ball, Frame, Robot
+from rsoccer_amd.Utils import KDTree
+from rsoccer_amd.ssl.ssl_gym_base import SSLBaseEnv
+
+_INFO_KEYS = ("goal", "rbt_in_gk_area", "done_ball_out", "done_ball_out_right", "done_rbt_out",
+              "ball_dist", "ball_grad", "energy")
+
+
+class SSLHWStaticDefendersEnv(SSLBaseEnv):
+    def __init__(self, field_type=2, render_mode=None, sim_backend=None):
+        super().__init__(field_type=field_type, n_robots_blue=1, n_robots_yellow=6, time_step=0.025,
+                         render_mode=render_mode, sim_backend=sim_backend)
+        self.action_space = gym.spaces.Box(low=-1, high=1, shape=(5,), dtype=np.float32)
+        n_obs = 4 + 8 * self.n_robots_blue + 2 * self.n_robots_yellow
+        self.observation_space = gym.spaces.Box(low=-self.NORM_BOUNDS, high=self.NORM_BOUNDS,
+                                                shape=(n_obs,), dtype=np.float32)
+        # reward scales: farthest robot-ball distance, a quarter of the half-field diagonal and
+        # the wheel effort of a full-speed 1000-step episode (static_defenders.py:64-73)
+        self.ball_dist_scale = np.linalg.norm([self.field.width, self.field.length / 2])
+        self.ball_grad_scale = np.linalg.norm([self.field.width / 2, self.field.length / 2]) / 4
+        self.energy_scale = (160 * 4) * 1000
+        # speed limits of this task replace the motor-derived ones (:76-78)
+        self.max_v = 2.5
+        self.max_w = 10
+        self.kick_speed_x = 5.0
+        self.reward_shaping_total = None
+
+    def reset(self, *, seed=None, options=None):
+        self.reward_shaping_total = None
+        return super().reset(seed=seed, options=options)
+
+    def step(self, action):
+        observation, reward, terminated, truncated, _ = super().step(action)
+        return observation, reward, terminated, truncated, self.reward_shaping_total
+
+    # ---- hooks ----
+    def _frame_to_observations(self):
+        f = self.frame
+        obs = [self.norm_pos(f.ball.x), self.norm_pos(f.ball.y), self.norm_v(f.ball.v_x), self.norm_v(f.ball.v_y)]
+        for i in range(self.n_robots_blue):
+            r = f.robots_blue[i]
+            heading = np.deg2rad(r.theta)
+            obs += [self.norm_pos(r.x), self.norm_pos(r.y), np.sin(heading), np.cos(heading),
+                    self.norm_v(r.v_x), self.norm_v(r.v_y), self.norm_w(r.v_theta), 1 if r.infrared else 0]
+        for i in range(self.n_robots_yellow):
+            r = f.robots_yellow[i]
+            obs += [self.norm_pos(r.x), self.norm_pos(r.y)]
+        return np.array(obs, dtype=np.float32)
+
+    def _get_commands(self, actions):
+        heading = np.deg2rad(self.frame.robots_blue[0].theta)
+        v_x, v_y, v_theta = self.convert_actions(actions, heading)
+        return [Robot(yellow=False, id=0, v_x=v_x, v_y=v_y, v_theta=v_theta,
+                      kick_v_x=self.kick_speed_x if actions[3] > 0 else 0.0,
+                      dribbler=bool(actions[4] > 0))]
+
+    def convert_actions(self, action, angle):
+        """de-normalise, rotate the global velocity into the robot frame, cap its norm"""
+        gx, gy = action[0] * self.max_v, action[1] * self.max_v
+        v_theta = action[2] * self.max_w
+        c, s = np.cos(angle), np.sin(angle)
+        v_x, v_y = gx * c + gy * s, -gx * s + gy * c
+        speed = np.linalg.norm([v_x, v_y])
+        scale = 1 if speed < self.max_v else self.max_v / speed
+        return v_x * scale, v_y * scale, v_theta
+
+    def _calculate_reward_and_done(self):
+        if self.reward_shaping_total is None:
+            self.reward_shaping_total = dict.fromkeys(_INFO_KEYS, 0)
+        total = self.reward_shaping_total
+        fld = self.field
+        half_len, half_wid = fld.length / 2, fld.width / 2
+        ball, robot = self.frame.ball, self.frame.robots_blue[0]
+        in_gk_area = robot.x > half_len - fld.penalty_length and abs(robot.y) < fld.penalty_width / 2
+        if robot.x < -0.2 or abs(robot.y) > half_wid:
+            total["done_rbt_out"] += 1
+            return 0, True
+        if in_gk_area:
+            total["rbt_in_gk_area"] += 1
+            return 0, True
+        if ball.x < 0 or abs(ball.y) > half_wid:
+            total["done_ball_out"] += 1
+            return 0, True
+        if ball.x > half_len:
+            if abs(ball.y) < fld.goal_width / 2:
+                total["goal"] += 1
+                return 5, True
+            total["done_ball_out_right"] += 1
+            return 0, True
+        if self.last_frame is None:
+            return 0, False
+        ball_dist_rw = self._ball_dist_rw() / self.ball_dist_scale
+        ball_grad_rw = self._ball_grad_rw() / self.ball_grad_scale
+        energy_rw = -self._energy_pen() / self.energy_scale
+        total["ball_dist"] += ball_dist_rw
+        total["ball_grad"] += ball_grad_rw
+        total["energy"] += energy_rw
+        return 0 + ball_dist_rw + ball_grad_rw + energy_rw, False
+
+    def _get_initial_positions_frame(self):
+        """robot at the origin; ball and six defenders random on the attacking half, 0.2 m apart,
+        ball outside the goalkeeper area (static_defenders.py:214-254)"""
+        fld = self.field
+        half_len, half_wid = fld.length / 2, fld.width / 2
+        rand_x = lambda: random.uniform(0.2, half_len - 0.1)
+        rand_y = lambda: random.uniform(-half_wid + 0.1, half_wid - 0.1)
+        in_gk_area = lambda o: o.x > half_len - fld.penalty_length and abs(o.y) < fld.penalty_width / 2
+        frame = Frame()
+        frame.robots_blue[0] = Robot(x=0.0, y=0.0, theta=0.0)
+        frame.ball = Ball(x=rand_x(), y=rand_y())
+        while in_gk_area(frame.ball):
+            frame.ball = Ball(x=rand_x(), y=rand_y())
+        placed = KDTree()
+        placed.insert((frame.ball.x, frame.ball.y))
+        placed.insert((0.0, 0.0))
+        for i in range(self.n_robots_yellow):
+            pos = (rand_x(), rand_y())
+            while placed.get_nearest(pos)[1] < 0.2:
+                pos = (rand_x(), rand_y())
+            placed.insert(pos)
+            frame.robots_yellow[i] = Robot(x=pos[0], y=pos[1], theta=random.uniform(0, 360))
+        return frame
+
+    # ---- reward terms ----
+    @staticmethod
+    def _dist(ax, ay, bx, by):
+        return np.linalg.norm(np.array([ax, ay]) - np.array([bx, by]))
+
+    def _ball_dist_rw(self):
+        lf, f = self.last_frame, self.frame
+        before = self._dist(lf.robots_blue[0].x, lf.robots_blue[0].y, lf.ball.x, lf.ball.y)
+        after = self._dist(f.robots_blue[0].x, f.robots_blue[0].y, f.ball.x, f.ball.y)
+        return np.clip(before - after, -1, 1)
+
+    def _ball_grad_rw(self):
+        goal_x = self.field.length / 2
+        lf, f = self.last_frame, self.frame
+        before = self._dist(goal_x, 0.0, lf.ball.x, lf.ball.y)
+        after = self._dist(goal_x, 0.0, f.ball.x, f.ball.y)
+        return np.clip(before - after, -1, 1)
+
+    def _energy_pen(self):
+        r = self.frame.robots_blue[0]
+        return abs(r.v_wheel0) + abs(r.v_wheel1) + abs(r.v_wheel2) + abs(r.v_wheel3)

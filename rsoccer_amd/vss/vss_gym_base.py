@@ -1,0 +1,109 @@
+"""Base class of the single-environment VSS tasks (IEEE Very Small Size Soccer).
+
+Same contract as the reference's ``VSSBaseEnv`` (rsoccer_gym/vss/vss_gym_base.py:19-220):
+construct the simulator adapter, derive the normalisation constants, run the
+``step()`` / ``reset()`` template and let a subclass supply four hooks —
+``_get_commands``, ``_frame_to_observations``, ``_calculate_reward_and_done`` and
+``_get_initial_positions_frame`` (:197-211).  Existing task classes written against the
+reference work unchanged on top of this class; the physics behind ``self.rsim`` is the HIP step
+engine.  This is the compatibility path (one env, one small GPU launch per step); training
+throughput comes from :mod:`rsoccer_amd.vec`.
+"""
+from typing import List
+
+import numpy as np
+
+from rsoccer_amd import gymshim as gym
+from rsoccer_amd.Entities import Frame, Robot
+from rsoccer_amd.Simulators.rsim import RSimVSS
+
+
+class VSSBaseEnv(gym.Env):
+    metadata = {"render.modes": ["human", "rgb_array"], "render_modes": ["human", "rgb_array"],
+                "render_fps": 60, "render.fps": 60}
+    NORM_BOUNDS = 1.2
+    _SIM_ADAPTER = RSimVSS
+    _LEVER_ARM = 0.04  # robot radius 0.0375 + wheel thickness 0.0025 (vss_gym_base.py:57-58)
+
+    def __init__(self, field_type: int, n_robots_blue: int, n_robots_yellow: int, time_step: float,
+                 render_mode=None, sim_backend=None):
+        super().__init__()
+        self.render_mode = render_mode
+        self.time_step = time_step
+        self.rsim = self._SIM_ADAPTER(field_type=field_type, n_robots_blue=n_robots_blue,
+                                      n_robots_yellow=n_robots_yellow,
+                                      time_step_ms=int(self.time_step * 1000), backend=sim_backend)
+        self.n_robots_blue = n_robots_blue
+        self.n_robots_yellow = n_robots_yellow
+        self.field_type = field_type
+        self.field = self.rsim.get_field_params()
+        # normalisers (vss_gym_base.py:52-58 / ssl_gym_base.py:53-59)
+        self.max_pos = max(self.field.width / 2, (self.field.length / 2) + self.field.penalty_length)
+        max_wheel_rad_s = (self.field.rbt_motor_max_rpm / 60) * 2 * np.pi
+        self.max_v = max_wheel_rad_s * self.field.rbt_wheel_radius
+        self.max_w = np.rad2deg(self.max_v / self._LEVER_ARM)
+        self.frame: Frame = None
+        self.last_frame: Frame = None
+        self.steps = 0
+        self.sent_commands = None
+
+    # ---- template methods ----
+    def step(self, action):
+        self.steps += 1
+        commands: List[Robot] = self._get_commands(action)
+        self.rsim.send_commands(commands)
+        self.sent_commands = commands
+        self.last_frame, self.frame = self.frame, self.rsim.get_frame()
+        observation = self._frame_to_observations()
+        reward, done = self._calculate_reward_and_done()
+        if self.render_mode == "human":
+            self.render()
+        return observation, reward, done, False, {}
+
+    def reset(self, *, seed=None, options=None):
+        super().reset(seed=seed, options=options)
+        self.steps = 0
+        self.last_frame = None
+        self.sent_commands = None
+        self.rsim.reset(self._get_initial_positions_frame())
+        self.frame = self.rsim.get_frame()
+        obs = self._frame_to_observations()
+        if self.render_mode == "human":
+            self.render()
+        return obs, {}
+
+    def render(self):
+        raise NotImplementedError(
+            "rendering (pygame) is outside the scope of the step engine; run with render_mode=None")
+
+    def close(self):
+        if self.rsim is not None:
+            self.rsim.stop()
+            self.rsim = None
+
+    # ---- hooks a task implements ----
+    def _get_commands(self, action):
+        """returns a list of commands of type List[Robot] from type action_space action"""
+        raise NotImplementedError
+
+    def _frame_to_observations(self):
+        """returns a type observation_space observation from a type List[Robot] state"""
+        raise NotImplementedError
+
+    def _calculate_reward_and_done(self):
+        """returns reward value and done flag from type List[Robot] state"""
+        raise NotImplementedError
+
+    def _get_initial_positions_frame(self) -> Frame:
+        """returns frame with robots initial positions"""
+        raise NotImplementedError
+
+    # ---- normalisation helpers ----
+    def norm_pos(self, pos):
+        return np.clip(pos / self.max_pos, -self.NORM_BOUNDS, self.NORM_BOUNDS)
+
+    def norm_v(self, v):
+        return np.clip(v / self.max_v, -self.NORM_BOUNDS, self.NORM_BOUNDS)
+
+    def norm_w(self, w):
+        return np.clip(w / self.max_w, -self.NORM_BOUNDS, self.NORM_BOUNDS)

@@ -113,8 +113,10 @@ def main():
     sys.path.insert(0, REF)
     sys.path.insert(0, tmp)
     import robosim
-    vss_field = dict(zip(FIELD_KEYS, O.OracleEnv(0, 0, 3, 3, 25, "f64").field_params()))
-    ssl_field = dict(zip(FIELD_KEYS, O.OracleEnv(1, 2, 1, 6, 25, "f64").field_params()))
+    # plain Python floats, like the dict a pybind11 module returns (numpy scalars would change the
+    # reference's float32/float64 promotion)
+    vss_field = dict(zip(FIELD_KEYS, (float(v) for v in O.OracleEnv(0, 0, 3, 3, 25, "f64").field_params())))
+    ssl_field = dict(zip(FIELD_KEYS, (float(v) for v in O.OracleEnv(1, 2, 1, 6, 25, "f64").field_params())))
     robosim.FIELD["vss"] = vss_field
     robosim.FIELD["ssl"] = ssl_field
 

