@@ -25,7 +25,7 @@ typedef struct SUF(rsxo_env) {
     R a_lin_h, a_lin_h2, a_lat_h, a_ang_h, mu_g_h, g_h, e_ground, vz_min, robot_h;
     R dck_rb, half_kw, ir_tol, drib_gain, drib_vmax, drib_vmax2;
     R ws[4], wc[4], pinv[3][4];
-    R deg2rad, rad2deg, pi, two_pi;
+    R deg2rad, rad2deg, h_deg;
     R state[5 + 11 * MAXROB + 1];
     /* ---- task ---- */
     int task, obs_dim, act_dim, info_dim, max_steps;
@@ -80,7 +80,7 @@ void* SUF(rsxo_create)(int kind, int field_type, int nb, int ny, int ts_ms) {
     for (int k = 0; k < 4; ++k) { e->ws[k] = RC(sin(c->wheel_ang[k])); e->wc[k] = RC(cos(c->wheel_ang[k])); }
     for (int i = 0; i < 3; ++i) for (int k = 0; k < 4; ++k) e->pinv[i][k] = RC(c->pinv[i][k]);
     e->deg2rad = RC(RSXO_PI / 180.0); e->rad2deg = RC(180.0 / RSXO_PI);
-    e->pi = RC(RSXO_PI); e->two_pi = RC(2.0 * RSXO_PI);
+    e->h_deg = RC(c->h * (180.0 / RSXO_PI)); /* heading is integrated in degrees, the wire unit */
     /* adapter's dummy line-up, rsim.py:20-24 */
     e->state[2] = e->r_ball;
     for (int k = 0; k < c->n_robots; ++k) {
@@ -166,7 +166,7 @@ static void SUF(walls)(const SUF(rsxo_env)* e, R r, R rest, R* px, R* py, R* pvx
 /* per-body working record */
 typedef struct SUF(body) {
     R x, y, vx, vy;        /* all */
-    R th, om, c, s;        /* robots: heading (rad), rate, cos/sin(th) */
+    R th, om, c, s;        /* robots: heading (DEGREES), rate (rad/s), cos/sin(heading) */
     R t0, t1, t2;          /* VSS: (v_target, om_target, -) | SSL: (vtx, vty, om_target) */
     R kick_x, kick_z; int drib, ir;
     R z, vz;               /* ball */
@@ -208,9 +208,9 @@ static void SUF(step_core)(SUF(rsxo_env)* e, const R* cmds) {
     for (int k = 0; k < N; ++k) {
         const R* r = s + 5 + RS * k;
         SUF(body)* o = &b[k];
-        o->x = r[0]; o->y = r[1]; o->th = r[2] * e->deg2rad; o->vx = r[3]; o->vy = r[4];
+        o->x = r[0]; o->y = r[1]; o->th = r[2]; o->vx = r[3]; o->vy = r[4];
         o->om = r[5] * e->deg2rad;
-        R_SINCOS(o->th, &o->s, &o->c);
+        R_SINCOS(o->th * e->deg2rad, &o->s, &o->c);
         if (!ssl) {
             R wl = SUF(clampr)(cmds[2 * k], -e->w_max, e->w_max);
             R wr = SUF(clampr)(cmds[2 * k + 1], -e->w_max, e->w_max);
@@ -264,10 +264,10 @@ static void SUF(step_core)(SUF(rsxo_env)* e, const R* cmds) {
             o->vy = vf * o->s + vl * o->c;
             o->x = o->x + o->vx * e->h;
             o->y = o->y + o->vy * e->h;
-            o->th = o->th + o->om * e->h;
-            if (o->th > e->pi) o->th = o->th - e->two_pi;
-            else if (o->th < -e->pi) o->th = o->th + e->two_pi;
-            R_SINCOS(o->th, &o->s, &o->c);
+            o->th = o->th + o->om * e->h_deg;
+            if (o->th > RC(180)) o->th = o->th - RC(360);
+            else if (o->th < RC(-180)) o->th = o->th + RC(360);
+            R_SINCOS(o->th * e->deg2rad, &o->s, &o->c);
         }
         if (ball->z > RC(0) || ball->vz > RC(0)) {
             ball->vz = ball->vz - e->g_h;
@@ -364,7 +364,7 @@ static void SUF(step_core)(SUF(rsxo_env)* e, const R* cmds) {
     for (int k = 0; k < N; ++k) {
         R* r = s + 5 + RS * k;
         const SUF(body)* o = &b[k];
-        r[0] = o->x; r[1] = o->y; r[2] = o->th * e->rad2deg; r[3] = o->vx; r[4] = o->vy;
+        r[0] = o->x; r[1] = o->y; r[2] = o->th; r[3] = o->vx; r[4] = o->vy;
         r[5] = o->om * e->rad2deg;
         if (ssl) {
             r[6] = c->n_sub ? (o->ir ? RC(1) : RC(0)) : r[6];
@@ -648,7 +648,7 @@ void SUF(rsxo_task_step)(void* p, const float* action) {
         for (int k = 1; k < N; ++k) { /* Utils.py:14-21, Box-Muller on Philox */
             SUF(draw)(e, t, RSXO_DOM_OU | ((uint32_t)k << 8), u);
             R u1 = RC((u[0] >> 8) + 1u) * RC(5.9604644775390625e-08);
-            R ang = (SUF(u01)(u[1]) - RC(0.5)) * e->two_pi;
+            R ang = (SUF(u01)(u[1]) - RC(0.5)) * RC(6.283185307179586);
             R rad = R_SQRT(RC(-2) * R_LOG(u1));
             R sn, cs;
             R_SINCOS(ang, &sn, &cs);

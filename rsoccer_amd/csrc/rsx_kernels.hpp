@@ -57,7 +57,7 @@ struct Buffers {
 // what one lane keeps in registers for its body
 struct Body {
     float x, y, vx, vy;       // all bodies
-    float th, om, c, s;       // robots: heading (rad), rate (rad/s), cos/sin(heading)
+    float th, om, c, s;       // robots: heading (DEGREES, the wire unit), rate (rad/s), cos/sin(heading)
     float t0, t1, t2;         // VSS: v target, omega target | SSL: local vx, vy, omega targets
     float kick_x, kick_z;     // SSL
     float z, vz;              // ball: height above rest, vertical speed
@@ -216,10 +216,10 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
             o.vy = vf * o.s + vl * o.c;
             o.x = o.x + o.vx * P.h;
             o.y = o.y + o.vy * P.h;
-            o.th = o.th + o.om * P.h;
-            if (o.th > K::pi) o.th = o.th - K::two_pi;
-            else if (o.th < -K::pi) o.th = o.th + K::two_pi;
-            sincos_f32(o.th, o.s, o.c);
+            o.th = o.th + o.om * P.h_deg;
+            if (o.th > 180.0f) o.th = o.th - 360.0f;
+            else if (o.th < -180.0f) o.th = o.th + 360.0f;
+            sincos_f32(o.th * K::deg2rad, o.s, o.c);
         } else if (is_ball) {
             if (o.z > 0.0f || o.vz > 0.0f) {
                 o.vz = o.vz - P.g_h;
@@ -428,9 +428,9 @@ __device__ __forceinline__ void load_body(const Params& P, const float* __restri
 #pragma unroll
             for (int i = 0; i < 4; ++i) w[i] = r[(7 + i) * B];
         }
-        o.th = th_deg * K::deg2rad;
+        o.th = th_deg;
         o.om = om_deg * K::deg2rad;
-        sincos_f32(o.th, o.s, o.c);
+        sincos_f32(o.th * K::deg2rad, o.s, o.c);
     } else if (is_ball) {
         const float* r = st + e;
         o.x = r[0]; o.y = r[B]; o.z = r[2 * B] - K::r_ball; o.vx = r[3 * B]; o.vy = r[4 * B];
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(64) void sim_step_kernel(const Params P, const Buff
     }
     physics<KIND, L, NR>(P, o, b, g, live, sh);
     if (is_robot) {
-        od = o.th * K::rad2deg; wd = o.om * K::rad2deg;
+        od = o.th; wd = o.om * K::rad2deg;
         if (KIND == RSX_KIND_SSL) wheel_speeds<KIND>(P, o, w);
     }
     store_body<KIND>(P, bufs.state, e, b, is_robot, is_ball, o, od, wd, w, P.n_sub != 0);
@@ -722,7 +722,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
                         else { a0 = u01(u.x) * 2.0f - 1.0f; a1 = u01(u.y) * 2.0f - 1.0f; }
                     } else {  // Ornstein-Uhlenbeck noise, Utils/Utils.py:14-21 (Box-Muller on Philox)
                         float u1 = (float)((u.x >> 8) + 1u) * 5.9604644775390625e-08f;
-                        float ang = (u01(u.y) - 0.5f) * K::two_pi;
+                        float ang = (u01(u.y) - 0.5f) * 6.283185307179586f;
                         float rad = sqrtf(-2.0f * log_f32(u1));
                         float sn, cs;
                         sincos_f32(ang, sn, cs);
@@ -764,11 +764,12 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
 
             // ---- wire-format values, observation, reward ----
             if (is_robot) {
-                od = o.th * K::rad2deg; wd = o.om * K::rad2deg;
+                od = o.th; wd = o.om * K::rad2deg;
                 if (KIND == RSX_KIND_SSL) wheel_speeds<KIND>(P, o, wheels);
-                // theta / omega live in HBM as degrees: keep the lane's copy equal to a reload
-                o.th = od * K::deg2rad; o.om = wd * K::deg2rad;
-                sincos_f32(o.th, o.s, o.c);
+                // omega lives in HBM as deg/s: keep the lane's copy equal to what a reload gives.
+                // (o.s, o.c) already are sin / cos of the stored heading: reused by the
+                // observation and by the next step of a multi-step launch.
+                o.om = wd * K::deg2rad;
             } else if (is_ball) {
                 o.z = (K::r_ball + o.z) - K::r_ball;  // height goes through the wire format too
             }
@@ -872,7 +873,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
                     o.x = pz.x; o.y = pz.y;
                     od = pz.z; wd = 0.0f;
                     wheels[0] = wheels[1] = wheels[2] = wheels[3] = 0.0f;
-                    if (is_robot) { o.th = od * K::deg2rad; sincos_f32(o.th, o.s, o.c); }
+                    if (is_robot) { o.th = od; sincos_f32(o.th * K::deg2rad, o.s, o.c); }
                 }
                 write_obs<KIND, TASK>(P, sh.stage + g * OD, b, is_robot, is_ball, o.x, o.y, o.vx, o.vy, o.s, o.c, wd, 0);
             }

@@ -86,7 +86,6 @@ struct KC {
     static constexpr float half_kw = (float)(D::kick_w / 2), ir_tol = 0.01f;
     static constexpr float drib_vmax = 1.0f, drib_vmax2 = 1.0f;
     static constexpr float deg2rad = (float)(PI_D / 180.0), rad2deg = (float)(180.0 / PI_D);
-    static constexpr float pi = (float)PI_D, two_pi = (float)(2.0 * PI_D);
 };
 
 // per-task literals
@@ -114,7 +113,7 @@ template <> struct TC<RSX_TASK_SSL_STATIC_DEFENDERS> {  // static_defenders.py:7
 struct Params {
     int kind, n_blue, n_yellow, n_robots, n_sub, state_dim, num_envs;
     // sub-step and field dependent
-    float h, a_lin_h, a_lin_h2, a_lat_h, a_ang_h, mu_g_h, g_h, drib_gain;
+    float h, h_deg, a_lin_h, a_lin_h2, a_lat_h, a_ang_h, mu_g_h, g_h, drib_gain;
     float half_len, half_wid, ghw, gd;
     // omni-wheel kinematics (SSL; used once per step)
     float ws[4], wc[4], pinv[3][4];
@@ -159,6 +158,7 @@ inline int derive_model_k(int field_type, int ts_ms, Params& P, HostModel& M) {
     M.dt = ts_ms * 0.001;
     const double h = P.n_sub ? M.dt / P.n_sub : 0.0;
     P.h = (float)h;
+    P.h_deg = (float)(h * (180.0 / PI_D));      // heading is integrated in degrees, the wire unit
     P.a_lin_h = (float)(D::a_lin * h); P.a_lin_h2 = (float)((D::a_lin * h) * (D::a_lin * h));
     P.a_lat_h = (float)(D::a_lat * h); P.a_ang_h = (float)(D::a_ang * h);
     P.mu_g_h = (float)(D::mu_g * h); P.g_h = (float)(GRAV_D * h);

@@ -1,0 +1,128 @@
+"""Fused batched tasks (one kernel launch per ``step()``)."""
+import numpy as np
+
+from rsoccer_amd import _lib
+from rsoccer_amd import gymshim as gym
+
+_VSS_INFO = ("goal_score", "move", "ball_grad", "energy", "goals_blue", "goals_yellow")
+_SD_INFO = ("goal", "rbt_in_gk_area", "done_ball_out", "done_ball_out_right", "done_rbt_out",
+            "ball_dist", "ball_grad", "energy")
+
+
+class VecFusedEnv:
+    """``num_envs`` copies of a fused task on one GPU.
+
+    ``reset()`` -> ``(obs, info)``; ``step(actions)`` -> ``(obs, reward, terminated, truncated,
+    info)`` like ``gymnasium.vector`` with same-step auto-reset: when an env's episode ends
+    (task ``done`` or the registry's TimeLimit) it is re-placed inside the same call, ``obs``
+    already holds the first observation of its next episode and ``info["final_obs"]`` the
+    terminal one.  All returned arrays are torch tensors on the env's device that VIEW the
+    engine's buffers (no copies): they are overwritten by the next ``step()``.
+
+    Every random draw (placement, OU noise, random actions) is keyed by
+    ``(seed, env_id_base + env index, episode, step)``, so results do not depend on
+    ``num_envs`` or on how a population of envs is split over GPUs.
+    """
+
+    KIND = None
+    TASK = None
+    FIELD_TYPE = 0
+    N_BLUE = N_YELLOW = 0
+    INFO_KEYS = ()
+    TIME_STEP = 0.025
+
+    def __init__(self, num_envs, device=0, seed=0, env_id_base=0, max_episode_steps=None,
+                 field_type=None):
+        import torch
+        self._torch = torch
+        self.num_envs = int(num_envs)
+        self.device = torch.device("cuda", int(device))
+        ft = self.FIELD_TYPE if field_type is None else field_type
+        self.sim = _lib.Sim(self.KIND, ft, self.N_BLUE, self.N_YELLOW, int(self.TIME_STEP * 1000),
+                            self.num_envs, int(device))
+        self.sim.task_attach(self.TASK, int(seed), int(env_id_base), int(max_episode_steps or 0))
+        self.max_episode_steps = self.sim.max_episode_steps
+        self._t = self.sim.task_tensors()
+        self.field = self.sim.get_field_params()
+        self.single_action_space = gym.spaces.Box(low=-1, high=1, shape=(self.sim.act_dim,), dtype=np.float32)
+        self.single_observation_space = gym.spaces.Box(low=-1.2, high=1.2, shape=(self.sim.obs_dim,), dtype=np.float32)
+        self.action_space, self.observation_space = self.single_action_space, self.single_observation_space
+
+    # ---- gym-like surface ----
+    def _stream(self):
+        return self._torch.cuda.current_stream(self.device).cuda_stream
+
+    def _info(self):
+        t = self._t
+        info = {k: t["info"][i] for i, k in enumerate(self.INFO_KEYS)}
+        info["final_obs"] = t["final_obs"]
+        info["episode_steps"] = t["steps"]
+        return info
+
+    def reset(self, *, seed=None, options=None):
+        """New random placement for every env.  ``seed`` is accepted for API compatibility; the
+        random streams are fixed by the constructor's ``seed`` (episode counters advance)."""
+        self.sim.task_reset(self._stream())
+        return self._t["obs"], {}
+
+    def reset_to(self, ball, blue, yellow, env_mask=None):
+        """Start new episodes on explicit placements (arrays as ``robosim.reset``: ball [B,4],
+        blue [B,nb,3], yellow [B,ny,3]); ``env_mask`` selects the envs to touch."""
+        self.sim.task_reset_to(ball, blue, yellow, env_mask, self._stream())
+        return self._t["obs"], {}
+
+    def step(self, actions=None):
+        """actions: ``[num_envs, act_dim]`` float32 (torch CUDA tensor = zero-copy; numpy is
+        staged through a device buffer) or None for uniform random actions drawn on device."""
+        torch = self._torch
+        ptr = None
+        if actions is not None:
+            if isinstance(actions, torch.Tensor):
+                a = actions
+                if a.device != self.device or a.dtype != torch.float32 or not a.is_contiguous():
+                    a = a.to(device=self.device, dtype=torch.float32).contiguous()
+            else:
+                a = self._t["actions"]
+                a.copy_(torch.from_numpy(np.ascontiguousarray(actions, dtype=np.float32)), non_blocking=True)
+            if tuple(a.shape) != (self.num_envs, self.sim.act_dim):
+                raise ValueError(f"actions must be [{self.num_envs}, {self.sim.act_dim}], got {tuple(a.shape)}")
+            self._keep = a  # keep the tensor alive until the launch has consumed it
+            ptr = a.data_ptr()
+        self.sim.task_step(ptr, self._stream())
+        t = self._t
+        return t["obs"], t["reward"], t["terminated"], t["truncated"], self._info()
+
+    def step_random(self, n=1, fused=False):
+        """``n`` steps with device-side random actions: ``n`` launches issued from C, or
+        (``fused=True``) one launch that keeps the state in registers between steps."""
+        (self.sim.task_rollout if fused else self.sim.task_step_n)(int(n), self._stream())
+        t = self._t
+        return t["obs"], t["reward"], t["terminated"], t["truncated"], self._info()
+
+    def metrics(self):
+        """Counters accumulated on device since construction (synchronises the stream)."""
+        m = self.sim.read_metrics(self._stream())
+        out = dict(zip(_lib.METRIC_NAMES, (int(v) for v in m)))
+        out["return_sum"] = out.pop("return_sum_q20") / float(1 << 20)
+        return out
+
+    @property
+    def state(self):
+        """[state_dim + 1, num_envs] float32 view of the SoA simulator state."""
+        return self.sim.state_tensor()
+
+    def close(self):
+        self.sim.close()
+
+
+class VecVSSEnv(VecFusedEnv):
+    """VSS-v0 (rsoccer_gym/vss/env_vss/vss_gym.py:13): obs 40, action 2, TimeLimit 1200."""
+    KIND, TASK, FIELD_TYPE, N_BLUE, N_YELLOW = _lib.KIND_VSS, _lib.TASK_VSS_V0, 0, 3, 3
+    INFO_KEYS = _VSS_INFO
+
+
+class VecSSLStaticDefendersEnv(VecFusedEnv):
+    """SSLStaticDefenders-v0 (ssl/ssl_hw_challenge/static_defenders.py:12): obs 24, action 5,
+    TimeLimit 1000, hardware-challenge field (field_type 2)."""
+    KIND, TASK, FIELD_TYPE, N_BLUE, N_YELLOW = _lib.KIND_SSL, _lib.TASK_SSL_STATIC_DEFENDERS, 2, 1, 6
+    INFO_KEYS = _SD_INFO

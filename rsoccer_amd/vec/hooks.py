@@ -1,0 +1,149 @@
+"""Batched form of the reference's subclass contract.
+
+The reference asks a task author for four hooks over ONE frame
+(rsoccer_gym/vss/vss_gym_base.py:197-211, ssl/ssl_gym_base.py:197-211).  Here the same four
+hooks see ``num_envs`` frames at once: every ``frame.ball.x`` / ``frame.robots_blue[i].theta``
+is a ``[B]`` float32 tensor that views one row of the simulator's SoA state (no copy), commands
+are written into ``self.commands`` (a ``[n_robots, C, B]`` view of the command buffer), and the
+hooks are ordinary torch code running on the device.  The physics in between is one launch of
+the raw step kernel (``rsx_step_dev``).
+"""
+import numpy as np
+
+from rsoccer_amd import _lib
+from rsoccer_amd.Entities import Field
+
+_VSS_BLOCK = ("x", "y", "theta", "v_x", "v_y", "v_theta")
+_SSL_BLOCK = _VSS_BLOCK + ("infrared", "v_wheel0", "v_wheel1", "v_wheel2", "v_wheel3")
+
+
+class _Rows:
+    """attribute -> row of a [rows, B] tensor"""
+
+    def __init__(self, state, base, names):
+        object.__setattr__(self, "_state", state)
+        object.__setattr__(self, "_index", {n: base + i for i, n in enumerate(names)})
+
+    def __getattr__(self, name):
+        try:
+            return self._state[self._index[name]]
+        except KeyError:
+            raise AttributeError(name) from None
+
+    def __setattr__(self, name, value):
+        self._state[self._index[name]].copy_(value) if hasattr(value, "shape") else self._state[self._index[name]].fill_(value)
+
+
+class VecFrame:
+    """``frame.ball.{x,y,z,v_x,v_y}``, ``frame.robots_blue[i].<field>``, ``frame.robots_yellow[i].<field>``
+    as [B] tensors (units of Entities/Frame.py:8: m, m/s, degrees, degrees/s)."""
+
+    def __init__(self, state, n_blue, n_yellow, kind):
+        block = _VSS_BLOCK if kind == _lib.KIND_VSS else _SSL_BLOCK
+        w = len(block)
+        self.state = state
+        self.ball = _Rows(state, 0, ("x", "y", "z", "v_x", "v_y"))
+        self.robots_blue = {i: _Rows(state, 5 + w * i, block) for i in range(n_blue)}
+        self.robots_yellow = {i: _Rows(state, 5 + w * (n_blue + i), block) for i in range(n_yellow)}
+
+    def clone(self):
+        f = object.__new__(VecFrame)
+        st = self.state.clone()
+        f.state = st
+        f.ball = _Rows(st, 0, ("x", "y", "z", "v_x", "v_y"))
+        rb = lambda rows: {i: _Rows(st, min(r._index.values()), tuple(r._index)) for i, r in rows.items()}
+        f.robots_blue, f.robots_yellow = rb(self.robots_blue), rb(self.robots_yellow)
+        return f
+
+
+class _VecBaseEnv:
+    KIND = None
+    NORM_BOUNDS = 1.2
+    _LEVER_ARM = 0.04
+
+    def __init__(self, field_type, n_robots_blue, n_robots_yellow, time_step, num_envs, device=0,
+                 keep_last_frame=True):
+        import torch
+        self._torch = torch
+        self.num_envs = int(num_envs)
+        self.device = torch.device("cuda", int(device))
+        self.time_step = time_step
+        self.n_robots_blue, self.n_robots_yellow = n_robots_blue, n_robots_yellow
+        self.field_type = field_type
+        self.sim = _lib.Sim(self.KIND, field_type, n_robots_blue, n_robots_yellow, int(time_step * 1000),
+                            self.num_envs, int(device))
+        self.field = Field(**self.sim.get_field_params())
+        self.max_pos = max(self.field.width / 2, self.field.length / 2 + self.field.penalty_length)
+        self.max_v = (self.field.rbt_motor_max_rpm / 60) * 2 * np.pi * self.field.rbt_wheel_radius
+        self.max_w = float(np.rad2deg(self.max_v / self._LEVER_ARM))
+        n = n_robots_blue + n_robots_yellow
+        self.frame = VecFrame(self.sim.state_tensor(), n_robots_blue, n_robots_yellow, self.KIND)
+        self.commands = self.sim.cmds_tensor().view(n, self.sim.cmd_dim, self.num_envs)
+        self.keep_last_frame = keep_last_frame
+        self.last_frame = None
+        self.steps = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+
+    def _stream(self):
+        return self._torch.cuda.current_stream(self.device).cuda_stream
+
+    def step(self, action):
+        self.steps += 1
+        self.commands.zero_()
+        self._get_commands(action)          # fills self.commands
+        if self.keep_last_frame:
+            self.last_frame = self.frame.clone()
+        self.sim.step_dev(self._stream())
+        obs = self._frame_to_observations()
+        reward, done = self._calculate_reward_and_done()
+        return obs, reward, done, self._torch.zeros_like(done), {}
+
+    def reset(self, env_mask=None):
+        """(Re)place the envs selected by ``env_mask`` (host bool array, default all)."""
+        ball, blue, yellow = self._get_initial_positions()
+        self.sim.reset(ball, blue, yellow, env_mask, self._stream())
+        if env_mask is None:
+            self.steps.zero_()
+        else:
+            self.steps[self._torch.as_tensor(np.asarray(env_mask, dtype=bool), device=self.device)] = 0
+        self.last_frame = None
+        return self._frame_to_observations(), {}
+
+    def close(self):
+        self.sim.close()
+
+    # ---- hooks ----
+    def _get_commands(self, action):
+        """write the commands of this step into self.commands ([n_robots, C, B])"""
+        raise NotImplementedError
+
+    def _frame_to_observations(self):
+        """returns the [B, obs_dim] observation tensor from self.frame"""
+        raise NotImplementedError
+
+    def _calculate_reward_and_done(self):
+        """returns ([B] reward, [B] done) tensors from self.frame / self.last_frame"""
+        raise NotImplementedError
+
+    def _get_initial_positions(self):
+        """returns host arrays ball [B,4], blue [B,nb,3], yellow [B,ny,3]"""
+        raise NotImplementedError
+
+    # ---- normalisation helpers (vss_gym_base.py:213-220) ----
+    def norm_pos(self, pos):
+        return self._torch.clamp(pos / self.max_pos, -self.NORM_BOUNDS, self.NORM_BOUNDS)
+
+    def norm_v(self, v):
+        return self._torch.clamp(v / self.max_v, -self.NORM_BOUNDS, self.NORM_BOUNDS)
+
+    def norm_w(self, w):
+        return self._torch.clamp(w / self.max_w, -self.NORM_BOUNDS, self.NORM_BOUNDS)
+
+
+class VecVSSBaseEnv(_VecBaseEnv):
+    KIND = _lib.KIND_VSS
+    _LEVER_ARM = 0.04
+
+
+class VecSSLBaseEnv(_VecBaseEnv):
+    KIND = _lib.KIND_SSL
+    _LEVER_ARM = 0.095

@@ -1,0 +1,203 @@
+"""The Python surfaces on the real engine (MI355X): robosim-compatible classes, the
+reference-shaped single-env tasks, the fused batched envs and the batched-hook base classes."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+import fake_robosim
+from helpers import f32_equal
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.npz"))
+
+
+def test_robosim_classes_match_the_oracle_bitwise(oracle_mod):
+    from rsoccer_amd import robosim
+    rng = np.random.default_rng(0)
+    for cls, kind, ft, nb, ny, C in ((robosim.VSS, 0, 0, 3, 3, 2), (robosim.SSL, 1, 2, 1, 6, 8)):
+        line = lambda n, s: [[s * 0.2 * i, 0, 0] for i in range(1, n + 1)]
+        sim = cls(ft, nb, ny, 25, [0, 0, 0.3, 0.1], line(nb, -1), line(ny, 1))
+        ref = oracle_mod.OracleEnv(kind, ft, nb, ny, 25, "f32")
+        ref.reset([0, 0, 0.3, 0.1], np.array(line(nb, -1)), np.array(line(ny, 1)))
+        assert set(sim.get_field_params()) == set(fake_robosim.VSS(0, 1, 0, 25, [0] * 4, [[0, 0, 0]], []).get_field_params())
+        for t in range(30):
+            cmds = rng.uniform(-40, 40, (nb + ny, C))
+            if kind == 1:
+                cmds[:, 0] = 0; cmds[:, 4:] = 0
+            sim.step(cmds); ref.step(cmds)
+            st = sim.get_state()
+            assert st.dtype == np.float64 and f32_equal(st, ref.get_state())
+        sim.close()
+
+
+def test_single_env_tasks_replay_reference_episodes_on_gpu():
+    """The reference-shaped VSSEnv / StaticDefenders classes with the HIP engine behind them
+    reproduce the recorded reference episodes (float64 oracle physics) to fp32 accuracy."""
+    from rsoccer_amd.ssl.ssl_hw_challenge import SSLHWStaticDefendersEnv
+    from rsoccer_amd.vss.env_vss import VSSEnv
+    env = VSSEnv()
+    random.seed(102); np.random.seed(202)
+    obs, _ = env.reset()
+    assert np.allclose(obs, G["vss_ep2_obs0"], atol=1e-6)
+    for t in range(25):
+        o, r, d, tr, info = env.step(G["vss_ep2_actions"][t])
+        assert np.allclose(o, G["vss_ep2_obs"][t], atol=2e-4), t
+        assert abs(r - G["vss_ep2_reward"][t]) < 2e-3 and d == bool(G["vss_ep2_done"][t])
+    env.close()
+    env = SSLHWStaticDefendersEnv(field_type=2)
+    random.seed(300)
+    obs, _ = env.reset()
+    assert np.allclose(obs, G["sd_ep0_obs0"], atol=1e-6)
+    for t in range(20):
+        o, r, d, tr, info = env.step(G["sd_ep0_actions"][t])
+        assert np.allclose(o, G["sd_ep0_obs"][t], atol=2e-4), t
+        assert abs(r - G["sd_ep0_reward"][t]) < 1e-3
+    env.close()
+
+
+def test_make_vss_v0_runs_1200_steps():
+    """BASELINE.json configs[0] on the real engine: VSS-v0, 1 env, random actions."""
+    import rsoccer_amd
+    env = rsoccer_amd.make("VSS-v0")
+    random.seed(1); np.random.seed(1)
+    obs, _ = env.reset(seed=0)
+    n = 0
+    while True:
+        obs, r, term, trunc, info = env.step(env.action_space.sample())
+        n += 1
+        assert obs.shape == (40,) and obs.dtype == np.float32 and np.all(np.abs(obs) <= 1.2 + 1e-6)
+        if term or trunc:
+            break
+    assert n <= 1200 and (term or n == 1200)
+    env.close()
+
+
+def test_fused_observation_matches_reference_arithmetic():
+    """The device-side observation of arbitrary states equals the reference's (golden vectors)."""
+    import torch
+    from rsoccer_amd import _lib as L
+    for task, kind, ft, nb, ny, key in ((1, 0, 0, 3, 3, "vss"), (2, 1, 2, 1, 6, "sd")):
+        states = G[f"{key}_obs_states"]
+        B = len(states)
+        sim = L.Sim(kind, ft, nb, ny, 25, B)
+        sim.task_attach(task, 0, 0, 0)
+        sim.set_state(np.concatenate([states, np.zeros((B, 1))], 1))
+        dummy = (np.zeros((B, 4)), np.zeros((B, nb, 3)), np.zeros((B, ny, 3)))
+        sim.task_reset_to(*dummy, env_mask=np.zeros(B, dtype=np.uint8))   # nothing teleported: obs refresh only
+        torch.cuda.synchronize()
+        obs = sim.task_tensors()["obs"].cpu().numpy()
+        assert np.max(np.abs(obs - G[f"{key}_obs"])) <= 3e-6
+        sim.close()
+
+
+def test_vec_env_api_and_determinism():
+    import torch
+    from rsoccer_amd.vec import VecSSLStaticDefendersEnv, VecVSSEnv
+    for cls, od, ad in ((VecVSSEnv, 40, 2), (VecSSLStaticDefendersEnv, 24, 5)):
+        a = cls(256, seed=3)
+        b = cls(256, seed=3)
+        c = cls(256, seed=4)
+        oa, _ = a.reset(); ob, _ = b.reset(); oc, _ = c.reset()
+        assert oa.shape == (256, od) and oa.dtype == torch.float32 and oa.is_cuda
+        assert torch.equal(oa, ob) and not torch.equal(oa, oc)
+        gen = torch.Generator(device="cuda").manual_seed(0)
+        ret = torch.zeros(256, device="cuda")
+        for t in range(50):
+            act = torch.rand(256, ad, device="cuda", generator=gen) * 2 - 1
+            oa, ra, ta, tra, ia = a.step(act)
+            ob, rb, tb, trb, ib = b.step(act.cpu().numpy())       # host actions take the staging path
+            assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(ta, tb)
+            assert ra.shape == (256,) and ta.dtype == torch.uint8 and set(ia) >= set(cls.INFO_KEYS)
+            ret += ra
+        assert torch.isfinite(ret).all() and oa.abs().max() <= 1.2 + 1e-6
+        a.step_random(30); a.step_random(30, fused=True)
+        m = a.metrics()
+        assert m["env_steps"] == 256 * 110 and m["episodes"] >= 0
+        with pytest.raises(ValueError):
+            a.step(torch.zeros(3, ad, device="cuda"))
+        for e in (a, b, c):
+            e.close()
+
+
+def test_time_limit_truncates_and_auto_resets():
+    import torch
+    from rsoccer_amd.vec import VecVSSEnv
+    env = VecVSSEnv(64, seed=1, max_episode_steps=7)
+    env.reset()
+    for t in range(1, 22):
+        obs, r, term, trunc, info = env.step(None)
+        steps = info["episode_steps"]
+        if t % 7 == 0:
+            assert bool(((trunc == 1) | (term == 1)).all())
+            assert bool((steps == 0).all())
+            assert not torch.equal(obs, info["final_obs"])
+        else:
+            ended = (term == 1)
+            assert bool((trunc[~ended] == 0).all())
+    m = env.metrics()
+    assert m["episodes"] >= 64 * 3 and m["episode_len_sum"] <= 64 * 21
+    env.close()
+
+
+def test_batched_hooks_env_matches_fused_kernel():
+    """A VSS-v0-like task written with the batched hooks (torch on VecFrame) sees the same
+    physics as the raw kernel and produces the reference observation layout."""
+    import torch
+    from rsoccer_amd.vec import VecVSSBaseEnv
+
+    class Task(VecVSSBaseEnv):
+        def __init__(self, n):
+            super().__init__(0, 3, 3, 0.025, n)
+            self.rng = np.random.default_rng(0)
+
+        def _get_commands(self, action):
+            v = torch.clamp(action * self.max_v, -self.max_v, self.max_v)
+            v = torch.where(v.abs() < 0.05, torch.zeros_like(v), v) / self.field.rbt_wheel_radius
+            self.commands[0, 0].copy_(v[:, 0]); self.commands[0, 1].copy_(v[:, 1])
+
+        def _frame_to_observations(self):
+            f = self.frame
+            cols = [self.norm_pos(f.ball.x), self.norm_pos(f.ball.y), self.norm_v(f.ball.v_x), self.norm_v(f.ball.v_y)]
+            for i in range(3):
+                r = f.robots_blue[i]
+                th = torch.deg2rad(r.theta)
+                cols += [self.norm_pos(r.x), self.norm_pos(r.y), torch.sin(th), torch.cos(th), self.norm_v(r.v_x),
+                         self.norm_v(r.v_y), self.norm_w(r.v_theta)]
+            for i in range(3):
+                r = f.robots_yellow[i]
+                cols += [self.norm_pos(r.x), self.norm_pos(r.y), self.norm_v(r.v_x), self.norm_v(r.v_y), self.norm_w(r.v_theta)]
+            return torch.stack(cols, 1)
+
+        def _calculate_reward_and_done(self):
+            done = self.frame.ball.x.abs() > self.field.length / 2
+            moved = self.frame.ball.x - self.last_frame.ball.x
+            return moved, done
+
+        def _get_initial_positions(self):
+            B = self.num_envs
+            ball = np.zeros((B, 4)); ball[:, :2] = self.rng.uniform(-0.3, 0.3, (B, 2))
+            blue = np.zeros((B, 3, 3)); yellow = np.zeros((B, 3, 3))
+            for k in range(3):
+                blue[:, k, :2] = [-0.5, 0.3 * (k - 1)]
+                yellow[:, k, :2] = [0.5, 0.3 * (k - 1)]; yellow[:, k, 2] = 180.0
+            return ball, blue, yellow
+
+    env = Task(128)
+    obs, _ = env.reset()
+    assert obs.shape == (128, 40) and obs.is_cuda
+    from oracle import oracle as O
+    ref = O.OracleEnv(0, 0, 3, 3, 25, "f32")
+    st0 = env.sim.get_state_full()
+    ref.set_state_full(st0[5])
+    act = torch.full((128, 2), 0.5, device="cuda")
+    for _ in range(10):
+        obs, rew, done, trunc, _ = env.step(act)
+        ref.step(env.commands[:, :, 5].cpu().numpy().astype(np.float64))
+    torch.cuda.synchronize()
+    assert f32_equal(env.sim.get_state_full()[5], ref.get_state_full())
+    assert rew.shape == (128,) and done.dtype == torch.bool
+    assert float(env.frame.robots_blue[0].v_x.mean()) > 0.1      # the agent robot did move
+    assert float(env.frame.robots_yellow[1].v_x.abs().max()) == 0.0
+    env.close()

@@ -1,0 +1,315 @@
+"""Known-answer and invariant tests of the 2-D step model (DESIGN.md "Physics model").
+
+The model is this project's own specification (the reference's physics lives in rc-robosim,
+which is absent); these tests are what defines acceptable behaviour, derived from what the
+reference's task code expects of a simulator.  They run against the CPU oracle
+in both precisions here, and — marked gpu — against the HIP engine through the
+robosim-compatible classes.
+"""
+import math
+
+import numpy as np
+import pytest
+
+
+def _make(backend, kind, ft, nb, ny, ts=25):
+    line = lambda n, s: [[s * 0.2 * i, 0, 0] for i in range(1, n + 1)]
+    if backend == "hip":
+        from rsoccer_amd import robosim
+        cls = robosim.VSS if kind == 0 else robosim.SSL
+        return cls(ft, nb, ny, ts, [0, 0, 0, 0], line(nb, -1), line(ny, 1))
+    import fake_robosim
+    fake_robosim.arm()
+    fake_robosim.PREC = backend
+    cls = fake_robosim.VSS if kind == 0 else fake_robosim.SSL
+    try:
+        return cls(ft, nb, ny, ts, [0, 0, 0, 0], line(nb, -1), line(ny, 1))
+    finally:
+        fake_robosim.PREC = "f64"
+
+
+BACKENDS = [pytest.param("f64", id="oracle-f64"), pytest.param("f32", id="oracle-f32"),
+            pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+FAR = [[5.0 + i, 5.0, 0.0] for i in range(8)]  # parking spots outside every field (walls clamp them)
+
+
+def _vss(backend, ball, blue0, others=None):
+    s = _make(backend, 0, 0, 3, 3)
+    blue = [blue0, [-0.6, 0.5, 0.0], [-0.6, -0.5, 0.0]]
+    yel = [[0.6, 0.5, 0.0], [0.6, 0.0, 0.0], [0.6, -0.5, 0.0]]
+    s.reset(np.array(ball, float), np.array(blue, float), np.array(yel, float))
+    return s
+
+
+def _ssl(backend, ball, blue0, ft=2, ny=0, yellow=None):
+    s = _make(backend, 1, ft, 1, ny)
+    s.reset(np.array(ball, float), np.array([blue0], float), np.array(yellow if yellow is not None else np.zeros((0, 3)), float))
+    return s
+
+
+def _cmd(n, c, rows):
+    a = np.zeros((n, c))
+    for i, r in rows.items():
+        a[i, :len(r)] = r
+    return a
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_state_layout_and_field(backend, oracle_mod):
+    s = _vss(backend, [0.1, 0.2, 0.3, -0.4], [-0.3, 0.1, 45.0])
+    st = s.get_state()
+    assert st.shape == (41,) and st.dtype == np.float64
+    f = s.get_field_params()
+    assert list(f)[:3] == ["length", "width", "penalty_length"] and len(f) == 17
+    assert np.allclose(st[:5], [0.1, 0.2, f["ball_radius"], 0.3, -0.4], atol=1e-7)
+    assert np.allclose(st[5:11], [-0.3, 0.1, 45.0, 0, 0, 0], atol=1e-5)
+    s2 = _ssl(backend, [1, 0, 0, 0], [0, 0, 0], ny=2, yellow=[[2, 1, 10], [2, -1, 20]])
+    assert s2.get_state().shape == (5 + 11 * 3,)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_differential_drive_straight_and_arc(backend, oracle_mod):
+    f = _vss(backend, [0.6, 0.55, 0, 0], [0, 0, 0]).get_field_params()
+    rw, b = f["rbt_wheel_radius"], 0.04
+    # equal wheels: straight line along the heading, speed -> r_w * w
+    s = _vss(backend, [0.6, 0.55, 0, 0], [-0.5, 0.0, 0.0])
+    for _ in range(20):
+        s.step(_cmd(6, 2, {0: [20.0, 20.0]}))
+    st = s.get_state()
+    assert abs(st[8] - rw * 20.0) < 1e-5 and abs(st[9]) < 1e-6 and abs(st[6]) < 1e-6 and abs(st[10]) < 1e-4
+    assert -0.5 < st[5] < 0.2
+    # unequal wheels: omega -> r_w (wr - wl) / (2 b), turning radius v / omega
+    s = _vss(backend, [0.6, 0.55, 0, 0], [0.0, 0.0, 0.0])
+    for _ in range(12):
+        s.step(_cmd(6, 2, {0: [10.0, 14.0]}))
+    st = s.get_state()
+    om = math.radians(st[10]); v = math.hypot(st[8], st[9])
+    assert abs(om - rw * 4.0 / (2 * b)) < 1e-3
+    assert abs(v / om - (rw * 12.0) / (rw * 4.0 / (2 * b))) < 2e-3
+    # wheel speeds saturate at the motor limit
+    s = _vss(backend, [0.6, 0.55, 0, 0], [-0.5, 0.0, 0.0])
+    for _ in range(30):
+        s.step(_cmd(6, 2, {0: [1e4, 1e4]}))
+    wmax = f["rbt_motor_max_rpm"] / 60 * 2 * math.pi
+    assert abs(s.get_state()[8] - rw * wmax) < 1e-4 or abs(s.get_state()[5]) > 0.6  # reached top speed (or the wall)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_idle_robots_stay_at_rest(backend, oracle_mod):
+    """contested_possession.py:166-169 / dribbling.py:143-145 read any yellow speed > 0.05 m/s as
+    a collision: untouched robots with zero commands must not creep."""
+    s = _vss(backend, [0.0, 0.3, 0, 0], [0, -0.3, 30.0])
+    before = s.get_state()
+    for _ in range(40):
+        s.step(np.zeros((6, 2)))
+    after = s.get_state()
+    assert np.array_equal(after[5:], before[5:])
+    y = [[1.0, 0.5, 0], [2.0, -0.5, 90.0]]
+    s = _ssl(backend, [0.5, 1.5, 0, 0], [0, 0, 0], ny=2, yellow=y)
+    before = s.get_state()
+    for _ in range(40):
+        s.step(np.zeros((3, 8)))
+    assert np.array_equal(s.get_state()[5:], before[5:])
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_ball_rolls_to_a_stop(backend, oracle_mod):
+    s = _vss(backend, [-0.5, 0.0, 0.6, 0.0], [0, 0.5, 0])
+    xs = []
+    for _ in range(120):
+        s.step(np.zeros((6, 2)))
+        xs.append(s.get_state()[[0, 3]].copy())
+    xs = np.array(xs)
+    assert xs[-1, 1] == 0.0                                  # stopped exactly
+    decel = (xs[0, 1] - xs[10, 1]) / (10 * 0.025)
+    assert abs(decel - 0.3) < 1e-3                            # constant rolling deceleration
+    assert abs((xs[-1, 0] + 0.5) - 0.6 ** 2 / (2 * 0.3)) < 0.01  # stopping distance v^2 / (2 a)
+    assert np.all(np.diff(xs[:, 1]) <= 1e-9)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_walls_and_goal_mouth(backend, oracle_mod):
+    f = _vss(backend, [0, 0, 0, 0], [0, 0.5, 0]).get_field_params()
+    L, W, gw, gd, rb = f["length"], f["width"], f["goal_width"], f["goal_depth"], f["ball_radius"]
+    # side wall: the ball bounces back with the wall's restitution and never leaves the field
+    s = _vss(backend, [0.0, 0.55, 0.0, 1.0], [0, -0.5, 0])
+    vy = []
+    for _ in range(8):
+        s.step(np.zeros((6, 2)))
+        st = s.get_state()
+        assert abs(st[1]) <= W / 2 - rb + 1e-6
+        vy.append(st[4])
+    assert min(vy) < -0.5 and abs(min(vy) / 1.0 + 0.6) < 0.03
+    # end wall outside the goal mouth: bounce
+    s = _vss(backend, [0.6, 0.4, 1.5, 0.0], [0, -0.5, 0])
+    for _ in range(10):
+        s.step(np.zeros((6, 2)))
+        assert s.get_state()[0] <= L / 2 - rb + 1e-6
+    assert s.get_state()[3] < 0
+    # through the goal mouth: the ball crosses x = L/2 (what vss_gym.py:161 calls a goal) and is
+    # stopped by the back wall of the goal
+    s = _vss(backend, [0.6, 0.05, 1.5, 0.0], [0, -0.5, 0])
+    crossed = False
+    for _ in range(12):
+        s.step(np.zeros((6, 2)))
+        st = s.get_state()
+        crossed |= st[0] > L / 2
+        assert st[0] <= L / 2 + gd - rb + 1e-6 and abs(st[1]) <= gw / 2 - rb + 1e-6 or st[0] <= L / 2
+    assert crossed
+    # a robot driven into a corner stays inside
+    s = _vss(backend, [0, 0, 0, 0], [0.6, 0.5, 40.0])
+    for _ in range(40):
+        s.step(_cmd(6, 2, {0: [40.0, 40.0]}))
+    st = s.get_state()
+    assert st[5] <= L / 2 - f["rbt_radius"] + 1e-6 and st[6] <= W / 2 - f["rbt_radius"] + 1e-6
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_robot_ball_collision(backend, oracle_mod):
+    """a robot pushing into a resting ball sends it away along the line of centres; momentum of
+    the pair only changes through the motor (no energy from nowhere)."""
+    s = _vss(backend, [0.0, 0.0, 0, 0], [-0.2, 0.0, 0.0])
+    hit = False
+    for _ in range(30):
+        s.step(_cmd(6, 2, {0: [30.0, 30.0]}))
+        st = s.get_state()
+        gap = math.hypot(st[0] - st[5], st[1] - st[6])
+        assert gap > 0.0375 + 0.0215 - 3e-3          # never deeply interpenetrating
+        hit |= st[3] > 0.1
+    st = s.get_state()
+    assert hit and st[3] > 0 and abs(st[4]) < 1e-5 and st[0] > 0.05
+    # robot - robot: two robots driven against each other stop each other, no tunnelling
+    s = _make(backend, 0, 0, 3, 3)
+    s.reset(np.array([0, 0.5, 0, 0.0]), np.array([[-0.1, 0, 0.0], [-0.6, 0.5, 0], [-0.6, -0.5, 0]]),
+            np.array([[0.1, 0, 180.0], [0.6, 0.5, 0], [0.6, -0.5, 0]]))
+    for _ in range(40):
+        s.step(_cmd(6, 2, {0: [30.0, 30.0], 3: [30.0, 30.0]}))
+        st = s.get_state()
+        assert st[5 + 18] - st[5] > 2 * 0.0375 - 4e-3
+    assert st[5] < 0 < st[5 + 18]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_holonomic_commands(backend, oracle_mod):
+    # local (v_x, v_y, v_theta) command: heading 90 deg, local +x is global +y
+    s = _ssl(backend, [2.0, 1.5, 0, 0], [0, 0, 90.0])
+    for _ in range(30):
+        s.step(_cmd(1, 8, {0: [0, 1.0, 0.0, 0.0]}))
+    st = s.get_state()
+    assert abs(st[9] - 1.0) < 1e-4 and abs(st[8]) < 1e-4 and st[6] > 0.3 and abs(st[5]) < 1e-3
+    # pure rotation at 2 rad/s
+    s = _ssl(backend, [2.0, 1.5, 0, 0], [0, 0, 0.0])
+    for _ in range(20):
+        s.step(_cmd(1, 8, {0: [0, 0.0, 0.0, 2.0]}))
+    assert abs(math.radians(s.get_state()[10]) - 2.0) < 1e-4
+    # the reported wheel speeds (static_defenders.py:311-322 reads them) reproduce the motion
+    # when fed back as a wheel-speed command
+    s = _ssl(backend, [2.0, 1.5, 0, 0], [0, 0, 30.0])
+    for _ in range(25):
+        s.step(_cmd(1, 8, {0: [0, 0.8, -0.4, 1.0]}))
+    st = s.get_state()
+    wheels = st[12:16]
+    s2 = _ssl(backend, [2.0, 1.5, 0, 0], [0, 0, 30.0])
+    for _ in range(25):
+        s2.step(_cmd(1, 8, {0: [1, *wheels]}))
+    st2 = s2.get_state()
+    # (the heading differs by the acceleration transient, so compare robot-frame quantities)
+    assert abs(math.hypot(*st2[8:10]) - math.hypot(*st[8:10])) < 1e-4 and abs(st2[10] - st[10]) < 1e-3
+    assert np.allclose(st2[12:16], wheels, atol=0.3)   # within one sub-step of heading change (omega * h)
+    # wheel speeds saturate at 160 rad/s (static_defenders.py:71)
+    s = _ssl(backend, [2.0, 1.5, 0, 0], [-2.0, 0, 0.0])
+    for _ in range(60):
+        s.step(_cmd(1, 8, {0: [0, 50.0, 0.0, 0.0]}))
+    assert np.max(np.abs(s.get_state()[12:16])) <= 160.0 + 1e-3
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_infrared_kick_and_dribbler(backend, oracle_mod):
+    # a ball 0.1 m in front of the robot centre is "possessed" (dribbling.py:193-195)
+    s = _ssl(backend, [0.1, 0.0, 0, 0], [0, 0, 0.0])
+    s.step(np.zeros((1, 8)))
+    assert s.get_state()[11] == 1.0
+    s = _ssl(backend, [0.3, 0.0, 0, 0], [0, 0, 0.0])
+    s.step(np.zeros((1, 8)))
+    assert s.get_state()[11] == 0.0
+    s = _ssl(backend, [0.0, 0.1, 0, 0], [0, 0, 0.0])  # beside, not in front
+    s.step(np.zeros((1, 8)))
+    assert s.get_state()[11] == 0.0
+    # kick: the ball leaves along the heading at kick_v_x (static_defenders.py:78,125)
+    s = _ssl(backend, [0.1 * math.cos(math.radians(30)), 0.1 * math.sin(math.radians(30)), 0, 0], [0, 0, 30.0])
+    s.step(_cmd(1, 8, {0: [0, 0, 0, 0, 0, 5.0, 0.0, 0]}))
+    st = s.get_state()
+    sp = math.hypot(st[3], st[4])
+    assert 4.8 < sp <= 5.0 + 1e-5 and abs(math.degrees(math.atan2(st[4], st[3])) - 30.0) < 0.5
+    # no kick without infrared
+    s = _ssl(backend, [0.5, 0.0, 0, 0], [0, 0, 0.0])
+    s.step(_cmd(1, 8, {0: [0, 0, 0, 0, 0, 5.0, 0.0, 0]}))
+    assert np.all(s.get_state()[3:5] == 0)
+    # dribbler: the ball is carried by a moving, turning robot
+    s = _ssl(backend, [0.1, 0.0, 0, 0], [0, 0, 0.0])
+    for _ in range(60):
+        s.step(_cmd(1, 8, {0: [0, 0.5, 0.0, 1.0, 0, 0, 0, 1]}))
+        st = s.get_state()
+    th = math.radians(st[7])
+    lx = (st[0] - st[5]) * math.cos(th) + (st[1] - st[6]) * math.sin(th)
+    ly = -(st[0] - st[5]) * math.sin(th) + (st[1] - st[6]) * math.cos(th)
+    assert st[11] == 1.0 and abs(lx - (0.073 + 0.0215)) < 0.012 and abs(ly) < 0.02
+    # same drive without dribbler: the ball is left behind / pushed away
+    s = _ssl(backend, [0.1, 0.0, 0, 0], [0, 0, 0.0])
+    for _ in range(60):
+        s.step(_cmd(1, 8, {0: [0, 0.5, 0.0, 1.0, 0, 0, 0, 0]}))
+    st = s.get_state()
+    th = math.radians(st[7])
+    ly = -(st[0] - st[5]) * math.sin(th) + (st[1] - st[6]) * math.cos(th)
+    assert st[11] == 0.0 or abs(ly) > 0.02
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_chip_kick_flies_over_a_robot(backend, oracle_mod):
+    y = [[0.6, 0.0, 0.0]]
+    s = _ssl(backend, [0.1, 0.0, 0, 0], [0, 0, 0.0], ny=1, yellow=y)
+    s.step(_cmd(2, 8, {0: [0, 0, 0, 0, 0, 3.0, 3.0, 0]}))
+    zmax, passed = 0.0, False
+    for _ in range(90):   # flight + the decaying bounces
+        s.step(np.zeros((2, 8)))
+        st = s.get_state()
+        zmax = max(zmax, st[2])
+        passed |= st[0] > 0.8
+    assert zmax > 0.15 + 0.0215 and passed                  # cleared the 0.15 m robot
+    assert np.all(s.get_state()[5 + 11 + 3: 5 + 11 + 5] == 0)   # the defender was never touched
+    assert abs(s.get_state()[2] - 0.0215) < 1e-6            # back on the ground
+    # the same kick flat (kick_v_z = 0) is blocked by the defender
+    s = _ssl(backend, [0.1, 0.0, 0, 0], [0, 0, 0.0], ny=1, yellow=y)
+    s.step(_cmd(2, 8, {0: [0, 0, 0, 0, 0, 3.0, 0.0, 0]}))
+    for _ in range(40):
+        s.step(np.zeros((2, 8)))
+    assert s.get_state()[0] < 0.6
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_ssl_ball_can_leave_the_field_lines(backend, oracle_mod):
+    """static_defenders.py:185-197 tests |y| > W/2 and x > L/2 outside the goal: the SSL field
+    has no wall on its lines, only further out."""
+    f = _ssl(backend, [0, 0, 0, 0], [0, -1.5, 0]).get_field_params()
+    s = _ssl(backend, [1.0, 1.9, 0.0, 2.0], [0, -1.5, 0])
+    for _ in range(20):
+        s.step(np.zeros((1, 8)))
+    assert s.get_state()[1] > f["width"] / 2
+    s = _ssl(backend, [2.8, 1.0, 2.0, 0.0], [0, -1.5, 0])
+    for _ in range(20):
+        s.step(np.zeros((1, 8)))
+    assert s.get_state()[0] > f["length"] / 2
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_time_step_scales_motion(backend, oracle_mod):
+    a = _make(backend, 0, 0, 3, 3, 25)
+    b = _make(backend, 0, 0, 3, 3, 50)
+    for s in (a, b):
+        s.reset(np.array([0.0, 0.5, 0.4, 0.0]), np.array([[-0.5, 0, 0], [-0.6, 0.5, 0], [-0.6, -0.5, 0]], float),
+                np.array([[0.6, 0.5, 0], [0.6, 0, 0], [0.6, -0.5, 0]], float))
+    for _ in range(4):
+        a.step(np.zeros((6, 2)))
+    for _ in range(2):
+        b.step(np.zeros((6, 2)))
+    assert np.allclose(a.get_state(), b.get_state(), atol=1e-6)
