@@ -110,19 +110,31 @@ void launch_sim(const rsx_sim* h, hipStream_t s) {
     else launch_sim_k<RSX_KIND_SSL>(h, s);
 }
 
-template <int KIND, int TASK, int NRS>
-void launch_task_k(const rsx_sim* h, const float* actions, int n_steps, int mode, hipStream_t s) {
+template <int KIND, int TASK, int NRS, int MODE>
+void launch_task_m(const rsx_sim* h, const float* actions, int n_steps, hipStream_t s) {
     const dim3 grid = grid_for(h);
     const Buffers b = buffers_of(h, actions);
-    if (h->NR == NRS && h->L == 8) { RSX_LAUNCH((task_step_kernel<KIND, 8, TASK, NRS>), h->P, b, n_steps, mode); return; }
+    if (h->NR == NRS && h->L == 8) { RSX_LAUNCH((task_step_kernel<KIND, 8, TASK, NRS, MODE>), h->P, b, n_steps); return; }
     switch (h->L) {
-        case 8: RSX_LAUNCH((task_step_kernel<KIND, 8, TASK, 0>), h->P, b, n_steps, mode); break;
-        case 16: RSX_LAUNCH((task_step_kernel<KIND, 16, TASK, 0>), h->P, b, n_steps, mode); break;
-        case 32: RSX_LAUNCH((task_step_kernel<KIND, 32, TASK, 0>), h->P, b, n_steps, mode); break;
-        default: RSX_LAUNCH((task_step_kernel<KIND, 64, TASK, 0>), h->P, b, n_steps, mode); break;
+        case 8: RSX_LAUNCH((task_step_kernel<KIND, 8, TASK, 0, MODE>), h->P, b, n_steps); break;
+        case 16: RSX_LAUNCH((task_step_kernel<KIND, 16, TASK, 0, MODE>), h->P, b, n_steps); break;
+        case 32: RSX_LAUNCH((task_step_kernel<KIND, 32, TASK, 0, MODE>), h->P, b, n_steps); break;
+        default: RSX_LAUNCH((task_step_kernel<KIND, 64, TASK, 0, MODE>), h->P, b, n_steps); break;
     }
 }
 
+template <int KIND, int TASK, int NRS>
+void launch_task_k(const rsx_sim* h, const float* actions, int n_steps, int mode, hipStream_t s) {
+    switch (mode) {
+        case MODE_STEP: launch_task_m<KIND, TASK, NRS, MODE_STEP>(h, actions, 1, s); break;
+        case MODE_ROLLOUT: launch_task_m<KIND, TASK, NRS, MODE_ROLLOUT>(h, nullptr, n_steps, s); break;
+        case MODE_RESET: launch_task_m<KIND, TASK, NRS, MODE_RESET>(h, nullptr, 1, s); break;
+        default: launch_task_m<KIND, TASK, NRS, MODE_REFRESH>(h, nullptr, 1, s); break;
+    }
+}
+
+// mode: MODE_STEP (one step, optional fed actions), MODE_ROLLOUT (n_steps in one launch),
+// MODE_RESET, MODE_REFRESH
 void launch_task(const rsx_sim* h, const float* actions, int n_steps, int mode, hipStream_t s) {
     if (h->P.task == RSX_TASK_VSS_V0) launch_task_k<RSX_KIND_VSS, RSX_TASK_VSS_V0, 6>(h, actions, n_steps, mode, s);
     else launch_task_k<RSX_KIND_SSL, RSX_TASK_SSL_STATIC_DEFENDERS, 7>(h, actions, n_steps, mode, s);
@@ -380,7 +392,7 @@ int rsx_task_view_get(rsx_sim* h, rsx_task_view* out) {
 
 int rsx_task_reset(rsx_sim* h, void* stream) {
     if (int rc = check_task(h)) return rc;
-    launch_task(h, nullptr, 1, 1, (hipStream_t)stream);
+    launch_task(h, nullptr, 1, MODE_RESET, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return RSX_OK;
 }
@@ -394,7 +406,7 @@ int rsx_task_reset_to(rsx_sim* h, const double* ball, const double* blue, const 
     // the kernel takes the env mask through the `truncated` buffer (cleared again below)
     if (env_mask) HIP_TRY(hipMemcpyAsync(h->d_flags + B, env_mask, B, hipMemcpyHostToDevice, s));
     else HIP_TRY(hipMemsetAsync(h->d_flags + B, 1, B, s));
-    launch_task(h, nullptr, 1, 2, s);
+    launch_task(h, nullptr, 1, MODE_REFRESH, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(h->d_flags + B, 0, B, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -403,7 +415,7 @@ int rsx_task_reset_to(rsx_sim* h, const double* ball, const double* blue, const 
 
 int rsx_task_step(rsx_sim* h, const float* actions_dev, void* stream) {
     if (int rc = check_task(h)) return rc;
-    launch_task(h, actions_dev, 1, 0, (hipStream_t)stream);
+    launch_task(h, actions_dev, 1, MODE_STEP, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     h->env_steps += h->P.num_envs;
     return RSX_OK;
@@ -414,7 +426,7 @@ int rsx_task_step_n(rsx_sim* h, int n, void* stream) {
     if (n < 1) return fail(RSX_ERR_ARG, "n must be >= 1");
     static const bool use_graph = std::getenv("RSX_USE_GRAPH") != nullptr;
     if (!use_graph) {
-        for (int i = 0; i < n; ++i) launch_task(h, nullptr, 1, 0, (hipStream_t)stream);
+        for (int i = 0; i < n; ++i) launch_task(h, nullptr, 1, MODE_STEP, (hipStream_t)stream);
         HIP_TRY(hipGetLastError());
         h->env_steps += (long long)n * h->P.num_envs;
         return RSX_OK;
@@ -424,7 +436,7 @@ int rsx_task_step_n(rsx_sim* h, int n, void* stream) {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         HIP_TRY(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-        for (int i = 0; i < n; ++i) launch_task(h, nullptr, 1, 0, h->cap_stream);
+        for (int i = 0; i < n; ++i) launch_task(h, nullptr, 1, MODE_STEP, h->cap_stream);
         HIP_TRY(hipStreamEndCapture(h->cap_stream, &graph));
         HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
         (void)hipGraphDestroy(graph);
@@ -437,8 +449,8 @@ int rsx_task_step_n(rsx_sim* h, int n, void* stream) {
 
 int rsx_task_rollout(rsx_sim* h, int n, void* stream) {
     if (int rc = check_task(h)) return rc;
-    if (n < 1) return fail(RSX_ERR_ARG, "n must be >= 1");
-    launch_task(h, nullptr, n, 0, (hipStream_t)stream);
+    if (n < 0) return fail(RSX_ERR_ARG, "n must be >= 0");  // 0 = load + store only (profiling)
+    launch_task(h, nullptr, n, MODE_ROLLOUT, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     h->env_steps += (long long)n * h->P.num_envs;
     return RSX_OK;

@@ -614,11 +614,19 @@ __device__ __forceinline__ void place_env(const Params& P, const int N, uint32_t
     }
 }
 
-// mode 0: step(action)   1: reset() with random placement   2: open a new episode on the state
-// already in the buffers for the envs flagged in the `truncated` bytes (reset_to)
-template <int KIND, int L, int TASK, int NR>
+// MODE (compile-time, so the per-step launch carries no loop and none of the reset-only code):
+//   MODE_STEP    one step(action) per launch
+//   MODE_ROLLOUT n_steps random-action steps per launch (state stays in registers)
+//   MODE_RESET   reset() with random placement
+//   MODE_REFRESH open a new episode on the state already in the buffers for the envs flagged in
+//                the `truncated` bytes (reset_to); observations recomputed, state untouched
+constexpr int MODE_STEP = 0, MODE_RESET = 1, MODE_REFRESH = 2, MODE_ROLLOUT = 3;
+
+template <int KIND, int L, int TASK, int NR, int MODE>
 __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buffers bufs,
-                                                       const int n_steps, const int mode) {
+                                                       const int n_steps_arg) {
+    constexpr int mode = MODE == MODE_ROLLOUT ? MODE_STEP : MODE;
+    const int n_steps = MODE == MODE_ROLLOUT ? n_steps_arg : 1;
     using K = KC<KIND>;
     using T = TC<TASK>;
     constexpr int G = 64 / L;
@@ -659,7 +667,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
     float reward = 0.0f; int term = 0, trunc = 0;
     bool was_reset = false;
     // caller-fed actions of the agent lane (robot 0); fed launches run a single step
-    const bool fed = bufs.actions != nullptr;
+    const bool fed = MODE == MODE_STEP && bufs.actions != nullptr;
     float act[AD];
 #pragma unroll
     for (int i = 0; i < AD; ++i) act[i] = 0.0f;
