@@ -109,7 +109,7 @@ static int rsxo_cfg_init(rsxo_cfg* c, int kind, int field_type, int nb, int ny, 
     c->r_wheel = f[15];
     c->w_max = f[16] / 60.0 * 2.0 * RSXO_PI;
     c->grav = 9.81; c->e_ground = 0.5; c->vz_min = 0.2; c->robot_h = 0.15;
-    c->dck = f[7]; c->half_kw = f[9] / 2; c->ir_tol = 0.01; c->drib_vmax = 1.0;
+    c->dck = f[7]; c->half_kw = f[9] / 2; c->ir_tol = 0.025; c->drib_vmax = 1.0;
     for (int k = 0; k < 4; ++k) c->wheel_ang[k] = f[10 + k] * RSXO_PI / 180.0;
     if (kind == 1) {
         /* omni inverse kinematics: wheel surface speed_k = -sin(a_k) vx + cos(a_k) vy + R w.

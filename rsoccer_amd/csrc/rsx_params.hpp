@@ -83,7 +83,7 @@ struct KC {
     static constexpr float inv_rw = (float)(1.0 / D::r_wheel);
     static constexpr float e_ground = 0.5f, vz_min = 0.2f, robot_h = 0.15f;   // [build]
     static constexpr float dck_rb = (float)(D::dck + D::r_ball);
-    static constexpr float half_kw = (float)(D::kick_w / 2), ir_tol = 0.01f;
+    static constexpr float half_kw = (float)(D::kick_w / 2), ir_tol = 0.025f;
     static constexpr float drib_vmax = 1.0f, drib_vmax2 = 1.0f;
     static constexpr float deg2rad = (float)(PI_D / 180.0), rad2deg = (float)(180.0 / PI_D);
 };

@@ -1,0 +1,112 @@
+"""SSLContestedPossession-v0: take the ball from a static opponent that holds it and score.
+Restates rsoccer_gym/ssl/ssl_hw_challenge/contested_possession.py:11-293.
+
+Observation Box(14): ball x, y, v_x, v_y; blue 0 x, y, sin, cos, v_x, v_y, v_theta, infrared;
+yellow 0 (x, y).  Action Box(5) as SSLStaticDefenders-v0.  Same terminations and shaped reward
+as static defenders (energy normalised over 1200 steps), plus: the episode ends when the
+opponent is moved faster than 0.1 m/s (a collision).
+"""
+import random
+
+import numpy as np
+
+from rsoccer_amd import gymshim as gym
+from rsoccer_amd.Entities import Ball, Frame, Robot
+from rsoccer_amd.ssl.ssl_gym_base import SSLBaseEnv
+from rsoccer_amd.ssl.ssl_hw_challenge import _shared
+
+_INFO_KEYS = ("goal", "rbt_in_gk_area", "done_ball_out", "done_ball_out_right", "done_rbt_out",
+              "ball_dist", "ball_grad", "energy", "collision")
+
+
+class SSLContestedPossessionEnv(SSLBaseEnv):
+    def __init__(self, render_mode=None, sim_backend=None):
+        super().__init__(field_type=2, n_robots_blue=1, n_robots_yellow=1, time_step=0.025,
+                         render_mode=render_mode, sim_backend=sim_backend)
+        self.action_space = gym.spaces.Box(low=-1, high=1, shape=(5,), dtype=np.float32)
+        n_obs = 4 + 8 * self.n_robots_blue + 2 * self.n_robots_yellow
+        self.observation_space = gym.spaces.Box(low=-self.NORM_BOUNDS, high=self.NORM_BOUNDS,
+                                                shape=(n_obs,), dtype=np.float32)
+        self.ball_dist_scale = np.linalg.norm([self.field.width, self.field.length / 2])
+        self.ball_grad_scale = np.linalg.norm([self.field.width / 2, self.field.length / 2]) / 4
+        self.energy_scale = (160 * 4) * 1200
+        self.max_v = 2.5
+        self.max_w = 10
+        self.kick_speed_x = 5.0
+        self.reward_shaping_total = None
+
+    def reset(self, *, seed=None, options=None):
+        self.reward_shaping_total = None
+        return super().reset(seed=seed, options=options)
+
+    def step(self, action):
+        observation, reward, terminated, truncated, _ = super().step(action)
+        return observation, reward, terminated, truncated, self.reward_shaping_total
+
+    def _frame_to_observations(self):
+        f = self.frame
+        obs = [self.norm_pos(f.ball.x), self.norm_pos(f.ball.y), self.norm_v(f.ball.v_x), self.norm_v(f.ball.v_y)]
+        for i in range(self.n_robots_blue):
+            r = f.robots_blue[i]
+            obs += _shared.blue_observation(self, r) + [1 if r.infrared else 0]
+        for i in range(self.n_robots_yellow):
+            obs += [self.norm_pos(f.robots_yellow[i].x), self.norm_pos(f.robots_yellow[i].y)]
+        return np.array(obs, dtype=np.float32)
+
+    def _get_commands(self, actions):
+        v_x, v_y, v_theta = self.convert_actions(actions, np.deg2rad(self.frame.robots_blue[0].theta))
+        return [Robot(yellow=False, id=0, v_x=v_x, v_y=v_y, v_theta=v_theta,
+                      kick_v_x=self.kick_speed_x if actions[3] > 0 else 0.0, dribbler=bool(actions[4] > 0))]
+
+    def convert_actions(self, action, angle):
+        return _shared.convert_actions(action, angle, self.max_v, self.max_w)
+
+    def _calculate_reward_and_done(self):
+        if self.reward_shaping_total is None:
+            self.reward_shaping_total = dict.fromkeys(_INFO_KEYS, 0)
+        total = self.reward_shaping_total
+        fld = self.field
+        half_len, half_wid = fld.length / 2, fld.width / 2
+        ball, robot = self.frame.ball, self.frame.robots_blue[0]
+        done = False
+        for r in self.frame.robots_yellow.values():
+            if abs(r.v_x) > 0.1 or abs(r.v_y) > 0.1:
+                total["collision"] += 1
+                done = True
+        if robot.x < -0.2 or abs(robot.y) > half_wid:
+            total["done_rbt_out"] += 1
+            return 0, True
+        if robot.x > half_len - fld.penalty_length and abs(robot.y) < fld.penalty_width / 2:
+            total["rbt_in_gk_area"] += 1
+            return 0, True
+        if ball.x < 0 or abs(ball.y) > half_wid:
+            total["done_ball_out"] += 1
+            return 0, True
+        if ball.x > half_len:
+            if abs(ball.y) < fld.goal_width / 2:
+                total["goal"] += 1
+                return 5, True
+            total["done_ball_out_right"] += 1
+            return 0, True
+        if self.last_frame is None:
+            return 0, done
+        ball_dist_rw = _shared.robot_ball_approach(self.last_frame, self.frame) / self.ball_dist_scale
+        ball_grad_rw = _shared.ball_progress_to(half_len, 0.0, self.last_frame, self.frame) / self.ball_grad_scale
+        r = robot
+        energy_rw = -(abs(r.v_wheel0) + abs(r.v_wheel1) + abs(r.v_wheel2) + abs(r.v_wheel3)) / self.energy_scale
+        total["ball_dist"] += ball_dist_rw
+        total["ball_grad"] += ball_grad_rw
+        total["energy"] += energy_rw
+        return 0 + ball_dist_rw + ball_grad_rw + energy_rw, done
+
+    def _get_initial_positions_frame(self):
+        """opponent with the ball 0.1 m in front of it, somewhere inside the penalty-width band"""
+        fld = self.field
+        half_len = fld.length / 2
+        frame = Frame()
+        frame.robots_blue[0] = Robot(x=0, y=0, theta=0.0)
+        enemy_x = random.uniform(fld.penalty_length, half_len - fld.penalty_length)
+        enemy_y = random.uniform(-fld.penalty_width / 2, fld.penalty_width / 2)
+        frame.ball = Ball(x=enemy_x - 0.1, y=enemy_y)
+        frame.robots_yellow[0] = Robot(x=enemy_x, y=enemy_y, theta=180.0)
+        return frame

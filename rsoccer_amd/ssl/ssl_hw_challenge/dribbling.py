@@ -1,0 +1,94 @@
+"""SSLDribbling-v0: keep the ball while slaloming through four static robots.
+Restates rsoccer_gym/ssl/ssl_hw_challenge/dribbling.py:11-202.
+
+Observation Box(21): checkpoint progress (count/6 mapped to [-1, 1]); ball x, y, v_x, v_y;
+blue 0 x, y, sin, cos, v_x, v_y, v_theta, infrared as +-1; four yellow (x, y).
+Action Box(4): global v_x, v_y, v_theta fractions, dribbler if > 0.
+Reward 1 per checkpoint (gaps between obstacles crossed in zig-zag; the last pair is lapped
+until seven crossings).  Ends on course completed, leaving the course, reversing the last
+checkpoint, or touching an obstacle (any yellow robot faster than 0.05 m/s).
+"""
+import numpy as np
+
+from rsoccer_amd import gymshim as gym
+from rsoccer_amd.Entities import Ball, Frame, Robot
+from rsoccer_amd.ssl.ssl_gym_base import SSLBaseEnv
+from rsoccer_amd.ssl.ssl_hw_challenge import _shared
+
+
+class SSLHWDribblingEnv(SSLBaseEnv):
+    def __init__(self, render_mode=None, sim_backend=None):
+        super().__init__(field_type=2, n_robots_blue=1, n_robots_yellow=4, time_step=0.025,
+                         render_mode=render_mode, sim_backend=sim_backend)
+        self.action_space = gym.spaces.Box(low=-1, high=1, shape=(4,), dtype=np.float32)
+        n_obs = 5 + 8 * self.n_robots_blue + 2 * self.n_robots_yellow
+        self.observation_space = gym.spaces.Box(low=-self.NORM_BOUNDS, high=self.NORM_BOUNDS,
+                                                shape=(n_obs,), dtype=np.float32)
+        self.checkpoints_count = 0
+        # obstacle x positions; checkpoints are the gaps between them (dribbling.py:58-63)
+        self.node_0, self.node_1, self.node_2, self.node_3 = -0.5, -1.0, -1.5, -2.0
+        self.field_margin = 1
+        self.max_v = 2.5
+        self.max_w = 10
+
+    def reset(self, *, seed=None, options=None):
+        self.checkpoints_count = 0
+        return super().reset(seed=seed, options=options)
+
+    def _frame_to_observations(self):
+        f = self.frame
+        obs = [((self.checkpoints_count / 6) * 2) - 1,
+               self.norm_pos(f.ball.x), self.norm_pos(f.ball.y), self.norm_v(f.ball.v_x), self.norm_v(f.ball.v_y)]
+        for i in range(self.n_robots_blue):
+            r = f.robots_blue[i]
+            obs += _shared.blue_observation(self, r) + [1 if r.infrared else -1]
+        for i in range(self.n_robots_yellow):
+            obs += [self.norm_pos(f.robots_yellow[i].x), self.norm_pos(f.robots_yellow[i].y)]
+        return np.array(obs, dtype=np.float32)
+
+    def _get_commands(self, actions):
+        v_x, v_y, v_theta = self.convert_actions(actions, np.deg2rad(self.frame.robots_blue[0].theta))
+        return [Robot(yellow=False, id=0, v_x=v_x, v_y=v_y, v_theta=v_theta, dribbler=bool(actions[3] > 0))]
+
+    def convert_actions(self, action, angle):
+        return _shared.convert_actions(action, angle, self.max_v, self.max_w)
+
+    def _calculate_reward_and_done(self):
+        ball, last_ball = self.frame.ball, self.last_frame.ball
+        robot = self.frame.robots_blue[0]
+        done = any(abs(r.v_x) > 0.05 or abs(r.v_y) > 0.05 for r in self.frame.robots_yellow.values())
+        out_of_course = (robot.x < self.node_3 - self.field_margin or robot.x > self.field_margin
+                         or abs(robot.y) > self.field_margin)
+        if out_of_course:
+            return 0, True
+        if not last_ball:
+            return 0, done
+        down = last_ball.y >= 0 and ball.y < 0      # crossed the obstacle line towards -y
+        up = last_ball.y < 0 and ball.y >= 0
+        n = self.checkpoints_count
+        reward = 0
+        if n == 0:
+            passed = self.node_1 < ball.x < self.node_0 and down
+        elif n == 1:
+            passed = self.node_2 < ball.x < self.node_1 and up
+        elif n % 2 == 0:
+            inside = self.node_3 < ball.x < self.node_2
+            passed = inside and down
+            if inside and not down and up:
+                done = True                          # went back through the last checkpoint
+        else:
+            passed = self.node_3 - self.field_margin < ball.x < self.node_3 and up
+        if passed:
+            reward = 1
+            self.checkpoints_count += 1
+            if n >= 2 and n % 2 == 0 and self.checkpoints_count == 7:
+                done = True
+        return reward, done
+
+    def _get_initial_positions_frame(self):
+        frame = Frame()
+        frame.ball = Ball(x=-0.1, y=0.0)
+        frame.robots_blue[0] = Robot(x=0.0, y=0.0, theta=180.0)
+        for i, x in enumerate((self.node_0, self.node_1, self.node_2, self.node_3)):
+            frame.robots_yellow[i] = Robot(x=x, y=0.0, theta=180.0)
+        return frame

@@ -1,0 +1,120 @@
+"""SSLPassEndurance-v0: a stationary shooter turns and kicks the ball to a stationary receiver.
+Restates rsoccer_gym/ssl/ssl_hw_challenge/pass_endurance.py:11-233.
+
+Observation Box(16): ball x, y, v_x, v_y; for each of the two blue robots x, y, sin, cos,
+v_theta, infrared.  Action Box(3): v_theta fraction, kick strength (ignored below |0.5|),
+dribbler if > 0.  Reward: progress of the ball towards the receiver; +1 and done when the
+receiver's infrared sees the ball; -1 and done when the ball leaves the shooter-receiver box or
+stalls for more than 20 steps.  info = {"reversed_dist", "ball_grad"}.
+"""
+import random
+
+import numpy as np
+
+from rsoccer_amd import gymshim as gym
+from rsoccer_amd.Entities import Ball, Frame, Robot
+from rsoccer_amd.ssl.ssl_gym_base import SSLBaseEnv
+from rsoccer_amd.ssl.ssl_hw_challenge import _shared
+
+
+class SSLPassEnduranceEnv(SSLBaseEnv):
+    def __init__(self, render_mode=None, sim_backend=None):
+        super().__init__(field_type=2, n_robots_blue=2, n_robots_yellow=0, time_step=0.025,
+                         render_mode=render_mode, sim_backend=sim_backend)
+        self.action_space = gym.spaces.Box(low=-1, high=1, shape=(3,), dtype=np.float32)
+        n_obs = 4 + 6 * self.n_robots_blue
+        self.observation_space = gym.spaces.Box(low=-self.NORM_BOUNDS, high=self.NORM_BOUNDS,
+                                                shape=(n_obs,), dtype=np.float32)
+        self.holding_steps = 0
+        self.stopped_steps = 0
+        self.recv_angle = 270
+        self.receiver_id = 1
+        self.ball_grad_scale = np.linalg.norm([self.field.width / 2, self.field.length / 2]) / 4
+        self.max_v = 2.5
+        self.max_w = 10
+        self.max_kick_x = 5.0
+        self.actions = {}
+        self.shooted = False
+        self.reward_shaping_total = None
+
+    def reset(self, *, seed=None, options=None):
+        self.reward_shaping_total = None
+        state, info = super().reset(seed=seed, options=options)
+        self.actions = {}
+        self.holding_steps = 0
+        self.stopped_steps = 0
+        self.shooted = False
+        return state, info
+
+    def step(self, action):
+        observation, reward, terminated, truncated, _ = super().step(action)
+        return observation, reward, terminated, truncated, self.reward_shaping_total
+
+    def _frame_to_observations(self):
+        f = self.frame
+        obs = [self.norm_pos(f.ball.x), self.norm_pos(f.ball.y), self.norm_v(f.ball.v_x), self.norm_v(f.ball.v_y)]
+        for i in range(self.n_robots_blue):
+            r = f.robots_blue[i]
+            obs += _shared.blue_observation(self, r, with_velocity=False) + [1 if r.infrared else 0]
+        return np.array(obs, dtype=np.float32)
+
+    def _get_commands(self, actions):
+        # like the reference (pass_endurance.py:108) the caller's array is edited in place
+        actions[1] = actions[1] if abs(actions[1]) > 0.5 else 0
+        self.actions = actions
+        shooter = Robot(yellow=False, id=0, v_x=0, v_y=0, v_theta=actions[0] * self.max_w,
+                        kick_v_x=actions[1] * self.max_kick_x, dribbler=bool(actions[2] > 0))
+        receiver = Robot(yellow=False, id=1, v_x=0, v_y=0, v_theta=0, kick_v_x=0, dribbler=True)
+        return [shooter, receiver]
+
+    def _calculate_reward_and_done(self):
+        if self.reward_shaping_total is None:
+            self.reward_shaping_total = {"reversed_dist": 0, "ball_grad": 0}
+        f = self.frame
+        recv, shooter = f.robots_blue[1], f.robots_blue[0]
+        reward, done = 0, False
+        if recv.infrared:
+            reward += 1
+            done = True
+        else:
+            progress = (1 / self.ball_grad_scale) * _shared.ball_progress_to(recv.x, recv.y, self.last_frame, f)
+            reward = progress
+            self.reward_shaping_total["ball_grad"] += progress
+        if self._wrong_ball() or self.holding_steps > 15:
+            reward -= 1
+            done = True
+        if done:
+            rv, sh, bl = (np.array([o.x, o.y]) for o in (recv, shooter, f.ball))
+            dist_robs = np.linalg.norm(rv - sh)
+            self.reward_shaping_total["reversed_dist"] = (dist_robs - np.linalg.norm(rv - bl)) / dist_robs
+        return reward, done
+
+    def _wrong_ball(self):
+        """ball outside the axis-aligned box spanned by the two robots (centimetre grid), or
+        not approaching the receiver for more than 20 consecutive steps"""
+        f, lf = self.frame, self.last_frame
+        ball, last_ball = np.array([f.ball.x, f.ball.y]), np.array([lf.ball.x, lf.ball.y])
+        recv = np.array([f.robots_blue[1].x, f.robots_blue[1].y])
+        shooter = np.array([f.robots_blue[0].x, f.robots_blue[0].y])
+        cb, cs, cr = (np.array(v * 100, dtype=int) for v in (ball, shooter, recv))
+        inside = all(min(cr[k], cs[k]) <= cb[k] <= max(cr[k], cs[k]) for k in (0, 1))
+        stalled = abs(np.linalg.norm(last_ball - recv) - np.linalg.norm(ball - recv)) < 0.01
+        self.stopped_steps = self.stopped_steps + 1 if stalled else 0
+        return self.stopped_steps > 20 or not inside
+
+    def _get_initial_positions_frame(self):
+        """shooter holding the ball (0.115 m behind it, facing it), receiver on the mirrored
+        side at least 1 m away in x, facing the shooter (pass_endurance.py:156-185)"""
+        rand_x = lambda: random.uniform(-1.5, 1.5)
+        frame = Frame()
+        frame.ball = Ball(x=rand_x(), y=random.uniform(1.5, -1.5))
+        side = frame.ball.y / abs(frame.ball.y)
+        frame.robots_blue[0] = Robot(x=frame.ball.x, y=frame.ball.y + 0.115 * side, theta=270 if side > 0 else 90)
+        recv_x = rand_x()
+        while abs(recv_x - frame.ball.x) < 1:
+            recv_x = rand_x()
+        receiver = np.array([recv_x, -frame.ball.y])
+        vect = receiver - np.array([frame.robots_blue[0].x, frame.robots_blue[0].y])
+        frame.robots_blue[1] = Robot(x=receiver[0], y=receiver[1],
+                                     theta=np.rad2deg(np.arctan2(vect[1], vect[0]) + np.pi))
+        return frame

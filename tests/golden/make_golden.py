@@ -339,6 +339,114 @@ def main():
             out[f"sd_ep{i}_{k}"] = np.array(v)
     out["sd_n_episodes"] = np.array(len(sd_eps))
 
+    # ------------------------------------------------------------ the other three SSL tasks
+    from rsoccer_gym.ssl.ssl_hw_challenge.dribbling import SSLHWDribblingEnv
+    from rsoccer_gym.ssl.ssl_hw_challenge.contested_possession import SSLContestedPossessionEnv
+    from rsoccer_gym.ssl.ssl_hw_challenge.pass_endurance import SSLPassEnduranceEnv
+
+    def run_task(tag, env_cls, nb, ny, scripts, info_keys, act_dim, action_hook=None):
+        tenv = env_cls()
+        tsim = tenv.rsim.simulator
+        N = nb + ny
+        width = 5 + 11 * N
+        torc = O.OracleEnv(1, 2, nb, ny, 25, "f64")
+        tinj = {}
+
+        def t_on_reset(ball, blue, yellow):
+            torc.reset(ball, np.asarray(blue, float).reshape(-1), np.asarray(yellow, float).reshape(-1))
+            tsim.state = torc.get_state()
+
+        def t_on_step(cmds):
+            torc.step(cmds)
+            st = torc.get_state()
+            if tick["t"] in tinj:
+                st = st.copy()
+                for idx, val in tinj[tick["t"]].items():
+                    st[idx] = val
+                full = torc.get_state_full(); full[:width] = st; torc.set_state_full(full)
+            tsim.state = st
+            tick["t"] += 1
+
+        tsim.on_reset, tsim.on_step = t_on_reset, t_on_step
+        out[f"{tag}_norms"] = np.array([tenv.max_pos, tenv.max_v, tenv.max_w])
+        # observations of arbitrary states
+        K = 24
+        sts = np.zeros((K, width))
+        sts[:, 0:2] = rng.uniform(-3.5, 3.5, (K, 2)); sts[:, 2] = 0.0215; sts[:, 3:5] = rng.uniform(-4, 4, (K, 2))
+        for k in range(N):
+            o = 5 + 11 * k
+            sts[:, o:o + 2] = rng.uniform(-3.5, 3.5, (K, 2)); sts[:, o + 2] = rng.uniform(-200, 200, K)
+            sts[:, o + 3:o + 5] = rng.uniform(-3, 3, (K, 2)); sts[:, o + 5] = rng.uniform(-600, 600, K)
+            sts[:, o + 6] = rng.integers(0, 2, K); sts[:, o + 7:o + 11] = rng.uniform(-160, 160, (K, 4))
+        ob = []
+        for i, s_ in enumerate(sts):
+            tsim.state = s_
+            tenv.frame = tenv.rsim.get_frame()
+            if hasattr(tenv, "checkpoints_count"):
+                tenv.checkpoints_count = i % 7
+            ob.append(tenv._frame_to_observations())
+        out[f"{tag}_obs_states"] = sts; out[f"{tag}_obs"] = np.array(ob, dtype=np.float32)
+        # seeded placement
+        pl = []
+        for sd in seeds:
+            random.seed(sd)
+            fr = tenv._get_initial_positions_frame()
+            pl.append(np.concatenate([a.ravel() for a in frame_to_arrays(fr, nb, ny)]))
+        out[f"{tag}_place"] = np.array(pl)
+        # episodes
+        for ep, (T, inj) in enumerate(scripts):
+            random.seed(400 + ep)
+            tinj.clear(); tinj.update(inj); tick["t"] = 0
+            del robosim.LOG[:]
+            obs0, _ = tenv.reset()
+            rec = dict(reset_state=tsim.state.copy(), obs0=np.array(obs0), actions=[], cmds=[], states=[], obs=[], reward=[], done=[], info=[])
+            for t in range(T):
+                a = rng.uniform(-1, 1, act_dim).astype(np.float32)
+                if action_hook:
+                    a = action_hook(ep, t, a)
+                rec["actions"].append(a.copy())
+                o, r, d, tr, info = tenv.step(a)
+                rec["cmds"].append(robosim.LOG[-1][1]); rec["states"].append(tsim.state.copy())
+                rec["obs"].append(o); rec["reward"].append(r); rec["done"].append(d)
+                rec["info"].append([info[k] for k in info_keys] if info_keys else [0.0])
+                if d:
+                    break
+            for k, v in rec.items():
+                out[f"{tag}_ep{ep}_{k}"] = np.array(v)
+        out[f"{tag}_n_episodes"] = np.array(len(scripts))
+
+    # dribbling: ball index 0,1; blue0 at 5..; yellow k at 16+11k.  Scripts walk the ball through
+    # the checkpoints by teleporting it (the reward code only looks at ball / robot positions).
+    def zigzag(points, start=2):
+        return {start + i: {0: x, 1: y} for i, (x, y) in enumerate(points)}
+    drib_scripts = [
+        (40, {}),
+        (20, zigzag([(-0.75, 0.2), (-0.75, -0.2), (-1.25, -0.2), (-1.25, 0.2), (-1.75, 0.2), (-1.75, -0.2),
+                     (-2.5, -0.2), (-2.5, 0.2), (-1.75, 0.2), (-1.75, -0.2), (-2.5, -0.2), (-2.5, 0.2),
+                     (-1.75, 0.2), (-1.75, -0.2)])),
+        (12, zigzag([(-0.75, 0.2), (-0.75, -0.2), (-1.25, -0.2), (-1.25, 0.2), (-1.25, -0.2), (-1.75, -0.2), (-1.75, 0.2)])),  # reversed
+        (8, {5: {5: 1.5}}),                   # robot leaves the course
+        (8, {5: {16 + 3: 0.2}}),              # an obstacle was hit (yellow 0 v_x)
+    ]
+    def drib_act(ep, t, a):
+        a[3] = 1.0
+        return a
+    run_task("drib", SSLHWDribblingEnv, 1, 4, drib_scripts, None, 4, drib_act)
+
+    cont_keys = ("goal", "rbt_in_gk_area", "done_ball_out", "done_ball_out_right", "done_rbt_out",
+                 "ball_dist", "ball_grad", "energy", "collision")
+    cont_scripts = [(30, {}), (10, {9: {16 + 3: 0.3}}), (10, {9: {5: -0.3}}), (10, {9: {5: 2.5, 6: 0.1}}),
+                    (10, {9: {0: -0.05}}), (10, {9: {0: 3.1, 1: 0.1}}), (10, {9: {0: 3.1, 1: 1.2}}),
+                    (10, {9: {16 + 4: -0.2, 0: 3.1, 1: 0.0}})]
+    run_task("cont", SSLContestedPossessionEnv, 1, 1, cont_scripts, cont_keys, 5)
+
+    def pass_act(ep, t, a):
+        if ep == 0:
+            a[0] = 0.3; a[1] = 1.0 if t > 8 else 0.0; a[2] = 1.0
+        return a
+    pass_scripts = [(60, {}), (40, {}), (30, {10: {0: 3.4, 1: 1.9}}), (12, {11: {16 + 6: 1.0}})]
+    run_task("pass", SSLPassEnduranceEnv, 2, 0, pass_scripts, ("reversed_dist", "ball_grad"), 3, pass_act)
+
     # ------------------------------------------------------------ KD-tree (Utils/kdtree.py)
     pts = rng.uniform(-1, 1, (12, 2))
     qs = rng.uniform(-1, 1, (20, 2))

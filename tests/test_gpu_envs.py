@@ -201,3 +201,38 @@ def test_batched_hooks_env_matches_fused_kernel():
     assert float(env.frame.robots_blue[0].v_x.mean()) > 0.1      # the agent robot did move
     assert float(env.frame.robots_yellow[1].v_x.abs().max()) == 0.0
     env.close()
+
+
+@pytest.mark.parametrize("env_id", ["VSS-v0", "SSLStaticDefenders-v0", "SSLDribbling-v0",
+                                    "SSLContestedPossession-v0", "SSLPassEndurance-v0"])
+def test_every_registered_id_steps_on_the_engine(env_id):
+    """the five ids of the reference registry, constructed through make(), physics on the GPU"""
+    import rsoccer_amd
+    env = rsoccer_amd.make(env_id)
+    random.seed(5); np.random.seed(5)
+    obs, info = env.reset()
+    assert obs.shape == env.observation_space.shape and obs.dtype == np.float32
+    for _ in range(60):
+        obs, r, term, trunc, info = env.step(env.action_space.sample())
+        assert np.all(np.isfinite(obs)) and np.isfinite(r)
+        if term or trunc:
+            obs, info = env.reset()
+    env.close()
+
+
+def test_pass_endurance_ball_is_held_and_can_be_passed():
+    """pass_endurance.py:156-185 places the ball 0.115 m in front of the shooter and expects the
+    dribbler to hold it and the kicker to release it."""
+    from rsoccer_amd.ssl.ssl_hw_challenge import SSLPassEnduranceEnv
+    env = SSLPassEnduranceEnv()
+    random.seed(11)
+    env.reset()
+    for _ in range(5):
+        obs, r, d, _, _ = env.step(np.array([0.0, 0.0, 1.0], dtype=np.float32))
+    assert env.frame.robots_blue[0].infrared          # shooter holds the ball
+    b0 = (env.frame.ball.x, env.frame.ball.y)
+    obs, r, d, _, _ = env.step(np.array([0.0, 1.0, 1.0], dtype=np.float32))   # kick
+    obs, r, d, _, _ = env.step(np.array([0.0, 0.0, 0.0], dtype=np.float32))
+    assert np.hypot(env.frame.ball.v_x, env.frame.ball.v_y) > 3.0
+    assert np.hypot(env.frame.ball.x - b0[0], env.frame.ball.y - b0[1]) > 0.1
+    env.close()

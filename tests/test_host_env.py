@@ -226,3 +226,88 @@ def test_base_class_hooks_raise_until_implemented(oracle_mod):
                 hook()
         assert float(env.norm_pos(10 * env.max_pos)) == 1.2 and float(env.norm_v(-10 * env.max_v)) == -1.2
         env.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# the other three registered SSL tasks (dribbling.py, contested_possession.py, pass_endurance.py)
+# ---------------------------------------------------------------------------------------------
+def _zigzag(points, start=2):
+    return {start + i: {0: x, 1: y} for i, (x, y) in enumerate(points)}
+
+
+TASKS = {
+    "drib": dict(cls="SSLHWDribblingEnv", nb=1, ny=4, info=None, scripts=[
+        (40, {}),
+        (20, _zigzag([(-0.75, 0.2), (-0.75, -0.2), (-1.25, -0.2), (-1.25, 0.2), (-1.75, 0.2), (-1.75, -0.2),
+                      (-2.5, -0.2), (-2.5, 0.2), (-1.75, 0.2), (-1.75, -0.2), (-2.5, -0.2), (-2.5, 0.2),
+                      (-1.75, 0.2), (-1.75, -0.2)])),
+        (12, _zigzag([(-0.75, 0.2), (-0.75, -0.2), (-1.25, -0.2), (-1.25, 0.2), (-1.25, -0.2), (-1.75, -0.2), (-1.75, 0.2)])),
+        (8, {5: {5: 1.5}}), (8, {5: {16 + 3: 0.2}})]),
+    "cont": dict(cls="SSLContestedPossessionEnv", nb=1, ny=1,
+                 info=("goal", "rbt_in_gk_area", "done_ball_out", "done_ball_out_right", "done_rbt_out",
+                       "ball_dist", "ball_grad", "energy", "collision"),
+                 scripts=[(30, {}), (10, {9: {16 + 3: 0.3}}), (10, {9: {5: -0.3}}), (10, {9: {5: 2.5, 6: 0.1}}),
+                          (10, {9: {0: -0.05}}), (10, {9: {0: 3.1, 1: 0.1}}), (10, {9: {0: 3.1, 1: 1.2}}),
+                          (10, {9: {16 + 4: -0.2, 0: 3.1, 1: 0.0}})]),
+    "pass": dict(cls="SSLPassEnduranceEnv", nb=2, ny=0, info=("reversed_dist", "ball_grad"),
+                 scripts=[(60, {}), (40, {}), (30, {10: {0: 3.4, 1: 1.9}}), (12, {11: {16 + 6: 1.0}})]),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(TASKS))
+def test_other_ssl_tasks_replay_reference_exactly(tag, oracle_mod):
+    import rsoccer_amd.ssl.ssl_hw_challenge as mod
+    spec = TASKS[tag]
+    fake_robosim.arm()
+    env = getattr(mod, spec["cls"])(sim_backend=fake_robosim)
+    nb, ny = spec["nb"], spec["ny"]
+    assert np.allclose([env.max_pos, env.max_v, env.max_w], G[f"{tag}_norms"], rtol=1e-15)
+    # observations of arbitrary states
+    for i, (s, want) in enumerate(zip(G[f"{tag}_obs_states"], G[f"{tag}_obs"])):
+        env.rsim.simulator.o.set_state_full(np.append(s, 0.0))
+        env.frame = env.rsim.get_frame()
+        if hasattr(env, "checkpoints_count"):
+            env.checkpoints_count = i % 7
+        assert np.array_equal(env._frame_to_observations(), want)
+    # seeded placement
+    for sd, want in zip(G["vss_place_seeds"], G[f"{tag}_place"]):
+        random.seed(int(sd))
+        fr = env._get_initial_positions_frame()
+        got = np.concatenate([[fr.ball.x, fr.ball.y, fr.ball.v_x, fr.ball.v_y]] +
+                             [[fr.robots_blue[i].x, fr.robots_blue[i].y, fr.robots_blue[i].theta] for i in range(nb)] +
+                             [[fr.robots_yellow[i].x, fr.robots_yellow[i].y, fr.robots_yellow[i].theta] for i in range(ny)])
+        assert np.array_equal(got, want)
+    # whole episodes
+    sent = []
+    real_step = env.rsim.simulator.step
+    env.rsim.simulator.step = lambda c: (sent.append(np.array(c)), real_step(c))[1]
+    ended = 0
+    for ep, (T, inj) in enumerate(spec["scripts"]):
+        random.seed(400 + ep)
+        fake_robosim.arm(inj)
+        obs, _ = env.reset()
+        assert np.array_equal(env.rsim.simulator.get_state(), G[f"{tag}_ep{ep}_reset_state"])
+        assert np.array_equal(obs, G[f"{tag}_ep{ep}_obs0"])
+        n = len(G[f"{tag}_ep{ep}_reward"])
+        for t in range(n):
+            o, r, d, tr, info = env.step(G[f"{tag}_ep{ep}_actions"][t].copy())
+            assert np.array_equal(sent[-1], G[f"{tag}_ep{ep}_cmds"][t]), (ep, t)
+            assert np.array_equal(o, G[f"{tag}_ep{ep}_obs"][t]), (ep, t)
+            assert r == G[f"{tag}_ep{ep}_reward"][t] and d == bool(G[f"{tag}_ep{ep}_done"][t]), (ep, t)
+            if spec["info"]:
+                assert [info[k] for k in spec["info"]] == list(G[f"{tag}_ep{ep}_info"][t]), (ep, t)
+        ended += int(d)
+    assert ended >= len(spec["scripts"]) - 2
+    env.close()
+
+
+def test_all_five_reference_ids_are_registered():
+    import json
+    import rsoccer_amd
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "registry.json")))
+    assert set(rsoccer_amd.registry) == set(ref)
+    for env_id, spec in ref.items():
+        assert rsoccer_amd.registry[env_id]["max_episode_steps"] == spec["max_episode_steps"]
+        assert rsoccer_amd.registry[env_id]["kwargs"] == spec["kwargs"]
+        # same class name behind the id as in the reference
+        assert rsoccer_amd.registry[env_id]["entry_point"].split(":")[1] == spec["entry_point"].split(":")[1]
