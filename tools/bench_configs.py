@@ -1,0 +1,81 @@
+"""Measures every BASELINE.json config that fits one GPU (parity-tested configs; bench.py is the
+contract for configs[1]) plus a batch-size sweep.  Writes a markdown table.
+usage: python tools/bench_configs.py [out.md]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from rsoccer_amd import _lib as L
+
+s = torch.cuda.current_stream().cuda_stream
+rows = []
+
+
+def timeit(fn, K):
+    fn(max(20, K // 10)); torch.cuda.synchronize()
+    t = time.perf_counter(); fn(K); torch.cuda.synchronize()
+    return (time.perf_counter() - t) / K * 1e6
+
+
+def fused(name, kind, ft, nb, ny, task, B, bytes_per_step, K=2000):
+    sim = L.Sim(kind, ft, nb, ny, 25, B); sim.task_attach(task, 0, 0, 0); sim.task_reset()
+    us = timeit(lambda n: sim.task_step_n(n, s), K)
+    ur = timeit(lambda n: sim.task_rollout(n, s), K)
+    rows.append((name, B, us, B / us, bytes_per_step * B / us / 1e3, ur, B / ur))
+    sim.close()
+
+
+def raw_ssl(name, ft, nb, ny, B, crowded, bytes_per_step, K=1000):
+    """SSL raw simulator (rsx_step_dev) with per-step random local-velocity commands written by
+    torch into the SoA command buffer — BASELINE configs[3] (synthetic SSLBaseEnv-style task)."""
+    sim = L.Sim(1, ft, nb, ny, 25, B)
+    N = nb + ny
+    rng = np.random.default_rng(0)
+    f = sim.get_field_params()
+    ball = np.zeros((B, 4)); rob = np.zeros((B, N, 3))
+    if crowded:   # every robot inside a 1.5 m disc around the ball: saturates the contact sweep
+        for k in range(N):
+            r, a = 0.25 + 1.25 * np.sqrt((k + 0.5) / N), 2.4 * k
+            rob[:, k, 0] = r * np.cos(a); rob[:, k, 1] = r * np.sin(a)
+    else:         # jittered grid, >= 0.2 m apart
+        gx, gy = np.meshgrid(np.linspace(-4.5, 4.5, 6), np.linspace(-3.2, 3.2, 4))
+        pts = np.stack([gx.ravel(), gy.ravel()], 1)[:N]
+        rob[:, :, :2] = pts[None] + rng.uniform(-0.3, 0.3, (B, N, 2))
+        ball[:, :2] = rng.uniform(-0.2, 0.2, (B, 2)) + [0.9, 0.8]
+    rob[:, :, 2] = rng.uniform(-180, 180, (B, N))
+    sim.reset(ball, rob[:, :nb], rob[:, nb:])
+    cm = sim.cmds_tensor().view(N, 8, B)
+    scale = torch.tensor([2.5, 2.5, 10.0], device="cuda").view(1, 3, 1)
+
+    def run(n):
+        for _ in range(n):
+            cm[:, 1:4, :] = (torch.rand(N, 3, B, device="cuda") * 2 - 1) * scale
+            sim.step_dev(s)
+    us = timeit(run, K)
+    def run_sim_only(n):
+        for _ in range(n):
+            sim.step_dev(s)
+    uso = timeit(run_sim_only, K)
+    rows.append((name + " (torch command generation included)", B, us, B / us, bytes_per_step * B / us / 1e3, float("nan"), float("nan")))
+    rows.append((name + " (step kernel only)", B, uso, B / uso, bytes_per_step * B / uso / 1e3, float("nan"), float("nan")))
+    sim.close()
+
+
+fused("configs[1] VSS-v0 3v3 fused", 0, 0, 3, 3, 1, 4096, 541)
+fused("configs[2] SSLStaticDefenders-v0 1v6 fused", 1, 2, 1, 6, 2, 2048, 981)
+raw_ssl("configs[3] SSL 11v11 raw sim, spread", 1, 11, 11, 1024, False, 2680)
+raw_ssl("configs[3] SSL 11v11 raw sim, crowded (worst-case contacts)", 1, 11, 11, 1024, True, 2680)
+for B in (256, 1024, 16384, 65536, 262144, 1048576, 4194304):
+    fused("sweep VSS-v0 fused", 0, 0, 3, 3, 1, B, 541, K=2000 if B <= 65536 else 200)
+for B in (16384, 262144):
+    fused("sweep SSLStaticDefenders-v0 fused", 1, 2, 1, 6, 2, B, 981, K=500 if B <= 65536 else 100)
+
+lines = ["| config | envs | us / step (1 launch per step) | M env-steps/s | algorithmic GB/s | frac of 8 TB/s | us / step (one launch) | M env-steps/s (one launch) |",
+         "|---|---|---|---|---|---|---|---|"]
+for name, B, us, rate, gbs, ur, rr in rows:
+    lines.append(f"| {name} | {B} | {us:.2f} | {rate:.1f} | {gbs:.1f} | {gbs / 8000 * 100:.2f} % | {ur:.2f} | {rr:.1f} |")
+text = "\n".join(lines)
+print(text)
+if len(sys.argv) > 1:
+    open(sys.argv[1], "w").write("# Per-config and batch-sweep measurements (MI355X)\n\nProduced by `python tools/bench_configs.py` "
+                                 "(algorithmic bytes per env-step: SURVEY.md 8(d)).\n\n" + text + "\n")
