@@ -73,6 +73,7 @@ struct Shared {
     float x0[64 / L][12];      // robot 0 -> reward lane exchange
     int flag[64 / L];          // episode-end flag per env
     float stage[(64 / L) * 64];  // obs staging, [env][obs_dim], obs_dim <= 64
+    float2 draws[64 / L][L < 16 ? 16 : L];  // placement: speculative Philox draws of an ended env
 };
 
 // clamp a circle (radius r, restitution rest) into the playable region
@@ -567,36 +568,58 @@ __device__ __forceinline__ float vss_wheel(float a) {
 }
 
 // Random placement of one env (vss_gym.py:194-233 / static_defenders.py:214-254 with Philox
-// draws).  Runs on the env's ball lane; poses go to A[body slot] = (x, y, theta_deg, 0).
+// draws).  The algorithm is sequential (every candidate is tested against the bodies already
+// placed, and the index of a draw depends on how many were rejected before it), and runs on the
+// env's ball lane; the expensive part, the Philox blocks, is hoisted: draws 0..NPRE-1 were
+// computed speculatively by all lanes of the env (place_predraw) and are only read here.
+// Poses go to A[body slot] = (x, y, theta_deg, 0).
+template <int L>
+__device__ __forceinline__ void place_predraw(const Params& P, uint32_t env_id, uint32_t episode,
+                                              int b, float2* __restrict__ draws) {
+    constexpr int NPRE = L < 16 ? 16 : L;
+#pragma unroll
+    for (int n = b; n < NPRE; n += L) {
+        const u32x4 u = philox4x32_10(env_id, episode, (uint32_t)n, DOM_PLACE, P.key0, P.key1);
+        draws[n] = make_float2(u01(u.x), u01(u.y));
+    }
+}
+
 template <int TASK, int L>
 __device__ __forceinline__ void place_env(const Params& P, const int N, uint32_t env_id,
-                                          uint32_t episode, int g, float4* A) {
+                                          uint32_t episode, int g, float4* A, const float2* draws) {
     constexpr int G = 64 / L;
+    constexpr int NPRE = L < 16 ? 16 : L;
     uint32_t n = 0;
+    auto draw = [&]() -> float2 {
+        const uint32_t i = n++;
+        if (i < (uint32_t)NPRE) return draws[i];
+        const u32x4 u = philox4x32_10(env_id, episode, i, DOM_PLACE, P.key0, P.key1);
+        return make_float2(u01(u.x), u01(u.y));
+    };
     int first = 0;
     float bx, by;
     if (TASK == RSX_TASK_SSL_STATIC_DEFENDERS) {
         bx = 0.0f; by = 0.0f;
         for (int t = 0; t < 64; ++t) {
-            u32x4 u = philox4x32_10(env_id, episode, n++, DOM_PLACE, P.key0, P.key1);
-            bx = P.pl_xlo + P.pl_xspan * u01(u.x);
-            by = P.pl_ylo + P.pl_yspan * u01(u.y);
+            const float2 u = draw();
+            bx = P.pl_xlo + P.pl_xspan * u.x;
+            by = P.pl_ylo + P.pl_yspan * u.y;
             if (!(bx > P.pen_x && fabsf(by) < P.half_pen_wid)) break;
         }
         A[0 * G + g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // blue 0 at the origin
         first = 1;
     } else {
-        u32x4 u = philox4x32_10(env_id, episode, n++, DOM_PLACE, P.key0, P.key1);
-        bx = P.pl_xlo + P.pl_xspan * u01(u.x);
-        by = P.pl_ylo + P.pl_yspan * u01(u.y);
+        const float2 u = draw();
+        bx = P.pl_xlo + P.pl_xspan * u.x;
+        by = P.pl_ylo + P.pl_yspan * u.y;
     }
     A[N * G + g] = make_float4(bx, by, 0.0f, 0.0f);
     for (int k = first; k < N; ++k) {
         float x = 0.0f, y = 0.0f;
         for (int t = 0; t < 64; ++t) {
-            u32x4 u = philox4x32_10(env_id, episode, n++, DOM_PLACE, P.key0, P.key1);
-            x = P.pl_xlo + P.pl_xspan * u01(u.x);
-            y = P.pl_ylo + P.pl_yspan * u01(u.y);
+            const float2 u = draw();
+            x = P.pl_xlo + P.pl_xspan * u.x;
+            y = P.pl_ylo + P.pl_yspan * u.y;
             bool ok = true;
             {   // ball first, then (static defenders) blue 0, then the robots placed so far
                 float dx = x - bx, dy = y - by;
@@ -609,8 +632,8 @@ __device__ __forceinline__ void place_env(const Params& P, const int N, uint32_t
             }
             if (ok) break;
         }
-        u32x4 u = philox4x32_10(env_id, episode, n++, DOM_PLACE, P.key0, P.key1);
-        A[k * G + g] = make_float4(x, y, 360.0f * u01(u.x), 0.0f);
+        const float2 u = draw();
+        A[k * G + g] = make_float4(x, y, 360.0f * u.x, 0.0f);
     }
 }
 
@@ -858,8 +881,8 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
             if (ended && mode == 0) {  // terminal observation
                 for (int i = b; i < OD; i += L) bufs.final_obs[(size_t)e * OD + i] = sh.stage[g * OD + i];
             }
+            if (ended && mode == 0) episode += 1;   // every lane of the env: the new episode's id
             if (ended && is_ball && mode == 0) {
-                episode += 1;
                 atomicAdd(&bufs.metrics[1], 1ull);
                 if (TASK == RSX_TASK_VSS_V0) {
                     if (info[4] > 0.0f) atomicAdd(&bufs.metrics[2], 1ull);
@@ -869,11 +892,11 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
                 atomicAdd(&bufs.metrics[5], (unsigned long long)steps);
                 if (trunc && !term) atomicAdd(&bufs.metrics[6], 1ull);
             }
-            wave_sync();  // stage rows of ended envs are about to be overwritten
-            if (ended && is_ball) place_env<TASK, L>(P, N, env_id, episode, g, sh.A);
+            if (ended) place_predraw<L>(P, env_id, episode, b, sh.draws[g]);
+            wave_sync();  // draws published; stage rows of ended envs are about to be overwritten
+            if (ended && is_ball) place_env<TASK, L>(P, N, env_id, episode, g, sh.A, sh.draws[g]);
             wave_sync();
             if (ended) {
-                if (!is_ball && mode == 0) episode += 1;
                 steps = 0; ou0 = 0.0f; ou1 = 0.0f; was_reset = true;
                 if (is_robot || is_ball) {
                     const float4 pz = sh.A[b * G + g];
