@@ -22,7 +22,7 @@ typedef struct SUF(rsxo_env) {
     R rs_rr, rs_rr2, rs_rb, rs_rb2;
     R w_rr, w_rb_r, w_rb_b, ope_rr, ope_rb, e_wb, e_wr, beta;
     R w_max, half_rw, rw_2b, inv_rw, r_wheel;
-    R a_lin_h, a_lin_h2, a_lat_h, a_ang_h, mu_g_h, g_h, e_ground, vz_min, robot_h;
+    R a_lin_h, a_lin_h2, a_lat_h, a_ang_h, mu_g_dt, g_h, e_ground, vz_min, robot_h;
     R dck_rb, half_kw, ir_tol, drib_gain, drib_vmax, drib_vmax2;
     R ws[4], wc[4], pinv[3][4];
     R deg2rad, rad2deg, h_deg;
@@ -72,7 +72,7 @@ void* SUF(rsxo_create)(int kind, int field_type, int nb, int ny, int ts_ms) {
     e->inv_rw = RC(1.0 / c->r_wheel);
     e->a_lin_h = RC(c->a_lin * c->h); e->a_lin_h2 = RC((c->a_lin * c->h) * (c->a_lin * c->h));
     e->a_lat_h = RC(c->a_lat * c->h); e->a_ang_h = RC(c->a_ang * c->h);
-    e->mu_g_h = RC(c->mu_g * c->h); e->g_h = RC(c->grav * c->h);
+    e->mu_g_dt = RC(c->mu_g * (c->time_step_ms * 0.001)); e->g_h = RC(c->grav * c->h);
     e->e_ground = RC(c->e_ground); e->vz_min = RC(c->vz_min); e->robot_h = RC(c->robot_h);
     e->dck_rb = RC(c->dck + c->r_ball); e->half_kw = RC(c->half_kw); e->ir_tol = RC(c->ir_tol);
     e->drib_gain = RC(c->h > 0 ? 0.5 / c->h : 0.0);
@@ -242,6 +242,17 @@ static void SUF(step_core)(SUF(rsxo_env)* e, const R* cmds) {
     SUF(body)* ball = &b[N];
     ball->x = s[0]; ball->y = s[1]; ball->z = s[2] - e->r_ball; ball->vx = s[3]; ball->vy = s[4];
     ball->vz = s[e->state_dim];
+    /* rolling resistance: a constant deceleration, applied once for the whole step() while the
+     * ball is on the ground (exact stop, never reverses) */
+    if (c->n_sub && !(ball->z > RC(0) || ball->vz > RC(0))) {
+        R sp2 = ball->vx * ball->vx + ball->vy * ball->vy;
+        if (sp2 > RC(0)) {
+            R sp = R_SQRT(sp2), ns = sp - e->mu_g_dt;
+            if (ns < RC(0)) ns = RC(0);
+            R k = ns / sp;
+            ball->vx = ball->vx * k; ball->vy = ball->vy * k;
+        }
+    }
 
     for (int sub = 0; sub < c->n_sub; ++sub) {
         /* ---- A: actuation + integration ---- */
@@ -276,14 +287,6 @@ static void SUF(step_core)(SUF(rsxo_env)* e, const R* cmds) {
                 ball->z = RC(0);
                 ball->vz = -ball->vz * e->e_ground;
                 if (ball->vz < e->vz_min) ball->vz = RC(0);
-            }
-        } else {
-            R sp2 = ball->vx * ball->vx + ball->vy * ball->vy;
-            if (sp2 > RC(0)) {
-                R sp = R_SQRT(sp2), ns = sp - e->mu_g_h;
-                if (ns < RC(0)) ns = RC(0);
-                R k = ns / sp;
-                ball->vx = ball->vx * k; ball->vy = ball->vy * k;
             }
         }
         ball->x = ball->x + ball->vx * e->h;

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librsx_hip.so")
+LIB_PATH = os.environ.get("RSX_LIB") or os.path.join(_HERE, "librsx_hip.so")  # RSX_LIB: development builds
 
 KIND_VSS, KIND_SSL = 0, 1
 TASK_NONE, TASK_VSS_V0, TASK_SSL_STATIC_DEFENDERS = 0, 1, 2

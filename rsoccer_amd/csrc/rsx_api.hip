@@ -70,10 +70,17 @@ dim3 grid_for(const rsx_sim* h) {
     return dim3((unsigned)(((tiles + 7) / 8) * 8));
 }
 
+#ifdef RSX_TIMING
+unsigned long long* g_dbg = nullptr;  // development builds: s_memtime stamps
+#endif
+
 Buffers buffers_of(const rsx_sim* h, const float* actions) {
     Buffers b;
     b.state = h->d_state; b.aux = h->d_aux; b.obs = h->d_obs; b.final_obs = h->d_final_obs;
     b.flags = h->d_flags; b.cmds = h->d_cmds; b.actions = actions; b.metrics = h->d_metrics;
+#ifdef RSX_TIMING
+    b.dbg = g_dbg;
+#endif
     return b;
 }
 
@@ -202,6 +209,10 @@ size_t align_up(size_t n) { return (n + 255) & ~(size_t)255; }
 }  // namespace
 
 extern "C" {
+
+#ifdef RSX_TIMING
+int rsx_dbg_set(unsigned long long* p) { g_dbg = p; return 0; }
+#endif
 
 int rsx_abi_version(void) { return RSX_ABI_VERSION; }
 const char* rsx_last_error(void) { return g_err.c_str(); }

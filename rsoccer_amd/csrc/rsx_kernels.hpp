@@ -52,6 +52,9 @@ struct Buffers {
     const float* cmds;     // [N*C][B]        (raw simulator path)
     const float* actions;  // [B][act_dim] or nullptr = random
     unsigned long long* metrics;  // [RSX_METRICS]
+#ifdef RSX_TIMING
+    unsigned long long* dbg;      // [8][gridDim] s_memtime stamps (development builds only)
+#endif
 };
 
 // what one lane keeps in registers for its body
@@ -197,6 +200,19 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
     const bool is_ball = live && b == N;
     const int lane = b * G + g;
 
+    // rolling resistance: a constant deceleration, applied once for the whole step() while the
+    // ball is on the ground (exact stop, never reverses) — keeps the sqrt + divide chain out of
+    // the sub-step loop, where the ball lane's branch is serialised with the robots' work
+    if (is_ball && P.n_sub && !(o.z > 0.0f || o.vz > 0.0f)) {
+        float sp2 = o.vx * o.vx + o.vy * o.vy;
+        if (sp2 > 0.0f) {
+            float sp = sqrtf(sp2), ns = sp - P.mu_g_dt;
+            if (ns < 0.0f) ns = 0.0f;
+            float k = ns / sp;
+            o.vx = o.vx * k; o.vy = o.vy * k;
+        }
+    }
+
     for (int sub = 0; sub < P.n_sub; ++sub) {
         // ---- A: actuation + integration ----
         if (is_robot) {
@@ -229,14 +245,6 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                     o.z = 0.0f;
                     o.vz = -o.vz * K::e_ground;
                     if (o.vz < K::vz_min) o.vz = 0.0f;
-                }
-            } else {
-                float sp2 = o.vx * o.vx + o.vy * o.vy;
-                if (sp2 > 0.0f) {
-                    float sp = sqrtf(sp2), ns = sp - P.mu_g_h;
-                    if (ns < 0.0f) ns = 0.0f;
-                    float k = ns / sp;
-                    o.vx = o.vx * k; o.vy = o.vy * k;
                 }
             }
             o.x = o.x + o.vx * P.h;
@@ -668,6 +676,12 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
     const int OD = P.obs_dim;
     float* const auxe = bufs.aux + e;  // column of this env in the scalar arena
 
+#ifdef RSX_TIMING
+#define RSX_STAMP(i) do { if (lane == 0) bufs.dbg[(size_t)(i) * gridDim.x + blockIdx.x] = __builtin_readcyclecounter(); } while (0)
+#else
+#define RSX_STAMP(i) do {} while (0)
+#endif
+    RSX_STAMP(0);
     // ---- load ----
     Body o; float od, wd, wheels[4];
     load_body<KIND>(P, bufs.state, e, b, is_robot, is_ball, o, od, wd, wheels);
@@ -704,6 +718,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
     // counters that wait also drains the previous trip's global STORES: one HBM write round
     // trip per env step in the multi-step (rollout) launches.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    RSX_STAMP(1);
 
     for (int it = 0; it < n_steps; ++it) {
         bool ended;
@@ -791,7 +806,9 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
             if (is_robot) robot_targets<KIND>(P, o, q);
 
             // ---- physics ----
+            RSX_STAMP(2);
             physics<KIND, L, NR>(P, o, b, g, live, sh);
+            RSX_STAMP(3);
 
             // ---- wire-format values, observation, reward ----
             if (is_robot) {
@@ -876,6 +893,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
             }
         }
 
+        RSX_STAMP(4);
         // ---- episode end: same-step auto-reset (or reset()) ----
         if (__any(ended)) {
             if (ended && mode == 0) {  // terminal observation
@@ -921,6 +939,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
         wave_sync();
     }
 
+    RSX_STAMP(5);
     // ---- store (wire format: degrees, deg/s; SSL: infrared + wheel speeds) ----
     if (mode != 2) store_body<KIND>(P, bufs.state, e, b, is_robot, is_ball, o, od, wd, wheels, P.n_sub != 0 || was_reset);
     if (live && b == 0) {
@@ -931,6 +950,11 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
         auxe[(size_t)(ROW_OU + 2 * b) * B] = ou0; auxe[(size_t)(ROW_OU + 2 * b + 1) * B] = ou1;
     }
     if (is_ball) { auxe[(size_t)ROW_PREV_POT * B] = prev_pot; auxe[(size_t)ROW_EP_RET * B] = ep_ret; }
+    RSX_STAMP(6);
+#ifdef RSX_TIMING
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    RSX_STAMP(7);
+#endif
 }
 
 }  // namespace rsx

@@ -113,7 +113,7 @@ template <> struct TC<RSX_TASK_SSL_STATIC_DEFENDERS> {  // static_defenders.py:7
 struct Params {
     int kind, n_blue, n_yellow, n_robots, n_sub, state_dim, num_envs;
     // sub-step and field dependent
-    float h, h_deg, a_lin_h, a_lin_h2, a_lat_h, a_ang_h, mu_g_h, g_h, drib_gain;
+    float h, h_deg, a_lin_h, a_lin_h2, a_lat_h, a_ang_h, mu_g_dt, g_h, drib_gain;
     float half_len, half_wid, ghw, gd;
     // omni-wheel kinematics (SSL; used once per step)
     float ws[4], wc[4], pinv[3][4];
@@ -161,7 +161,7 @@ inline int derive_model_k(int field_type, int ts_ms, Params& P, HostModel& M) {
     P.h_deg = (float)(h * (180.0 / PI_D));      // heading is integrated in degrees, the wire unit
     P.a_lin_h = (float)(D::a_lin * h); P.a_lin_h2 = (float)((D::a_lin * h) * (D::a_lin * h));
     P.a_lat_h = (float)(D::a_lat * h); P.a_ang_h = (float)(D::a_ang * h);
-    P.mu_g_h = (float)(D::mu_g * h); P.g_h = (float)(GRAV_D * h);
+    P.mu_g_dt = (float)(D::mu_g * (ts_ms * 0.001)); P.g_h = (float)(GRAV_D * h);
     P.drib_gain = (float)(h > 0 ? 0.5 / h : 0.0);
     P.half_len = (float)(f[0] / 2); P.half_wid = (float)(f[1] / 2);
     P.ghw = (float)(f[4] / 2); P.gd = (float)f[5];
