@@ -43,6 +43,9 @@ extern "C" {
 #define RSX_TASK_NONE                 0 /* raw simulator only                                         */
 #define RSX_TASK_VSS_V0               1 /* rsoccer_gym/vss/env_vss/vss_gym.py:13  (obs 40, act 2)     */
 #define RSX_TASK_SSL_STATIC_DEFENDERS 2 /* ssl/ssl_hw_challenge/static_defenders.py:12 (obs 24, act 5)*/
+#define RSX_TASK_SSL_DRIBBLING        3 /* ssl/ssl_hw_challenge/dribbling.py:11         (obs 21, act 4)*/
+#define RSX_TASK_SSL_CONTESTED        4 /* ssl/ssl_hw_challenge/contested_possession.py:11 (obs 14, act 5)*/
+#define RSX_TASK_SSL_PASS_ENDURANCE   5 /* ssl/ssl_hw_challenge/pass_endurance.py:11    (obs 16, act 3)*/
 
 /* error codes */
 #define RSX_OK              0
@@ -73,10 +76,11 @@ typedef struct rsx_dev_view {
 
 typedef struct rsx_task_view {
     int32_t  task;
-    int32_t  obs_dim;       /* 40 | 24                                                       */
-    int32_t  act_dim;       /* 2 | 5                                                         */
-    int32_t  info_dim;      /* 6 | 8 : cumulative reward-shaping terms, order of the
-                               reference's reward_shaping_total dict                         */
+    int32_t  obs_dim;       /* 40 | 24 | 21 | 14 | 16                                        */
+    int32_t  act_dim;       /* 2 | 5 | 4 | 5 | 3                                             */
+    int32_t  info_dim;      /* 6 | 8 | 1 | 9 | 2 : cumulative reward-shaping terms, order of the
+                               reference's reward_shaping_total dict (dribbling, which has
+                               none: its checkpoint counter)                                 */
     int32_t  max_episode_steps;
     float*   obs;           /* [B][obs_dim] f32 row-major (what a policy consumes)           */
     float*   reward;        /* [B] f32                                                       */
@@ -138,10 +142,10 @@ int rsx_step_dev(rsx_sim* h, void* stream);
 
 /* ---- fused task epilogues -------------------------------------------------------------- */
 
-/* Attach a task to a handle whose kind / robot counts match it (VSS_V0: VSS 3v3;
- * STATIC_DEFENDERS: SSL 1v6).  seed + (env_id_base + local env index) key every random draw,
+/* Attach a task to a handle whose kind / robot counts match it (VSS_V0: VSS, n_blue >= 1;
+ * STATIC_DEFENDERS: SSL 1vN; DRIBBLING: SSL 1v4; CONTESTED: SSL 1v1; PASS_ENDURANCE: SSL 2v0).  seed + (env_id_base + local env index) key every random draw,
  * so results do not depend on batch size, batch position or sharding.
- * max_episode_steps <= 0 selects the registry value (1200 / 1000). */
+ * max_episode_steps <= 0 selects the registry value (1200 / 1000 / 4800 / 1200 / 1200). */
 int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base,
                     int max_episode_steps);
 int rsx_task_view_get(rsx_sim* h, rsx_task_view* out);

@@ -113,9 +113,12 @@ class OracleEnv:
             raise ValueError("oracle: task does not match the simulator")
         self.task = task
         self.obs_dim = {1: 4 + 7 * self.n_blue + 5 * self.n_yellow,
-                        2: 4 + 8 * self.n_blue + 2 * self.n_yellow}[task]
-        self.act_dim = {1: 2, 2: 5}[task]
-        self.info_dim = {1: 6, 2: 8}[task]
+                        2: 4 + 8 * self.n_blue + 2 * self.n_yellow,
+                        3: 5 + 8 * self.n_blue + 2 * self.n_yellow,
+                        4: 4 + 8 * self.n_blue + 2 * self.n_yellow,
+                        5: 4 + 6 * self.n_blue}[task]
+        self.act_dim = {1: 2, 2: 5, 3: 4, 4: 5, 5: 3}[task]
+        self.info_dim = {1: 6, 2: 8, 3: 1, 4: 9, 5: 2}[task]
 
     def task_reset(self):
         self._f("rsxo_task_reset")(self.h)
@@ -181,6 +184,16 @@ class OracleEnv:
         n = np.ascontiguousarray(normals, dtype=np.float64).reshape(-1)
         self._f("rsxo_ou_eval")(self.h, _d(x), _d(n), len(x))
         return x
+
+    def set_scalar(self, v):
+        f = self._f("rsxo_task_set_scalar")
+        f.argtypes = [C.c_void_p, C.c_double]
+        f(self.h, float(v))
+
+    def get_scalar(self):
+        f = self._f("rsxo_task_get_scalar")
+        f.restype = C.c_double
+        return f(self.h)
 
     def norms(self):
         out = np.zeros(3)

@@ -15,8 +15,10 @@
  *       file is its executable definition and the HIP kernels are checked against it
  *       (bit-exact for the f32 instantiation).
  *   (2) TASK ARITHMETIC — observation / command / reward / done / placement / OU-noise
- *       formulas of VSS-v0 (rsoccer_gym/vss/env_vss/vss_gym.py:93-311) and
- *       SSLStaticDefenders-v0 (rsoccer_gym/ssl/ssl_hw_challenge/static_defenders.py:90-322).
+ *       formulas of VSS-v0 (rsoccer_gym/vss/env_vss/vss_gym.py:93-311),
+ *       SSLStaticDefenders-v0 (rsoccer_gym/ssl/ssl_hw_challenge/static_defenders.py:90-322),
+ *       SSLDribbling-v0 (dribbling.py:76-202), SSLContestedPossession-v0
+ *       (contested_possession.py:78-227) and SSLPassEndurance-v0 (pass_endurance.py:77-233).
  *       These ARE pinned: tests/test_oracle_golden.py checks them against vectors captured by
  *       importing the reference (tests/golden/make_golden.py).
  *
@@ -203,8 +205,27 @@ void rsxo_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 void rsxo_set_threads(int n) { (void)n; }
 #endif
 
+/* atan2 for the float instantiation (Cephes atanf; only used by the PassEndurance placement) */
+static inline float rsxo_atan_f32(float x) {
+    float sgn = x < 0.0f ? -1.0f : 1.0f;
+    x = fabsf(x);
+    float y;
+    if (x > 2.414213562373095f) { y = 1.5707963267948966f; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y = 0.7853981633974483f; x = (x - 1.0f) / (x + 1.0f); }
+    else y = 0.0f;
+    float z = x * x;
+    y = y + ((((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x);
+    return sgn * y;
+}
+static inline float rsxo_atan2_f32(float y, float x) {
+    if (x > 0.0f) return rsxo_atan_f32(y / x);
+    if (x < 0.0f) return rsxo_atan_f32(y / x) + (y >= 0.0f ? 3.14159265358979f : -3.14159265358979f);
+    return y > 0.0f ? 1.5707963267948966f : (y < 0.0f ? -1.5707963267948966f : 0.0f);
+}
+
 /* ---- instantiate: float ---- */
 #define R float
+#define R_ATAN2(y, x) rsxo_atan2_f32((y), (x))
 #define SUF(n) n##_f32
 #define R_SINCOS(a, s, c) rsxo_sincos_f32((a), (s), (c))
 #define R_LOG(x) rsxo_log_f32(x)
@@ -217,6 +238,7 @@ void rsxo_set_threads(int n) { (void)n; }
 #undef R_LOG
 #undef R_SQRT
 #undef R_FABS
+#undef R_ATAN2
 
 /* ---- instantiate: double ---- */
 static inline void rsxo_sincos_f64(double a, double* s, double* c) { *s = sin(a); *c = cos(a); }
@@ -226,4 +248,5 @@ static inline void rsxo_sincos_f64(double a, double* s, double* c) { *s = sin(a)
 #define R_LOG(x) log(x)
 #define R_SQRT(x) sqrt(x)
 #define R_FABS(x) fabs(x)
+#define R_ATAN2(y, x) atan2((y), (x))
 #include "rsx_oracle_impl.h"

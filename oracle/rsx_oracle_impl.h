@@ -34,7 +34,7 @@ typedef struct SUF(rsxo_env) {
     R max_pos, inv_max_pos, max_v, inv_max_v, inv_max_w, deadzone;
     R ou[MAXROB][2];
     R prev_pot, ep_ret;
-    R info[8];
+    R info[10];
     R obs[64], final_obs[64], reward;
     R last_cmds[MAXROB * 8];
     uint8_t terminated, truncated;
@@ -409,6 +409,18 @@ int SUF(rsxo_task_attach)(void* p, int task, uint64_t seed, uint64_t env_id, int
         if (c->kind != 1 || c->n_blue != 1) return -1;
         e->obs_dim = 4 + 8 * c->n_blue + 2 * c->n_yellow; e->act_dim = 5; e->info_dim = 8;
         e->max_steps = max_steps > 0 ? max_steps : 1000;
+    } else if (task == 3) {  /* SSLDribbling-v0: dribbling.py:46-57, registry 4800 steps */
+        if (c->kind != 1 || c->n_blue != 1 || c->n_yellow != 4) return -1;
+        e->obs_dim = 5 + 8 * c->n_blue + 2 * c->n_yellow; e->act_dim = 4; e->info_dim = 1;
+        e->max_steps = max_steps > 0 ? max_steps : 4800;
+    } else if (task == 4) {  /* SSLContestedPossession-v0: contested_possession.py:42-52, 1200 steps */
+        if (c->kind != 1 || c->n_blue != 1 || c->n_yellow != 1) return -1;
+        e->obs_dim = 4 + 8 * c->n_blue + 2 * c->n_yellow; e->act_dim = 5; e->info_dim = 9;
+        e->max_steps = max_steps > 0 ? max_steps : 1200;
+    } else if (task == 5) {  /* SSLPassEndurance-v0: pass_endurance.py:45-56, 1200 steps */
+        if (c->kind != 1 || c->n_blue != 2 || c->n_yellow != 0) return -1;
+        e->obs_dim = 4 + 6 * c->n_blue; e->act_dim = 3; e->info_dim = 2;
+        e->max_steps = max_steps > 0 ? max_steps : 1200;
     } else return -1;
     e->task = task;
     e->key[0] = (uint32_t)seed; e->key[1] = (uint32_t)(seed >> 32);
@@ -417,7 +429,7 @@ int SUF(rsxo_task_attach)(void* p, int task, uint64_t seed, uint64_t env_id, int
     double max_pos = fmax(f[1] / 2, f[0] / 2 + f[2]);
     double max_v = (f[16] / 60.0) * 2.0 * RSXO_PI * f[15];
     double max_w = (max_v / (c->kind == 0 ? 0.04 : 0.095)) * (180.0 / RSXO_PI);
-    if (task == 2) { max_v = 2.5; max_w = 10.0; } /* static_defenders.py:76-77 */
+    if (task >= 2) { max_v = 2.5; max_w = 10.0; } /* static_defenders.py:76-77 and the same in the other SSL tasks */
     e->max_pos = RC(max_pos); e->inv_max_pos = RC(1.0 / max_pos);
     e->max_v = RC(max_v); e->inv_max_v = RC(1.0 / max_v); e->inv_max_w = RC(1.0 / max_w);
     e->deadzone = RC(0.05);
@@ -427,7 +439,7 @@ int SUF(rsxo_task_attach)(void* p, int task, uint64_t seed, uint64_t env_id, int
     e->pen_x = RC(f[0] / 2 - f[2]); e->half_pen_wid = RC(f[3] / 2);
     e->inv_bd_scale = RC(1.0 / sqrt(f[1] * f[1] + (f[0] / 2) * (f[0] / 2)));
     e->inv_bg_scale = RC(1.0 / (sqrt((f[1] / 2) * (f[1] / 2) + (f[0] / 2) * (f[0] / 2)) / 4.0));
-    e->inv_en_scale = RC(1.0 / (160.0 * 4.0 * 1000.0));
+    e->inv_en_scale = RC(1.0 / (160.0 * 4.0 * (task == 4 ? 1200.0 : 1000.0)));  /* static_defenders.py:71-73, contested_possession.py:60-62 */
     if (task == 1) { /* vss_gym.py:199-206 */
         e->pl_xlo = RC(-(f[0] / 2) + 0.1); e->pl_xspan = RC((f[0] / 2 - 0.1) - (-(f[0] / 2) + 0.1));
         e->pl_min_d2 = RC(0.1 * 0.1);
@@ -448,6 +460,7 @@ static void SUF(task_obs)(const SUF(rsxo_env)* e, R* o) {
     const R* s = e->state;
     const R lo = RC(-1.2), hi = RC(1.2);
     int n = 0;
+    if (e->task == 3) o[n++] = ((e->prev_pot / RC(6)) * RC(2)) - RC(1);  /* checkpoint progress, dribbling.py:80 */
     o[n++] = SUF(clampr)(s[0] * e->inv_max_pos, lo, hi);
     o[n++] = SUF(clampr)(s[1] * e->inv_max_pos, lo, hi);
     o[n++] = SUF(clampr)(s[3] * e->inv_max_v, lo, hi);
@@ -459,10 +472,13 @@ static void SUF(task_obs)(const SUF(rsxo_env)* e, R* o) {
         o[n++] = SUF(clampr)(r[0] * e->inv_max_pos, lo, hi);
         o[n++] = SUF(clampr)(r[1] * e->inv_max_pos, lo, hi);
         o[n++] = sn; o[n++] = cs;
-        o[n++] = SUF(clampr)(r[3] * e->inv_max_v, lo, hi);
-        o[n++] = SUF(clampr)(r[4] * e->inv_max_v, lo, hi);
+        if (e->task != 5) {  /* pass_endurance.py:84-90 leaves the linear velocity out */
+            o[n++] = SUF(clampr)(r[3] * e->inv_max_v, lo, hi);
+            o[n++] = SUF(clampr)(r[4] * e->inv_max_v, lo, hi);
+        }
         o[n++] = SUF(clampr)(r[5] * e->inv_max_w, lo, hi);
-        if (e->task == 2) o[n++] = r[6] != RC(0) ? RC(1) : RC(0);
+        if (e->task == 3) o[n++] = r[6] != RC(0) ? RC(1) : RC(-1);       /* dribbling.py:99 */
+        else if (e->task >= 2) o[n++] = r[6] != RC(0) ? RC(1) : RC(0);
     }
     for (int k = c->n_blue; k < c->n_robots; ++k) {
         const R* r = s + 5 + e->RS * k;
@@ -491,9 +507,20 @@ static void SUF(vss_cmds)(const SUF(rsxo_env)* e, const R* act, R* cmds) {
         cmds[2 * k + 1] = SUF(vss_wheel)(e, act[2 * k + 1]);
     }
 }
-/* static_defenders.py:114-148; theta_deg = pre-step heading of blue 0 */
+/* SSL tasks; theta_deg = pre-step heading of blue 0.
+ * task 2/4: static_defenders.py:114-148, contested_possession.py:106-137 (v_x, v_y, v_theta, kick, dribbler)
+ * task 3:   dribbling.py:106-135 (v_x, v_y, v_theta, dribbler)
+ * task 5:   pass_endurance.py:106-130 (v_theta, kick strength, dribbler; receiver: dribbler on) */
 static void SUF(sd_cmds)(const SUF(rsxo_env)* e, const R* a, R theta_deg, R* cmds) {
     memset(cmds, 0, sizeof(R) * 8 * e->cfg.n_robots);
+    if (e->task == 5) {
+        R k = R_FABS(a[1]) > RC(0.5) ? a[1] : RC(0);
+        cmds[3] = a[0] * RC(10.0);
+        cmds[5] = k * RC(5.0);
+        cmds[7] = a[2] > RC(0) ? RC(1) : RC(0);
+        cmds[8 + 7] = RC(1);
+        return;
+    }
     R sn, cs;
     R_SINCOS(theta_deg * e->deg2rad, &sn, &cs);
     R gx = a[0] * e->max_v, gy = a[1] * e->max_v, vth = a[2] * RC(10.0);
@@ -501,8 +528,12 @@ static void SUF(sd_cmds)(const SUF(rsxo_env)* e, const R* a, R theta_deg, R* cmd
     R nrm = R_SQRT(lx * lx + ly * ly);
     if (!(nrm < e->max_v)) { R sc = e->max_v / nrm; lx = lx * sc; ly = ly * sc; }
     cmds[1] = lx; cmds[2] = ly; cmds[3] = vth;
-    cmds[5] = a[3] > RC(0) ? RC(5.0) : RC(0);
-    cmds[7] = a[4] > RC(0) ? RC(1) : RC(0);
+    if (e->task == 3) {
+        cmds[7] = a[3] > RC(0) ? RC(1) : RC(0);
+    } else {
+        cmds[5] = a[3] > RC(0) ? RC(5.0) : RC(0);
+        cmds[7] = a[4] > RC(0) ? RC(1) : RC(0);
+    }
 }
 
 /* ---- reward / done; `last` = pre-step state (the reference's last_frame) ---- */
@@ -531,9 +562,61 @@ static void SUF(task_reward)(SUF(rsxo_env)* e, const R* last, const R* cmds, int
             reward = (t_move + t_grad) + t_en;
             e->info[1] += t_move; e->info[2] += t_grad; e->info[3] += t_en;
         }
-    } else { /* static_defenders.py:150-212,256-322 */
+    } else if (e->task == 3) { /* dribbling.py:137-185; prev_pot holds checkpoints_count */
+        const R* r0 = s + 5;
+        R bx = s[0], by = s[1], lby = last[1], rx = r0[0], ry = r0[1];
+        for (int k = 1; k < e->cfg.n_robots; ++k) { /* an obstacle was hit */
+            const R* ry_ = s + 5 + 11 * k;
+            if (R_FABS(ry_[3]) > RC(0.05) || R_FABS(ry_[4]) > RC(0.05)) done = 1;
+        }
+        if (rx < RC(-3.0) || rx > RC(1.0) || R_FABS(ry) > RC(1.0)) done = 1; /* node_3 - margin, margin */
+        else {
+            int n = (int)e->prev_pot, passed = 0;
+            int down = lby >= RC(0) && by < RC(0), up = lby < RC(0) && by >= RC(0);
+            if (n == 0) passed = bx < RC(-0.5) && bx > RC(-1.0) && down;
+            else if (n == 1) passed = bx < RC(-1.0) && bx > RC(-1.5) && up;
+            else if (n % 2 == 0) {
+                int inside = bx < RC(-1.5) && bx > RC(-2.0);
+                passed = inside && down;
+                if (inside && !down && up) done = 1; /* reversed the last checkpoint */
+            } else passed = bx > RC(-3.0) && bx < RC(-2.0) && up;
+            if (passed) {
+                reward = RC(1);
+                e->prev_pot = RC(n + 1);
+                if (n >= 2 && n % 2 == 0 && n + 1 == 7) done = 1; /* course completed */
+            }
+        }
+        e->info[0] = e->prev_pot;
+    } else if (e->task == 5) { /* pass_endurance.py:132-154,187-233; prev_pot holds stopped_steps */
+        const R* sh = s + 5; const R* rc = s + 5 + 11;
+        R bx = s[0], by = s[1], lbx = last[0], lby = last[1];
+        R ddx = rc[0] - bx, ddy = rc[1] - by, ldx = rc[0] - lbx, ldy = rc[1] - lby;
+        R dist = R_SQRT(ddx * ddx + ddy * ddy), last_dist = R_SQRT(ldx * ldx + ldy * ldy);
+        if (rc[6] != RC(0)) { reward = RC(1); done = 1; }
+        else {
+            R g = e->inv_bg_scale * SUF(clampr)(last_dist - dist, RC(-1), RC(1));
+            reward = g; e->info[1] += g;
+        }
+        /* __wrong_ball: centimetre grid (int truncation), then the stall counter */
+        int cbx = (int)(bx * RC(100)), cby = (int)(by * RC(100));
+        int csx = (int)(sh[0] * RC(100)), csy = (int)(sh[1] * RC(100));
+        int crx = (int)(rc[0] * RC(100)), cry = (int)(rc[1] * RC(100));
+        int in_x = (crx < csx ? crx : csx) <= cbx && cbx <= (crx > csx ? crx : csx);
+        int in_y = (cry < csy ? cry : csy) <= cby && cby <= (cry > csy ? cry : csy);
+        if (R_FABS(last_dist - dist) < RC(0.01)) e->prev_pot = e->prev_pot + RC(1); else e->prev_pot = RC(0);
+        if (e->prev_pot > RC(20) || !(in_x && in_y)) { reward = reward - RC(1); done = 1; }
+        if (done) {
+            R rdx = rc[0] - sh[0], rdy = rc[1] - sh[1];
+            R dist_robs = R_SQRT(rdx * rdx + rdy * rdy);
+            e->info[0] = (dist_robs - dist) / dist_robs;
+        }
+    } else { /* static_defenders.py:150-212,256-322; contested_possession.py:139-201 */
         const R* r0 = s + 5;
         R bx = s[0], by = s[1], rx = r0[0], ry = r0[1];
+        if (e->task == 4) { /* the opponent was moved: collision (contested_possession.py:166-169) */
+            const R* y0 = s + 5 + 11;
+            if (R_FABS(y0[3]) > RC(0.1) || R_FABS(y0[4]) > RC(0.1)) { e->info[8] += RC(1); done = 1; }
+        }
         if (rx < RC(-0.2) || R_FABS(ry) > e->half_wid) { done = 1; e->info[4] += RC(1); }
         else if (rx > e->pen_x && R_FABS(ry) < e->half_pen_wid) { done = 1; e->info[1] += RC(1); }
         else if (bx < RC(0) || R_FABS(by) > e->half_wid) { done = 1; e->info[2] += RC(1); }
@@ -566,6 +649,39 @@ static void SUF(task_place)(SUF(rsxo_env)* e) {
     uint32_t n = 0, u[4];
     R px[MAXBOD], py[MAXBOD]; int np = 0;
     int first = 0;
+    if (e->task == 3) { /* dribbling.py:187-202: fixed course */
+        s[0] = RC(-0.1); s[1] = RC(0);
+        s[5 + 2] = RC(180);
+        for (int k = 1; k < 5; ++k) { R* r = s + 5 + 11 * k; r[0] = RC(-0.5) * RC(k); r[2] = RC(180); }
+        return;
+    }
+    if (e->task == 4) { /* contested_possession.py:203-220: opponent holds the ball */
+        const double* f = c->field;
+        SUF(draw)(e, n++, RSXO_DOM_PLACE, u);
+        R ex = RC(f[2]) + RC((f[0] / 2 - f[2]) - f[2]) * SUF(u01)(u[0]);
+        R ey = RC(-(f[3] / 2)) + RC(f[3]) * SUF(u01)(u[1]);
+        s[0] = ex - RC(0.1); s[1] = ey;
+        R* y0 = s + 5 + 11; y0[0] = ex; y0[1] = ey; y0[2] = RC(180);
+        return;
+    }
+    if (e->task == 5) { /* pass_endurance.py:156-185: shooter behind the ball, receiver mirrored */
+        SUF(draw)(e, n++, RSXO_DOM_PLACE, u);
+        R bx = RC(-1.5) + RC(3.0) * SUF(u01)(u[0]);
+        R by = RC(1.5) + RC(-3.0) * SUF(u01)(u[1]);
+        R side = by < RC(0) ? RC(-1) : RC(1);
+        s[0] = bx; s[1] = by;
+        R* sh = s + 5; R* rc = s + 5 + 11;
+        sh[0] = bx; sh[1] = by + RC(0.115) * side; sh[2] = side > RC(0) ? RC(270) : RC(90);
+        R rx = RC(0);
+        for (int t = 0; t < 64; ++t) {
+            SUF(draw)(e, n++, RSXO_DOM_PLACE, u);
+            rx = RC(-1.5) + RC(3.0) * SUF(u01)(u[0]);
+            if (!(R_FABS(rx - bx) < RC(1))) break;
+        }
+        rc[0] = rx; rc[1] = -by;
+        rc[2] = (R_ATAN2(rc[1] - sh[1], rc[0] - sh[0]) + RC(3.14159265358979323846)) * e->rad2deg;
+        return;
+    }
     if (e->task == 2) { /* blue 0 fixed at the origin */
         for (int t = 0; t < 64; ++t) {
             SUF(draw)(e, n++, RSXO_DOM_PLACE, u);
@@ -604,6 +720,7 @@ static void SUF(task_place)(SUF(rsxo_env)* e) {
 
 static void SUF(task_begin_episode)(SUF(rsxo_env)* e) {
     e->steps = 0;
+    if (e->task >= 3) e->prev_pot = RC(0); /* checkpoints_count / stopped_steps */
     memset(e->ou, 0, sizeof(e->ou));
     SUF(task_obs)(e, e->obs);
 }
@@ -676,7 +793,9 @@ void SUF(rsxo_task_step)(void* p, const float* action) {
         memcpy(e->final_obs, e->obs, sizeof(e->obs));
         e->metrics[1] += 1;
         if (e->task == 1) { e->metrics[2] += e->info[4] > RC(0); e->metrics[3] += e->info[5] > RC(0); }
-        else e->metrics[2] += e->info[0] > RC(0);
+        else if (e->task == 2 || e->task == 4) e->metrics[2] += e->info[0] > RC(0);  /* goal */
+        else if (e->task == 3) e->metrics[2] += e->info[0] >= RC(7);                  /* course completed */
+        else e->metrics[2] += e->terminated && e->state[5 + 11 + 6] != RC(0);         /* pass received */
         e->metrics[4] += (int64_t)llrint((double)(e->ep_ret * RC(1048576.0)));
         e->metrics[5] += e->steps;
         e->metrics[6] += e->truncated && !e->terminated;
@@ -723,7 +842,7 @@ void SUF(rsxo_task_cmds_eval)(void* p, const double* act, double theta_deg, doub
         SUF(vss_cmds)(e, a, q);
         for (int i = 0; i < 2 * N; ++i) out[i] = (double)q[i];
     } else {
-        for (int i = 0; i < 5; ++i) a[i] = RC(act[i]);
+        for (int i = 0; i < e->act_dim; ++i) a[i] = RC(act[i]);
         SUF(sd_cmds)(e, a, RC(theta_deg), q);
         for (int i = 0; i < 8 * N; ++i) out[i] = (double)q[i];
     }
@@ -750,6 +869,9 @@ void SUF(rsxo_ou_eval)(void* p, double* x, const double* nrm, int n) {
         x[i] = (double)xi;
     }
 }
+/* the per-episode task scalar: checkpoints_count (dribbling) / stopped_steps (pass endurance) */
+void SUF(rsxo_task_set_scalar)(void* p, double v) { ((SUF(rsxo_env)*)p)->prev_pot = RC(v); }
+double SUF(rsxo_task_get_scalar)(void* p) { return (double)((SUF(rsxo_env)*)p)->prev_pot; }
 void SUF(rsxo_task_norms)(void* p, double out[3]) {
     SUF(rsxo_env)* e = (SUF(rsxo_env)*)p;
     out[0] = 1.0 / (double)e->inv_max_pos; out[1] = (double)e->max_v; out[2] = 1.0 / (double)e->inv_max_w;

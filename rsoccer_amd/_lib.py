@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("RSX_LIB") or os.path.join(_HERE, "librsx_hip.so")  # 
 
 KIND_VSS, KIND_SSL = 0, 1
 TASK_NONE, TASK_VSS_V0, TASK_SSL_STATIC_DEFENDERS = 0, 1, 2
+TASK_SSL_DRIBBLING, TASK_SSL_CONTESTED, TASK_SSL_PASS_ENDURANCE = 3, 4, 5
 FIELD_KEYS = (
     "length", "width", "penalty_length", "penalty_width", "goal_width", "goal_depth",
     "ball_radius", "rbt_distance_center_kicker", "rbt_kicker_thickness", "rbt_kicker_width",

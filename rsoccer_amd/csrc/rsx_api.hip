@@ -142,9 +142,31 @@ void launch_task_k(const rsx_sim* h, const float* actions, int n_steps, int mode
 
 // mode: MODE_STEP (one step, optional fed actions), MODE_ROLLOUT (n_steps in one launch),
 // MODE_RESET, MODE_REFRESH
+// tasks whose team sizes are fixed by the task: one variant each (8 lanes per env, exact robot count)
+template <int TASK, int NRS, int MODE>
+void launch_fixed_m(const rsx_sim* h, const float* actions, int n_steps, hipStream_t s) {
+    const dim3 grid = grid_for(h);
+    const Buffers b = buffers_of(h, actions);
+    RSX_LAUNCH((task_step_kernel<RSX_KIND_SSL, 8, TASK, NRS, MODE>), h->P, b, n_steps);
+}
+template <int TASK, int NRS>
+void launch_fixed(const rsx_sim* h, const float* actions, int n_steps, int mode, hipStream_t s) {
+    switch (mode) {
+        case MODE_STEP: launch_fixed_m<TASK, NRS, MODE_STEP>(h, actions, 1, s); break;
+        case MODE_ROLLOUT: launch_fixed_m<TASK, NRS, MODE_ROLLOUT>(h, nullptr, n_steps, s); break;
+        case MODE_RESET: launch_fixed_m<TASK, NRS, MODE_RESET>(h, nullptr, 1, s); break;
+        default: launch_fixed_m<TASK, NRS, MODE_REFRESH>(h, nullptr, 1, s); break;
+    }
+}
+
 void launch_task(const rsx_sim* h, const float* actions, int n_steps, int mode, hipStream_t s) {
-    if (h->P.task == RSX_TASK_VSS_V0) launch_task_k<RSX_KIND_VSS, RSX_TASK_VSS_V0, 6>(h, actions, n_steps, mode, s);
-    else launch_task_k<RSX_KIND_SSL, RSX_TASK_SSL_STATIC_DEFENDERS, 7>(h, actions, n_steps, mode, s);
+    switch (h->P.task) {
+        case RSX_TASK_VSS_V0: launch_task_k<RSX_KIND_VSS, RSX_TASK_VSS_V0, 6>(h, actions, n_steps, mode, s); break;
+        case RSX_TASK_SSL_STATIC_DEFENDERS: launch_task_k<RSX_KIND_SSL, RSX_TASK_SSL_STATIC_DEFENDERS, 7>(h, actions, n_steps, mode, s); break;
+        case RSX_TASK_SSL_DRIBBLING: launch_fixed<RSX_TASK_SSL_DRIBBLING, 5>(h, actions, n_steps, mode, s); break;
+        case RSX_TASK_SSL_CONTESTED: launch_fixed<RSX_TASK_SSL_CONTESTED, 2>(h, actions, n_steps, mode, s); break;
+        default: launch_fixed<RSX_TASK_SSL_PASS_ENDURANCE, 2>(h, actions, n_steps, mode, s); break;
+    }
 }
 
 int check(const rsx_sim* h) {
@@ -362,8 +384,10 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
     if (h->P.task != RSX_TASK_NONE) return fail(RSX_ERR_STATE, "a task is already attached");
     Params P = h->P;
     if (derive_task(task, seed, env_id_base, max_episode_steps, h->M, P))
-        return fail(RSX_ERR_ARG, "task does not match the simulator (VSS_V0: kind VSS, n_blue >= 1; STATIC_DEFENDERS: kind SSL, n_blue == 1)");
+        return fail(RSX_ERR_ARG, "task does not match the simulator (VSS_V0: VSS, n_blue >= 1; STATIC_DEFENDERS: SSL 1vN; DRIBBLING: SSL 1v4; CONTESTED: SSL 1v1; PASS_ENDURANCE: SSL 2v0)");
     if (P.obs_dim > 64) return fail(RSX_ERR_ARG, "observation wider than 64 floats is not supported");
+    if (task >= RSX_TASK_SSL_DRIBBLING && h->L != 8)
+        return fail(RSX_ERR_ARG, "this task runs with 8 lanes per env only (unset RSX_LANES_PER_ENV)");
     const size_t B = (size_t)P.num_envs;
     const size_t n_aux = align_up((size_t)aux_rows(P.n_robots) * B * sizeof(float));
     const size_t n_obs = align_up(B * P.obs_dim * sizeof(float));

@@ -40,7 +40,9 @@ namespace rsx {
 
 // rows of the per-env scalar arena `aux` ([rows][B], 4 bytes each)
 constexpr int ROW_REWARD = 0, ROW_PREV_POT = 1, ROW_EP_RET = 2, ROW_STEPS = 3, ROW_EPISODE = 4,
-              ROW_INFO = 5 /* 8 rows */, ROW_OU = 13 /* 2*N rows */;
+              ROW_INFO = 5 /* 10 rows */, ROW_OU = 15 /* 2*N rows */;
+// ROW_PREV_POT is the per-episode task scalar: previous ball potential (VSS-v0), checkpoint
+// counter (dribbling), stalled-step counter (pass endurance)
 __host__ __device__ constexpr int aux_rows(int n_robots) { return ROW_OU + 2 * n_robots; }
 
 struct Buffers {
@@ -526,34 +528,44 @@ __global__ __launch_bounds__(64) void sim_step_kernel(const Params P, const Buff
 // fused task step
 // =============================================================================================
 
-// observation entries owned by this lane -> staging row of its env
-// (vss_gym.py:93-117, static_defenders.py:90-112); values are the WIRE-format state.
+// observation entries owned by this lane -> staging row of its env; values are the WIRE-format
+// state.  Layouts: vss_gym.py:93-117, static_defenders.py:90-112, dribbling.py:76-104,
+// contested_possession.py:78-104, pass_endurance.py:77-91.
 template <int KIND, int TASK>
 __device__ __forceinline__ void write_obs(const Params& P, float* __restrict__ row, int b,
                                           bool is_robot, bool is_ball, float x, float y, float vx,
-                                          float vy, float sn, float cs, float om_deg, int ir) {
+                                          float vy, float sn, float cs, float om_deg, int ir,
+                                          float tscalar) {
     // sn / cs = sin / cos of (theta_deg * deg2rad), i.e. of the wire-format heading
     using T = TC<TASK>;
     const float lo = -1.2f, hi = 1.2f;
+    constexpr int OFF = TASK == RSX_TASK_SSL_DRIBBLING ? 1 : 0;   // dribbling: slot 0 = checkpoint progress
+    constexpr int WB = TASK == RSX_TASK_VSS_V0 ? 7 : (TASK == RSX_TASK_SSL_PASS_ENDURANCE ? 6 : 8);
+    constexpr int WY = TASK == RSX_TASK_VSS_V0 ? 5 : 2;
     if (is_ball) {
-        row[0] = clampf(x * P.inv_max_pos, lo, hi);
-        row[1] = clampf(y * P.inv_max_pos, lo, hi);
-        row[2] = clampf(vx * T::inv_max_v, lo, hi);
-        row[3] = clampf(vy * T::inv_max_v, lo, hi);
+        if (OFF) row[0] = ((tscalar / 6.0f) * 2.0f) - 1.0f;
+        row[OFF + 0] = clampf(x * P.inv_max_pos, lo, hi);
+        row[OFF + 1] = clampf(y * P.inv_max_pos, lo, hi);
+        row[OFF + 2] = clampf(vx * T::inv_max_v, lo, hi);
+        row[OFF + 3] = clampf(vy * T::inv_max_v, lo, hi);
     } else if (is_robot) {
-        constexpr int WB = TASK == RSX_TASK_VSS_V0 ? 7 : 8;
-        constexpr int WY = TASK == RSX_TASK_VSS_V0 ? 5 : 2;
         if (b < P.n_blue) {
-            float* r = row + 4 + WB * b;
+            float* r = row + OFF + 4 + WB * b;
             r[0] = clampf(x * P.inv_max_pos, lo, hi);
             r[1] = clampf(y * P.inv_max_pos, lo, hi);
             r[2] = sn; r[3] = cs;
-            r[4] = clampf(vx * T::inv_max_v, lo, hi);
-            r[5] = clampf(vy * T::inv_max_v, lo, hi);
-            r[6] = clampf(om_deg * T::inv_max_w, lo, hi);
-            if (TASK == RSX_TASK_SSL_STATIC_DEFENDERS) r[7] = ir ? 1.0f : 0.0f;
+            if (TASK == RSX_TASK_SSL_PASS_ENDURANCE) {
+                r[4] = clampf(om_deg * T::inv_max_w, lo, hi);
+                r[5] = ir ? 1.0f : 0.0f;
+            } else {
+                r[4] = clampf(vx * T::inv_max_v, lo, hi);
+                r[5] = clampf(vy * T::inv_max_v, lo, hi);
+                r[6] = clampf(om_deg * T::inv_max_w, lo, hi);
+                if (TASK == RSX_TASK_SSL_DRIBBLING) r[7] = ir ? 1.0f : -1.0f;
+                else if (TASK != RSX_TASK_VSS_V0) r[7] = ir ? 1.0f : 0.0f;
+            }
         } else {
-            float* r = row + 4 + WB * P.n_blue + WY * (b - P.n_blue);
+            float* r = row + OFF + 4 + WB * P.n_blue + WY * (b - P.n_blue);
             r[0] = clampf(x * P.inv_max_pos, lo, hi);
             r[1] = clampf(y * P.inv_max_pos, lo, hi);
             if (TASK == RSX_TASK_VSS_V0) {
@@ -606,6 +618,37 @@ __device__ __forceinline__ void place_env(const Params& P, const int N, uint32_t
     };
     int first = 0;
     float bx, by;
+    if (TASK == RSX_TASK_SSL_DRIBBLING) {  // dribbling.py:187-202: fixed course
+        A[N * G + g] = make_float4(-0.1f, 0.0f, 0.0f, 0.0f);
+        A[0 * G + g] = make_float4(0.0f, 0.0f, 180.0f, 0.0f);
+        for (int k = 1; k < 5; ++k) A[k * G + g] = make_float4(-0.5f * (float)k, 0.0f, 180.0f, 0.0f);
+        return;
+    }
+    if (TASK == RSX_TASK_SSL_CONTESTED) {  // contested_possession.py:203-220: the opponent holds the ball
+        const float2 u = draw();
+        const float ex = P.pl_xlo + P.pl_xspan * u.x, ey = P.pl_ylo + P.pl_yspan * u.y;
+        A[N * G + g] = make_float4(ex - 0.1f, ey, 0.0f, 0.0f);
+        A[0 * G + g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        A[1 * G + g] = make_float4(ex, ey, 180.0f, 0.0f);
+        return;
+    }
+    if (TASK == RSX_TASK_SSL_PASS_ENDURANCE) {  // pass_endurance.py:156-185
+        const float2 u = draw();
+        const float px = -1.5f + 3.0f * u.x, py = 1.5f + -3.0f * u.y;
+        const float side = py < 0.0f ? -1.0f : 1.0f;
+        const float sx = px, sy = py + 0.115f * side;
+        float rx = 0.0f;
+        for (int t = 0; t < 64; ++t) {
+            const float2 v = draw();
+            rx = -1.5f + 3.0f * v.x;
+            if (!(fabsf(rx - px) < 1.0f)) break;
+        }
+        const float ry = -py;
+        A[N * G + g] = make_float4(px, py, 0.0f, 0.0f);
+        A[0 * G + g] = make_float4(sx, sy, side > 0.0f ? 270.0f : 90.0f, 0.0f);
+        A[1 * G + g] = make_float4(rx, ry, (atan2_f32(ry - sy, rx - sx) + 3.14159265358979323846f) * KC<RSX_KIND_SSL>::rad2deg, 0.0f);
+        return;
+    }
     if (TASK == RSX_TASK_SSL_STATIC_DEFENDERS) {
         bx = 0.0f; by = 0.0f;
         for (int t = 0; t < 64; ++t) {
@@ -694,7 +737,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
     if (TASK == RSX_TASK_VSS_V0 && is_robot && b >= 1) {
         ou0 = auxe[(size_t)(ROW_OU + 2 * b) * B]; ou1 = auxe[(size_t)(ROW_OU + 2 * b + 1) * B];
     }
-    float info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float info[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     float prev_pot = 0.0f, ep_ret = 0.0f;
     if (is_ball) {
 #pragma unroll
@@ -702,6 +745,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
         prev_pot = auxe[(size_t)ROW_PREV_POT * B]; ep_ret = auxe[(size_t)ROW_EP_RET * B];
     }
     float reward = 0.0f; int term = 0, trunc = 0;
+    bool success = false;  // goal scored / course completed / pass received (metrics[2])
     bool was_reset = false;
     // caller-fed actions of the agent lane (robot 0); fed launches run a single step
     const bool fed = MODE == MODE_STEP && bufs.actions != nullptr;
@@ -728,13 +772,13 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
                 episode += 1; steps = 0; ou0 = 0.0f; ou1 = 0.0f;
                 if (is_ball) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) info[i] = 0.0f;
+                    for (int i = 0; i < 10; ++i) info[i] = 0.0f;
 #pragma unroll
                     for (int i = 0; i < ID; ++i) auxe[(size_t)(ROW_INFO + i) * B] = 0.0f;
                     ep_ret = 0.0f; prev_pot = 0.0f;
                 }
             }
-            write_obs<KIND, TASK>(P, sh.stage + g * OD, b, is_robot, is_ball, o.x, o.y, o.vx, o.vy, o.s, o.c, wd, o.ir);
+            write_obs<KIND, TASK>(P, sh.stage + g * OD, b, is_robot, is_ball, o.x, o.y, o.vx, o.vy, o.s, o.c, wd, o.ir, prev_pot);
             wave_sync();
             ended = false;
         } else if (mode == 1) {
@@ -743,7 +787,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
             episode += 1;
             if (is_ball) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) info[i] = 0.0f;
+                for (int i = 0; i < 10; ++i) info[i] = 0.0f;
                 ep_ret = 0.0f; prev_pot = 0.0f;
             }
         } else {
@@ -751,7 +795,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
             const uint32_t t = (uint32_t)steps;
             if (is_ball && first_step) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) info[i] = 0.0f;
+                for (int i = 0; i < 10; ++i) info[i] = 0.0f;
                 ep_ret = 0.0f;
             }
             const float lastx = o.x, lasty = o.y;  // the reference's last_frame (pre-step)
@@ -779,29 +823,44 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
                     }
                     q[0] = vss_wheel(a0); q[1] = vss_wheel(a1);
                 }
-            } else {  // static_defenders.py:114-148
+            } else {  // the SSL tasks: only blue 0 is driven by the agent
                 if (is_robot && b == 0) {
-                    float a[5];
+                    float a[5] = {0, 0, 0, 0, 0};
                     if (fed) {
 #pragma unroll
                         for (int i = 0; i < AD; ++i) a[i] = act[i];
                     } else {
                         u32x4 u = philox4x32_10(env_id, episode, t, DOM_ACT, P.key0, P.key1);
                         a[0] = u01(u.x) * 2.0f - 1.0f; a[1] = u01(u.y) * 2.0f - 1.0f;
-                        a[2] = u01(u.z) * 2.0f - 1.0f; a[3] = u01(u.w) * 2.0f - 1.0f;
-                        u32x4 v = philox4x32_10(env_id, episode, t, DOM_ACT | (1u << 8), P.key0, P.key1);
-                        a[4] = u01(v.x) * 2.0f - 1.0f;
+                        a[2] = u01(u.z) * 2.0f - 1.0f;
+                        if (AD > 3) a[3] = u01(u.w) * 2.0f - 1.0f;
+                        if (AD > 4) {
+                            u32x4 v = philox4x32_10(env_id, episode, t, DOM_ACT | (1u << 8), P.key0, P.key1);
+                            a[4] = u01(v.x) * 2.0f - 1.0f;
+                        }
                     }
-                    float sn, cs;
-                    sincos_f32(od * K::deg2rad, sn, cs);
-                    float gx = a[0] * T::max_v, gy = a[1] * T::max_v, vth = a[2] * 10.0f;
-                    float lx = gx * cs + gy * sn, ly = gy * cs - gx * sn;
-                    float nrm = sqrtf(lx * lx + ly * ly);
-                    if (!(nrm < T::max_v)) { float sc = T::max_v / nrm; lx = lx * sc; ly = ly * sc; }
-                    q[1] = lx; q[2] = ly; q[3] = vth;
-                    q[5] = a[3] > 0.0f ? 5.0f : 0.0f;
-                    q[7] = a[4] > 0.0f ? 1.0f : 0.0f;
+                    if (TASK == RSX_TASK_SSL_PASS_ENDURANCE) {  // pass_endurance.py:106-130
+                        float k = fabsf(a[1]) > 0.5f ? a[1] : 0.0f;
+                        q[3] = a[0] * 10.0f;
+                        q[5] = k * 5.0f;
+                        q[7] = a[2] > 0.0f ? 1.0f : 0.0f;
+                    } else {  // static_defenders.py:114-148, dribbling.py:106-135, contested_possession.py:106-137
+                        float sn, cs;
+                        sincos_f32(od * K::deg2rad, sn, cs);
+                        float gx = a[0] * T::max_v, gy = a[1] * T::max_v, vth = a[2] * 10.0f;
+                        float lx = gx * cs + gy * sn, ly = gy * cs - gx * sn;
+                        float nrm = sqrtf(lx * lx + ly * ly);
+                        if (!(nrm < T::max_v)) { float sc = T::max_v / nrm; lx = lx * sc; ly = ly * sc; }
+                        q[1] = lx; q[2] = ly; q[3] = vth;
+                        if (TASK == RSX_TASK_SSL_DRIBBLING) {
+                            q[7] = a[3] > 0.0f ? 1.0f : 0.0f;
+                        } else {
+                            q[5] = a[3] > 0.0f ? 5.0f : 0.0f;
+                            q[7] = a[4] > 0.0f ? 1.0f : 0.0f;
+                        }
+                    }
                 }
+                if (TASK == RSX_TASK_SSL_PASS_ENDURANCE && is_robot && b == 1) q[7] = 1.0f;  // receiver: dribbler on
             }
             if (is_robot) robot_targets<KIND>(P, o, q);
 
@@ -821,15 +880,21 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
             } else if (is_ball) {
                 o.z = (K::r_ball + o.z) - K::r_ball;  // height goes through the wire format too
             }
-            write_obs<KIND, TASK>(P, sh.stage + g * OD, b, is_robot, is_ball, o.x, o.y, o.vx, o.vy, o.s, o.c, wd, o.ir);
+            write_obs<KIND, TASK>(P, sh.stage + g * OD, b, is_robot, is_ball, o.x, o.y, o.vx, o.vy, o.s, o.c, wd, o.ir, prev_pot);
+            // what the reward lane (the ball's) needs from the robots' lanes
             if (is_robot && b == 0) {
                 float* xr = sh.x0[g];
                 xr[0] = o.x; xr[1] = o.y;
                 if (TASK == RSX_TASK_VSS_V0) { xr[2] = o.vx; xr[3] = o.vy; xr[4] = q[0]; xr[5] = q[1]; }
-                else {
+                else if (TASK == RSX_TASK_SSL_STATIC_DEFENDERS || TASK == RSX_TASK_SSL_CONTESTED) {
                     xr[6] = lastx; xr[7] = lasty;
                     xr[8] = wheels[0]; xr[9] = wheels[1]; xr[10] = wheels[2]; xr[11] = wheels[3];
                 }
+            } else if (is_robot) {
+                float* xr = sh.x0[g];
+                if (TASK == RSX_TASK_SSL_DRIBBLING) xr[1 + b] = (fabsf(o.vx) > 0.05f || fabsf(o.vy) > 0.05f) ? 1.0f : 0.0f;
+                if (TASK == RSX_TASK_SSL_CONTESTED && b == 1) xr[2] = (fabsf(o.vx) > 0.1f || fabsf(o.vy) > 0.1f) ? 1.0f : 0.0f;
+                if (TASK == RSX_TASK_SSL_PASS_ENDURANCE && b == 1) { xr[2] = o.x; xr[3] = o.y; xr[4] = o.ir ? 1.0f : 0.0f; }
             }
             wave_sync();
             if (is_ball) {
@@ -856,8 +921,56 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
                         reward = (t_move + t_grad) + t_en;
                         info[1] += t_move; info[2] += t_grad; info[3] += t_en;
                     }
-                } else {  // static_defenders.py:150-212,256-322
+                } else if (TASK == RSX_TASK_SSL_DRIBBLING) {  // dribbling.py:137-185; prev_pot = checkpoints_count
                     const float rx = xr[0], ry = xr[1];
+                    if (xr[2] != 0.0f || xr[3] != 0.0f || xr[4] != 0.0f || xr[5] != 0.0f) term = 1;  // an obstacle was hit
+                    if (rx < -3.0f || rx > 1.0f || fabsf(ry) > 1.0f) term = 1;                         // left the course
+                    else {
+                        const int n = (int)prev_pot;
+                        const bool down = lasty >= 0.0f && by < 0.0f, up = lasty < 0.0f && by >= 0.0f;
+                        bool passed;
+                        if (n == 0) passed = bx < -0.5f && bx > -1.0f && down;
+                        else if (n == 1) passed = bx < -1.0f && bx > -1.5f && up;
+                        else if (n % 2 == 0) {
+                            const bool inside = bx < -1.5f && bx > -2.0f;
+                            passed = inside && down;
+                            if (inside && !down && up) term = 1;   // reversed the last checkpoint
+                        } else passed = bx > -3.0f && bx < -2.0f && up;
+                        if (passed) {
+                            reward = 1.0f;
+                            prev_pot = (float)(n + 1);
+                            if (n >= 2 && n % 2 == 0 && n + 1 == 7) term = 1;   // course completed
+                        }
+                    }
+                    info[0] = prev_pot;
+                    success = prev_pot >= 7.0f;
+                } else if (TASK == RSX_TASK_SSL_PASS_ENDURANCE) {  // pass_endurance.py:132-154,187-233; prev_pot = stopped_steps
+                    const float shx = xr[0], shy = xr[1], rcx = xr[2], rcy = xr[3];
+                    const bool rc_ir = xr[4] != 0.0f;
+                    float ddx = rcx - bx, ddy = rcy - by, ldx = rcx - lastx, ldy = rcy - lasty;
+                    float dist = sqrtf(ddx * ddx + ddy * ddy), last_dist = sqrtf(ldx * ldx + ldy * ldy);
+                    if (rc_ir) { reward = 1.0f; term = 1; }
+                    else {
+                        float gr = P.inv_bg_scale * clampf(last_dist - dist, -1.0f, 1.0f);
+                        reward = gr; info[1] += gr;
+                    }
+                    // "wrong ball": outside the shooter-receiver box on a centimetre grid, or stalled
+                    const int cbx = (int)(bx * 100.0f), cby = (int)(by * 100.0f);
+                    const int csx = (int)(shx * 100.0f), csy = (int)(shy * 100.0f);
+                    const int crx = (int)(rcx * 100.0f), cry = (int)(rcy * 100.0f);
+                    const bool in_x = min(crx, csx) <= cbx && cbx <= max(crx, csx);
+                    const bool in_y = min(cry, csy) <= cby && cby <= max(cry, csy);
+                    if (fabsf(last_dist - dist) < 0.01f) prev_pot = prev_pot + 1.0f; else prev_pot = 0.0f;
+                    if (prev_pot > 20.0f || !(in_x && in_y)) { reward = reward - 1.0f; term = 1; }
+                    if (term) {
+                        float rdx = rcx - shx, rdy = rcy - shy;
+                        float dist_robs = sqrtf(rdx * rdx + rdy * rdy);
+                        info[0] = (dist_robs - dist) / dist_robs;
+                    }
+                    success = term && rc_ir;
+                } else {  // static_defenders.py:150-212,256-322; contested_possession.py:139-201
+                    const float rx = xr[0], ry = xr[1];
+                    if (TASK == RSX_TASK_SSL_CONTESTED && xr[2] != 0.0f) { info[8] += 1.0f; term = 1; }  // opponent moved
                     if (rx < -0.2f || fabsf(ry) > P.half_wid) { term = 1; info[4] += 1.0f; }
                     else if (rx > P.pen_x && fabsf(ry) < P.half_pen_wid) { term = 1; info[1] += 1.0f; }
                     else if (bx < 0.0f || fabsf(by) > P.half_wid) { term = 1; info[2] += 1.0f; }
@@ -871,10 +984,11 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
                         float bd = clampf(sqrtf(ldx * ldx + ldy * ldy) - sqrtf(cdx * cdx + cdy * cdy), -1.0f, 1.0f) * P.inv_bd_scale;
                         float lgx = P.half_len - lastx, cgx = P.half_len - bx;
                         float bg = clampf(sqrtf(lgx * lgx + lasty * lasty) - sqrtf(cgx * cgx + by * by), -1.0f, 1.0f) * P.inv_bg_scale;
-                        float en = -(((fabsf(xr[8]) + fabsf(xr[9])) + fabsf(xr[10])) + fabsf(xr[11])) * TC<RSX_TASK_SSL_STATIC_DEFENDERS>::inv_en_scale;
+                        float en = -(((fabsf(xr[8]) + fabsf(xr[9])) + fabsf(xr[10])) + fabsf(xr[11])) * T::inv_en_scale;
                         info[5] += bd; info[6] += bg; info[7] += en;
                         reward = (bd + bg) + en;
                     }
+                    success = info[0] > 0.0f;
                 }
                 ep_ret = ep_ret + reward;
             }
@@ -905,7 +1019,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
                 if (TASK == RSX_TASK_VSS_V0) {
                     if (info[4] > 0.0f) atomicAdd(&bufs.metrics[2], 1ull);
                     if (info[5] > 0.0f) atomicAdd(&bufs.metrics[3], 1ull);
-                } else if (info[0] > 0.0f) atomicAdd(&bufs.metrics[2], 1ull);
+                } else if (success) atomicAdd(&bufs.metrics[2], 1ull);
                 atomicAdd(&bufs.metrics[4], (unsigned long long)__float2ll_rn(ep_ret * 1048576.0f));
                 atomicAdd(&bufs.metrics[5], (unsigned long long)steps);
                 if (trunc && !term) atomicAdd(&bufs.metrics[6], 1ull);
@@ -916,6 +1030,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
             wave_sync();
             if (ended) {
                 steps = 0; ou0 = 0.0f; ou1 = 0.0f; was_reset = true;
+                if (TASK >= RSX_TASK_SSL_DRIBBLING) prev_pot = 0.0f;  // checkpoints_count / stopped_steps
                 if (is_robot || is_ball) {
                     const float4 pz = sh.A[b * G + g];
                     o = Body{};
@@ -924,7 +1039,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
                     wheels[0] = wheels[1] = wheels[2] = wheels[3] = 0.0f;
                     if (is_robot) { o.th = od; sincos_f32(o.th * K::deg2rad, o.s, o.c); }
                 }
-                write_obs<KIND, TASK>(P, sh.stage + g * OD, b, is_robot, is_ball, o.x, o.y, o.vx, o.vy, o.s, o.c, wd, 0);
+                write_obs<KIND, TASK>(P, sh.stage + g * OD, b, is_robot, is_ball, o.x, o.y, o.vx, o.vy, o.s, o.c, wd, 0, 0.0f);
             }
             wave_sync();
         }

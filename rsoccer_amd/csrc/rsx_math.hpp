@@ -69,6 +69,24 @@ __device__ __forceinline__ float log_f32(float x) {
     return r;
 }
 
+// atan2 (Cephes atanf), fixed operation order — only the PassEndurance placement needs it
+__device__ __forceinline__ float atan_f32(float x) {
+    const float sgn = x < 0.0f ? -1.0f : 1.0f;
+    x = fabsf(x);
+    float y;
+    if (x > 2.414213562373095f) { y = 1.5707963267948966f; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y = 0.7853981633974483f; x = (x - 1.0f) / (x + 1.0f); }
+    else y = 0.0f;
+    const float z = x * x;
+    y = y + ((((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x);
+    return sgn * y;
+}
+__device__ __forceinline__ float atan2_f32(float y, float x) {
+    if (x > 0.0f) return atan_f32(y / x);
+    if (x < 0.0f) return atan_f32(y / x) + (y >= 0.0f ? 3.14159265358979f : -3.14159265358979f);
+    return y > 0.0f ? 1.5707963267948966f : (y < 0.0f ? -1.5707963267948966f : 0.0f);
+}
+
 // Philox4x32-10 (Salmon, Moraes, Dror, Shaw — SC'11).  counter = (global env id, episode,
 // tick, domain), key = (seed lo, seed hi): a draw depends only on WHAT it is for, never on the
 // thread that computes it, so results are invariant to batch size, batch position and sharding.

@@ -97,14 +97,35 @@ template <> struct TC<RSX_TASK_VSS_V0> {  // normalisers: vss_gym_base.py:52-58
     static constexpr float max_v = (float)max_v_d, inv_max_v = (float)(1.0 / max_v_d);
     static constexpr float inv_max_w = (float)(1.0 / max_w_d);
     static constexpr float deadzone = 0.05f;                         // vss_gym.py:73
+    static constexpr float inv_en_scale = 0.0f;                      // (SSL tasks only)
     static constexpr int info_dim = 6, act_dim = 2, max_steps = 1200; // rsoccer_gym/__init__.py:4
 };
-template <> struct TC<RSX_TASK_SSL_STATIC_DEFENDERS> {  // static_defenders.py:76-77
+// the four SSL hardware-challenge tasks share the speed caps 2.5 m/s / 10 rad/s
+// (static_defenders.py:76-77, dribbling.py:66-67, contested_possession.py:65-66, pass_endurance.py:72-73)
+struct TCSslBase {
     static constexpr double max_v_d = 2.5, max_w_d = 10.0;
     static constexpr float max_v = 2.5f, inv_max_v = (float)(1.0 / 2.5), inv_max_w = (float)(1.0 / 10.0);
-    static constexpr float inv_en_scale = (float)(1.0 / (160.0 * 4.0 * 1000.0));  // :71-73
     static constexpr float deadzone = 0.0f;
+};
+template <> struct TC<RSX_TASK_SSL_STATIC_DEFENDERS> : TCSslBase {
+    static constexpr float inv_en_scale = (float)(1.0 / (160.0 * 4.0 * 1000.0));  // static_defenders.py:71-73
     static constexpr int info_dim = 8, act_dim = 5, max_steps = 1000;  // rsoccer_gym/__init__.py:11
+    static constexpr int n_blue = 1, n_yellow = -1;                    // -1: any
+};
+template <> struct TC<RSX_TASK_SSL_DRIBBLING> : TCSslBase {
+    static constexpr float inv_en_scale = 0.0f;
+    static constexpr int info_dim = 1, act_dim = 4, max_steps = 4800;  // rsoccer_gym/__init__.py:17
+    static constexpr int n_blue = 1, n_yellow = 4;                     // dribbling.py:47-48
+};
+template <> struct TC<RSX_TASK_SSL_CONTESTED> : TCSslBase {
+    static constexpr float inv_en_scale = (float)(1.0 / (160.0 * 4.0 * 1200.0));  // contested_possession.py:60-62
+    static constexpr int info_dim = 9, act_dim = 5, max_steps = 1200;  // rsoccer_gym/__init__.py:23
+    static constexpr int n_blue = 1, n_yellow = 1;                     // contested_possession.py:43-44
+};
+template <> struct TC<RSX_TASK_SSL_PASS_ENDURANCE> : TCSslBase {
+    static constexpr float inv_en_scale = 0.0f;
+    static constexpr int info_dim = 2, act_dim = 3, max_steps = 1200;  // rsoccer_gym/__init__.py:29
+    static constexpr int n_blue = 2, n_yellow = 0;                     // pass_endurance.py:48-49
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -228,6 +249,24 @@ inline int derive_task(int task, uint64_t seed, uint64_t env_id_base, int max_st
         P.obs_dim = 4 + 8 * P.n_blue + 2 * P.n_yellow;   // static_defenders.py:54-56
         M.act_dim = T::act_dim; M.info_dim = T::info_dim;
         P.max_steps = max_steps > 0 ? max_steps : T::max_steps;
+    } else if (task == RSX_TASK_SSL_DRIBBLING) {
+        using T = TC<RSX_TASK_SSL_DRIBBLING>;
+        if (P.kind != RSX_KIND_SSL || P.n_blue != T::n_blue || P.n_yellow != T::n_yellow) return -1;
+        P.obs_dim = 5 + 8 * P.n_blue + 2 * P.n_yellow;   // dribbling.py:52
+        M.act_dim = T::act_dim; M.info_dim = T::info_dim;
+        P.max_steps = max_steps > 0 ? max_steps : T::max_steps;
+    } else if (task == RSX_TASK_SSL_CONTESTED) {
+        using T = TC<RSX_TASK_SSL_CONTESTED>;
+        if (P.kind != RSX_KIND_SSL || P.n_blue != T::n_blue || P.n_yellow != T::n_yellow) return -1;
+        P.obs_dim = 4 + 8 * P.n_blue + 2 * P.n_yellow;   // contested_possession.py:48
+        M.act_dim = T::act_dim; M.info_dim = T::info_dim;
+        P.max_steps = max_steps > 0 ? max_steps : T::max_steps;
+    } else if (task == RSX_TASK_SSL_PASS_ENDURANCE) {
+        using T = TC<RSX_TASK_SSL_PASS_ENDURANCE>;
+        if (P.kind != RSX_KIND_SSL || P.n_blue != T::n_blue || P.n_yellow != T::n_yellow) return -1;
+        P.obs_dim = 4 + 6 * P.n_blue;                    // pass_endurance.py:55
+        M.act_dim = T::act_dim; M.info_dim = T::info_dim;
+        P.max_steps = max_steps > 0 ? max_steps : T::max_steps;
     } else {
         return -1;
     }
@@ -243,11 +282,15 @@ inline int derive_task(int task, uint64_t seed, uint64_t env_id_base, int max_st
     if (task == RSX_TASK_VSS_V0) {          // vss_gym.py:199-206,211
         P.pl_xlo = (float)(-(f[0] / 2) + 0.1); P.pl_xspan = (float)((f[0] / 2 - 0.1) - (-(f[0] / 2) + 0.1));
         P.pl_min_d2 = (float)(0.1 * 0.1);
+    } else if (task == RSX_TASK_SSL_CONTESTED) {   // contested_possession.py:210-211: the opponent's spot
+        P.pl_xlo = (float)f[2]; P.pl_xspan = (float)((f[0] / 2 - f[2]) - f[2]);
+        P.pl_min_d2 = 0.0f;
     } else {                                // static_defenders.py:221-225,239
         P.pl_xlo = 0.2f; P.pl_xspan = (float)((f[0] / 2 - 0.1) - 0.2);
         P.pl_min_d2 = (float)(0.2 * 0.2);
     }
     P.pl_ylo = (float)(-(f[1] / 2) + 0.1); P.pl_yspan = (float)((f[1] / 2 - 0.1) - (-(f[1] / 2) + 0.1));
+    if (task == RSX_TASK_SSL_CONTESTED) { P.pl_ylo = (float)(-(f[3] / 2)); P.pl_yspan = (float)f[3]; }
     P.ou_theta_dt = (float)(0.17 * M.dt);            // Utils/Utils.py:6,17
     P.ou_sig_sqdt = (float)(0.5 * std::sqrt(M.dt));  // Utils/Utils.py:8,18
     return 0;

@@ -1,7 +1,8 @@
 """Batched environments: thousands of independent copies of a task on one GPU.
 
-* :class:`VecVSSEnv`, :class:`VecSSLStaticDefendersEnv` — the reference tasks VSS-v0 and
-  SSLStaticDefenders-v0 with everything the reference does per step in Python (action ->
+* :class:`VecVSSEnv`, :class:`VecSSLStaticDefendersEnv`, :class:`VecSSLDribblingEnv`,
+  :class:`VecSSLContestedPossessionEnv`, :class:`VecSSLPassEnduranceEnv` — the five registered
+  reference tasks with everything the reference does per step in Python (action ->
   commands, OU noise, physics, observation, reward, done, TimeLimit, reset placement) fused
   into one kernel launch per ``step()``.  Observations / rewards / flags are device tensors.
 * :class:`VecVSSBaseEnv`, :class:`VecSSLBaseEnv` — the batched form of the subclass contract
@@ -9,8 +10,9 @@
   ``_get_initial_positions``): hooks receive a :class:`VecFrame` whose fields are ``[B]``
   tensors viewing the simulator's SoA state, and run as torch ops on the device.
 """
-from rsoccer_amd.vec.fused import VecFusedEnv, VecSSLStaticDefendersEnv, VecVSSEnv
+from rsoccer_amd.vec.fused import (VecFusedEnv, VecSSLContestedPossessionEnv, VecSSLDribblingEnv,
+                                   VecSSLPassEnduranceEnv, VecSSLStaticDefendersEnv, VecVSSEnv)
 from rsoccer_amd.vec.hooks import VecFrame, VecSSLBaseEnv, VecVSSBaseEnv
 
-__all__ = ["VecFusedEnv", "VecVSSEnv", "VecSSLStaticDefendersEnv", "VecFrame", "VecVSSBaseEnv",
-           "VecSSLBaseEnv"]
+__all__ = ["VecFusedEnv", "VecVSSEnv", "VecSSLStaticDefendersEnv", "VecSSLDribblingEnv",
+           "VecSSLContestedPossessionEnv", "VecSSLPassEnduranceEnv", "VecFrame", "VecVSSBaseEnv", "VecSSLBaseEnv"]

@@ -115,6 +115,9 @@ class VecFusedEnv:
         self.sim.close()
 
 
+_CONT_INFO = _SD_INFO + ("collision",)
+
+
 class VecVSSEnv(VecFusedEnv):
     """VSS-v0 (rsoccer_gym/vss/env_vss/vss_gym.py:13): obs 40, action 2, TimeLimit 1200."""
     KIND, TASK, FIELD_TYPE, N_BLUE, N_YELLOW = _lib.KIND_VSS, _lib.TASK_VSS_V0, 0, 3, 3
@@ -126,3 +129,24 @@ class VecSSLStaticDefendersEnv(VecFusedEnv):
     TimeLimit 1000, hardware-challenge field (field_type 2)."""
     KIND, TASK, FIELD_TYPE, N_BLUE, N_YELLOW = _lib.KIND_SSL, _lib.TASK_SSL_STATIC_DEFENDERS, 2, 1, 6
     INFO_KEYS = _SD_INFO
+
+
+class VecSSLDribblingEnv(VecFusedEnv):
+    """SSLDribbling-v0 (ssl/ssl_hw_challenge/dribbling.py:11): obs 21, action 4, TimeLimit 4800.
+    info: the checkpoint counter (the reference task returns an empty info dict)."""
+    KIND, TASK, FIELD_TYPE, N_BLUE, N_YELLOW = _lib.KIND_SSL, _lib.TASK_SSL_DRIBBLING, 2, 1, 4
+    INFO_KEYS = ("checkpoints",)
+
+
+class VecSSLContestedPossessionEnv(VecFusedEnv):
+    """SSLContestedPossession-v0 (ssl/ssl_hw_challenge/contested_possession.py:11): obs 14,
+    action 5, TimeLimit 1200."""
+    KIND, TASK, FIELD_TYPE, N_BLUE, N_YELLOW = _lib.KIND_SSL, _lib.TASK_SSL_CONTESTED, 2, 1, 1
+    INFO_KEYS = _CONT_INFO
+
+
+class VecSSLPassEnduranceEnv(VecFusedEnv):
+    """SSLPassEndurance-v0 (ssl/ssl_hw_challenge/pass_endurance.py:11): obs 16, action 3,
+    TimeLimit 1200."""
+    KIND, TASK, FIELD_TYPE, N_BLUE, N_YELLOW = _lib.KIND_SSL, _lib.TASK_SSL_PASS_ENDURANCE, 2, 2, 0
+    INFO_KEYS = ("reversed_dist", "ball_grad")

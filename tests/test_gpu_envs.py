@@ -94,8 +94,9 @@ def test_fused_observation_matches_reference_arithmetic():
 
 def test_vec_env_api_and_determinism():
     import torch
-    from rsoccer_amd.vec import VecSSLStaticDefendersEnv, VecVSSEnv
-    for cls, od, ad in ((VecVSSEnv, 40, 2), (VecSSLStaticDefendersEnv, 24, 5)):
+    from rsoccer_amd import vec
+    for cls, od, ad in ((vec.VecVSSEnv, 40, 2), (vec.VecSSLStaticDefendersEnv, 24, 5), (vec.VecSSLDribblingEnv, 21, 4),
+                        (vec.VecSSLContestedPossessionEnv, 14, 5), (vec.VecSSLPassEnduranceEnv, 16, 3)):
         a = cls(256, seed=3)
         b = cls(256, seed=3)
         c = cls(256, seed=4)

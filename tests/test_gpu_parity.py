@@ -113,8 +113,11 @@ def _cmp_task(sim, refs, tens, t, check_state=True):
 
 TASKS = [
     # task, kind, ft, nb, ny, B, steps, max_episode_steps
-    (1, 0, 0, 3, 3, 45, 260, 100),
-    (2, 1, 2, 1, 6, 37, 200, 60),
+    (1, 0, 0, 3, 3, 45, 260, 100),     # VSS-v0
+    (2, 1, 2, 1, 6, 37, 200, 60),      # SSLStaticDefenders-v0
+    (3, 1, 2, 1, 4, 29, 220, 70),      # SSLDribbling-v0
+    (4, 1, 2, 1, 1, 53, 220, 50),      # SSLContestedPossession-v0
+    (5, 1, 2, 2, 0, 21, 220, 40),      # SSLPassEndurance-v0
 ]
 
 

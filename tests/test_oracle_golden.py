@@ -178,3 +178,85 @@ def test_device_style_placement_obeys_the_reference_rules(oracle_mod, task, kind
                 assert 0.2 - 1e-6 <= p[0] <= L / 2 - 0.1 + 1e-6 and abs(p[1]) <= W / 2 - 0.1 + 1e-6
             assert not (pts[0][0] > L / 2 - pen_l and abs(pts[0][1]) < pen_w / 2)
         assert np.all(s[3:5] == 0)
+
+
+# ---------------------------------------------------------------------------------------------
+# SSLDribbling-v0 (task 3), SSLContestedPossession-v0 (task 4), SSLPassEndurance-v0 (task 5)
+# ---------------------------------------------------------------------------------------------
+OTHER = {"drib": (3, (1, 2, 1, 4)), "cont": (4, (1, 2, 1, 1)), "pass": (5, (1, 2, 2, 0))}
+
+
+def _other_env(O, tag, prec):
+    task, kind = OTHER[tag]
+    e = O.OracleEnv(*kind, 25, prec)
+    e.task_attach(task, 0, 0, 0)
+    return e
+
+
+@pytest.mark.parametrize("prec,otol,stol", PRECS)
+@pytest.mark.parametrize("tag", sorted(OTHER))
+def test_other_tasks_observations(oracle_mod, prec, otol, stol, tag):
+    e = _other_env(oracle_mod, tag, prec)
+    assert np.allclose(e.norms(), G[f"{tag}_norms"], rtol=1e-6)
+    for i, (s, want) in enumerate(zip(G[f"{tag}_obs_states"], G[f"{tag}_obs"])):
+        e.set_state_full(np.append(s, 0.0))
+        if tag == "drib":
+            e.set_scalar(i % 7)
+        got = e.obs_eval()
+        assert got.shape == want.shape and np.max(np.abs(got - want)) <= otol, (tag, i)
+
+
+@pytest.mark.parametrize("prec,otol,stol", PRECS)
+@pytest.mark.parametrize("tag", sorted(OTHER))
+def test_other_tasks_episodes(oracle_mod, prec, otol, stol, tag):
+    """commands, observations, rewards, dones (and info) of the recorded reference episodes"""
+    n_ep = int(G[f"{tag}_n_episodes"])
+    dones = 0
+    for ep in range(n_ep):
+        e = _other_env(oracle_mod, tag, prec)
+        R = {k: G[f"{tag}_ep{ep}_{k}"] for k in ("reset_state", "obs0", "actions", "cmds", "states", "obs", "reward", "done", "info")}
+        e.set_state_full(np.append(R["reset_state"], 0.0))
+        e.set_scalar(0)
+        assert np.max(np.abs(e.obs_eval() - R["obs0"])) <= otol
+        last = R["reset_state"]
+        for t in range(len(R["reward"])):
+            cm = e.cmds_eval(R["actions"][t], last[7])
+            assert np.allclose(cm, R["cmds"][t], rtol=0, atol=3e-6), (tag, ep, t, cm, R["cmds"][t])
+            e.set_state_full(np.append(R["states"][t], 0.0))
+            assert np.max(np.abs(e.obs_eval() - R["obs"][t])) <= otol, (tag, ep, t)
+            r, d = e.reward_eval(last, R["cmds"][t], t == 0)
+            assert d == bool(R["done"][t]), (tag, ep, t)
+            assert abs(r - R["reward"][t]) <= (5e-5 if prec == "f32" else 1e-7), (tag, ep, t, r, R["reward"][t])
+            if tag != "drib":
+                info = e.task_out()["info"]
+                assert np.allclose(info, R["info"][t], rtol=0, atol=3e-4 if prec == "f32" else 1e-6), (tag, ep, t, info, R["info"][t])
+            last = R["states"][t]
+        dones += int(R["done"][-1])
+    assert dones >= n_ep - 2
+
+
+@pytest.mark.parametrize("tag", sorted(OTHER))
+def test_other_tasks_device_style_placement(oracle_mod, tag):
+    task, kind = OTHER[tag]
+    f = oracle_mod.OracleEnv(*kind).field_params()
+    for env_id in range(100):
+        e = oracle_mod.OracleEnv(*kind, 25, "f32")
+        e.task_attach(task, 9, env_id, 0)
+        e.task_reset()
+        s = e.get_state()
+        if tag == "drib":    # dribbling.py:187-202
+            assert np.allclose(s[:2], [-0.1, 0]) and np.allclose(s[5:8], [0, 0, 180])
+            assert [s[5 + 11 * k] for k in range(1, 5)] == [-0.5, -1.0, -1.5, -2.0]
+        elif tag == "cont":  # contested_possession.py:203-220
+            ex, ey = s[16], s[17]
+            assert f[2] - 1e-6 <= ex <= f[0] / 2 - f[2] + 1e-6 and abs(ey) <= f[3] / 2 + 1e-6
+            assert np.allclose(s[:2], [ex - 0.1, ey], atol=1e-6) and s[18] == 180 and np.all(s[5:8] == 0)
+        else:                # pass_endurance.py:156-185
+            bx, by = s[0], s[1]
+            side = -1.0 if by < 0 else 1.0
+            assert abs(bx) <= 1.5 + 1e-6 and abs(by) <= 1.5 + 1e-6
+            assert np.allclose(s[5:8], [bx, by + 0.115 * side, 270 if side > 0 else 90], atol=1e-6)
+            rx, ry, rth = s[16], s[17], s[18]
+            assert abs(rx - bx) >= 1 - 1e-6 and abs(ry + by) < 1e-6
+            want = np.rad2deg(np.arctan2(ry - s[6], rx - s[5]) + np.pi)
+            assert abs(rth - want) < 2e-3
