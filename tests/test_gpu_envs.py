@@ -102,7 +102,9 @@ def test_vec_env_api_and_determinism():
         c = cls(256, seed=4)
         oa, _ = a.reset(); ob, _ = b.reset(); oc, _ = c.reset()
         assert oa.shape == (256, od) and oa.dtype == torch.float32 and oa.is_cuda
-        assert torch.equal(oa, ob) and not torch.equal(oa, oc)
+        assert torch.equal(oa, ob)
+        if cls is not vec.VecSSLDribblingEnv:       # the dribbling course is a fixed placement
+            assert not torch.equal(oa, oc)
         gen = torch.Generator(device="cuda").manual_seed(0)
         ret = torch.zeros(256, device="cuda")
         for t in range(50):

@@ -63,6 +63,9 @@ def raw_ssl(name, ft, nb, ny, B, crowded, bytes_per_step, K=1000):
 
 fused("configs[1] VSS-v0 3v3 fused", 0, 0, 3, 3, 1, 4096, 541)
 fused("configs[2] SSLStaticDefenders-v0 1v6 fused", 1, 2, 1, 6, 2, 2048, 981)
+fused("SSLDribbling-v0 1v4 fused", 1, 2, 1, 4, 3, 2048, 2 * 4 * 60 + 4 * 40 + 4 * 21 + 5)
+fused("SSLContestedPossession-v0 1v1 fused", 1, 2, 1, 1, 4, 2048, 2 * 4 * 27 + 4 * 16 + 4 * 14 + 5)
+fused("SSLPassEndurance-v0 2v0 fused", 1, 2, 2, 0, 5, 2048, 2 * 4 * 27 + 4 * 16 + 4 * 16 + 5)
 raw_ssl("configs[3] SSL 11v11 raw sim, spread", 1, 11, 11, 1024, False, 2680)
 raw_ssl("configs[3] SSL 11v11 raw sim, crowded (worst-case contacts)", 1, 11, 11, 1024, True, 2680)
 for B in (256, 1024, 16384, 65536, 262144, 1048576, 4194304):
