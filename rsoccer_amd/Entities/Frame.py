@@ -7,15 +7,14 @@ Units: seconds, m, m/s, degrees, degrees/s; origin at the field centre.
 """
 from typing import Dict
 
-from .Ball import Ball
-from .Robot import Robot
+from rsoccer_amd.Entities.records import Ball, Robot
 
 _VSS_BLOCK = ("x", "y", "theta", "v_x", "v_y", "v_theta")
 _SSL_BLOCK = _VSS_BLOCK + ("infrared", "v_wheel0", "v_wheel1", "v_wheel2", "v_wheel3")
 
 
 class Frame:
-    """Units: seconds, m, m/s, degrees, degrees/s. Reference is field center."""
+    """One world snapshot; s, m, m/s, degrees, degrees/s; origin = field centre."""
 
     _block = ()
 

@@ -1,3 +1,4 @@
-from rsoccer_amd.vss.env_vss.vss_gym import VSSEnv
+"""VSS-v0 task."""
+from .vss_gym import VSSEnv
 
 __all__ = ["VSSEnv"]

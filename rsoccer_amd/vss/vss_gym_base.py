@@ -83,19 +83,19 @@ class VSSBaseEnv(gym.Env):
 
     # ---- hooks a task implements ----
     def _get_commands(self, action):
-        """returns a list of commands of type List[Robot] from type action_space action"""
+        """action (as drawn from action_space) -> the List[Robot] commands of this step"""
         raise NotImplementedError
 
     def _frame_to_observations(self):
-        """returns a type observation_space observation from a type List[Robot] state"""
+        """self.frame -> observation vector of observation_space"""
         raise NotImplementedError
 
     def _calculate_reward_and_done(self):
-        """returns reward value and done flag from type List[Robot] state"""
+        """self.frame (and self.last_frame) -> (reward, done)"""
         raise NotImplementedError
 
     def _get_initial_positions_frame(self) -> Frame:
-        """returns frame with robots initial positions"""
+        """the Frame holding the start poses of an episode (reset)"""
         raise NotImplementedError
 
     # ---- normalisation helpers ----
