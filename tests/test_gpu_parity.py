@@ -258,3 +258,77 @@ def test_reset_to_matches_oracle(oracle_mod):
             r.task_step(None)
     _cmp_task(sim, refs, tens, "after reset_to")
     sim.close()
+
+
+def test_vss_v0_on_the_5v5_field_uses_16_lane_groups(oracle_mod):
+    """VSS-v0 arithmetic on field_type 1 (5v5: 11 bodies -> 16 lanes per env, generic kernel)."""
+    L = _lib()
+    O = oracle_mod
+    B, seed = 19, 21
+    sim = L.Sim(0, 1, 5, 5, 25, B)
+    sim.task_attach(1, seed, 0, 45)
+    assert sim.obs_dim == 64
+    tens = sim.task_tensors()
+    refs = _mk_oracles(O, 0, 1, 5, 5, B)
+    for e, r in enumerate(refs):
+        r.task_attach(1, seed, e, 45)
+        r.task_reset()
+    sim.task_reset()
+    for t in range(120):
+        sim.task_step(None)
+        for r in refs:
+            r.task_step(None)
+    _cmp_task(sim, refs, tens, "5v5")
+    sim.close()
+
+
+def test_one_wavefront_per_env_layout_gives_identical_results():
+    """RSX_LANES_PER_ENV=64 selects the 'one wavefront per env' mapping of BASELINE.json's north
+    star; results must not depend on the mapping (run in a subprocess: the variable is read at
+    handle creation)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from rsoccer_amd import _lib as L\n"
+        "out = []\n"
+        "for task, kind, ft, nb, ny in ((1, 0, 0, 3, 3), (2, 1, 2, 1, 6)):\n"
+        "    s = L.Sim(kind, ft, nb, ny, 25, 37); s.task_attach(task, 5, 0, 30); s.task_reset(); s.task_step_n(100)\n"
+        "    torch.cuda.synchronize(); out.append(s.get_state_full()); out.append(s.task_tensors()['obs'].cpu().numpy().astype(np.float64))\n"
+        "np.save(sys.argv[1], np.concatenate([o.ravel() for o in out]))\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    res = []
+    for lanes in (None, "64"):
+        env = dict(os.environ)
+        env.pop("RSX_LANES_PER_ENV", None)
+        if lanes:
+            env["RSX_LANES_PER_ENV"] = lanes
+        path = "/tmp/rsx_lanes_%s.npy" % (lanes or "default")
+        subprocess.check_call([sys.executable, "-c", code, path], env=env)
+        res.append(np.load(path))
+    assert np.array_equal(res[0], res[1])
+
+
+def test_api_errors_are_reported_not_crashed():
+    L = _lib()
+    sim = L.Sim(0, 0, 3, 3, 25, 8)
+    with pytest.raises(L.RsxError, match="no task attached"):
+        sim.task_step(None)
+    with pytest.raises(L.RsxError, match="does not match"):
+        sim.task_attach(2, 0, 0, 0)           # StaticDefenders needs an SSL handle
+    sim.task_attach(1, 0, 0, 0)
+    with pytest.raises(L.RsxError, match="already attached"):
+        sim.task_attach(1, 0, 0, 0)
+    with pytest.raises(L.RsxError):
+        sim.task_rollout(-1)
+    sim.close()
+    for bad in ((2, 0, 3, 3), (0, 7, 3, 3), (0, 0, 0, 0), (0, 0, 20, 20)):
+        with pytest.raises(L.RsxError, match="bad simulator configuration"):
+            L.Sim(*bad, 25, 4)
+    with pytest.raises(L.RsxError, match="device_id"):
+        L.Sim(0, 0, 3, 3, 25, 4, device_id=99)
+    ssl = L.Sim(1, 2, 1, 6, 25, 4)
+    with pytest.raises(L.RsxError, match="does not match"):
+        ssl.task_attach(3, 0, 0, 0)           # dribbling needs 1v4
+    ssl.close()
