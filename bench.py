@@ -11,7 +11,7 @@ OU noise for the other five robots, 5 physics sub-steps, observation, reward, do
 and same-step auto-reset, in ONE kernel launch per step (mode `step`, the default and the value
 reported).  All inputs are resident in HBM before the timed region.  With N > 1 each rank owns
 envs [rank*B, (rank+1)*B) (weak scaling, no data-path collective); a 64-byte metrics vector is
-all-reduced over RCCL every 100 steps, off the critical path.
+all-reduced over RCCL every 200 steps (a ~20 us stream-ordered collective).
 
 Prints ONE JSON line on rank 0 (see the driver contract); extra keys: `roofline`,
 `cpu_baseline`, `rollout` (the same work with all K steps inside one launch).
@@ -103,10 +103,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the step engine has no CPU path")
     torch.cuda.set_device(local_rank)
-    distributed = world > 1
+    # RSX_BENCH_FORCE_DIST=1 runs the RCCL path even with one rank (used to test it on a 1-GPU box)
+    distributed = world > 1 or os.environ.get("RSX_BENCH_FORCE_DIST") == "1"
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     B, K, W = args.envs, args.steps, args.warmup
     sim = L.Sim(L.KIND_VSS, 0, 3, 3, 25, B, local_rank)
@@ -115,7 +117,16 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     sim.task_reset(stream)
     mbuf = torch.zeros(L.N_METRICS, dtype=torch.int64, device="cuda")
-    pending = []
+    ALLREDUCE_EVERY = 200   # steps between metrics all-reduces
+
+    def allreduce_metrics():
+        """The only inter-GPU exchange: sum of the 8-entry int64 metrics vector (64 bytes).
+        Enqueued on the compute stream as a stream-ordered (host-asynchronous) collective:
+        measured on MI355X, recording a HIP event on a busy stream costs ~200 us of stream time,
+        so the async_op=True / side-stream forms of torch.distributed (which record events) are
+        3 orders of magnitude more expensive than the ~20 us collective itself."""
+        mbuf.copy_(tens["metrics"], non_blocking=True)
+        dist.all_reduce(mbuf)
 
     def run(n, timed_mode):
         if timed_mode == "rollout":
@@ -123,12 +134,11 @@ def main():
             return
         done = 0
         while done < n:
-            m = min(100, n - done)
+            m = min(ALLREDUCE_EVERY, n - done)
             sim.task_step_n(m, stream)   # m launches, one per env.step()
             done += m
-            if distributed:              # trivial metrics all-reduce, every 100 steps
-                mbuf.copy_(tens["metrics"])
-                pending.append(dist.all_reduce(mbuf, async_op=True))
+            if distributed and not os.environ.get("RSX_BENCH_NO_ALLREDUCE"):
+                allreduce_metrics()
 
     def barrier():
         if distributed:
@@ -144,9 +154,6 @@ def main():
         run(K, mode)
         ev1.record()
         torch.cuda.synchronize()
-        for p in pending:
-            p.wait()
-        del pending[:]
         barrier()
         wall = time.perf_counter() - t0
         dev_ms = ev0.elapsed_time(ev1)
