@@ -332,3 +332,26 @@ def test_api_errors_are_reported_not_crashed():
     with pytest.raises(L.RsxError, match="does not match"):
         ssl.task_attach(3, 0, 0, 0)           # dribbling needs 1v4
     ssl.close()
+
+
+@pytest.mark.parametrize("ts_ms", [0, 3, 12, 50])
+def test_other_time_steps_bitexact(oracle_mod, ts_ms):
+    """sub-step count follows time_step_ms (0 = no physics: commands, observation, reward only)"""
+    L = _lib()
+    O = oracle_mod
+    B = 11
+    for task, kind, ft, nb, ny in ((1, 0, 0, 3, 3), (2, 1, 2, 1, 6)):
+        sim = L.Sim(kind, ft, nb, ny, ts_ms, B)
+        sim.task_attach(task, 17, 0, 25)
+        tens = sim.task_tensors()
+        refs = [O.OracleEnv(kind, ft, nb, ny, ts_ms, "f32") for _ in range(B)]
+        for e, r in enumerate(refs):
+            r.task_attach(task, 17, e, 25)
+            r.task_reset()
+        sim.task_reset()
+        for t in range(60):
+            sim.task_step(None)
+            for r in refs:
+                r.task_step(None)
+        _cmp_task(sim, refs, tens, f"ts={ts_ms}")
+        sim.close()
