@@ -163,16 +163,18 @@ void rsxo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t o
 #define RSXO_DOM_PLACE 3u
 
 /* float-only elementary functions with a fixed operation order (mirrored instruction for
- * instruction by rsoccer_amd/csrc/rsx_math.hpp); coefficients: Cephes sinf/cosf/logf. */
+ * instruction by rsoccer_amd/csrc/rsx_math.hpp); coefficients: Cephes sinf/cosf/logf.
+ * Fused multiply-adds appear ONLY where written (fmaf: one rounding, identical on x86 -mfma,
+ * glibc's software fmaf and the GPU's v_fma_f32); the build keeps -ffp-contract=off. */
 static inline void rsxo_sincos_f32(float a, float* s, float* c) {
     float t = a * 0.636619772f;
     int k = (int)(t + (t >= 0.0f ? 0.5f : -0.5f));
     float fk = (float)k;
-    float r = ((a - fk * 1.5703125f) - fk * 4.837512969970703125e-4f) - fk * 7.54978995489188e-8f;
+    float r = fmaf(fk, -7.54978995489188e-8f, fmaf(fk, -4.837512969970703125e-4f, fmaf(fk, -1.5703125f, a)));
     float z = r * r;
-    float ps = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
-    float pc = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f)
-                   * z * z - 0.5f * z + 1.0f;
+    float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+    float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z,
+                    fmaf(-0.5f, z, 1.0f));
     switch (k & 3) {
         case 0: *s = ps; *c = pc; break;
         case 1: *s = pc; *c = -ps; break;
@@ -187,23 +189,16 @@ static inline float rsxo_log_f32(float x) { /* x in [2^-24, 1] */
     float m; memcpy(&m, &ix, 4);
     if (m > 1.41421356f) { m = m * 0.5f; e = e + 1; }
     float f = m - 1.0f, z = f * f;
-    float p = ((((((((7.0376836292e-2f * f - 1.1514610310e-1f) * f + 1.1676998740e-1f) * f
-                    - 1.2420140846e-1f) * f + 1.4249322787e-1f) * f - 1.6668057665e-1f) * f
-                 + 2.0000714765e-1f) * f - 2.4999993993e-1f) * f + 3.3333331174e-1f) * f * z;
+    float p = fmaf(fmaf(fmaf(fmaf(fmaf(fmaf(fmaf(fmaf(7.0376836292e-2f, f, -1.1514610310e-1f), f, 1.1676998740e-1f), f,
+                    -1.2420140846e-1f), f, 1.4249322787e-1f), f, -1.6668057665e-1f), f, 2.0000714765e-1f), f,
+                    -2.4999993993e-1f), f, 3.3333331174e-1f) * f * z;
     float fe = (float)e;
-    p = p + fe * -2.12194440e-4f;
-    p = p - 0.5f * z;
+    p = fmaf(fe, -2.12194440e-4f, p);
+    p = fmaf(-0.5f, z, p);
     float r = f + p;
-    r = r + fe * 0.693359375f;
+    r = fmaf(fe, 0.693359375f, r);
     return r;
 }
-
-#ifdef _OPENMP
-#include <omp.h>
-void rsxo_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
-#else
-void rsxo_set_threads(int n) { (void)n; }
-#endif
 
 /* atan2 for the float instantiation (Cephes atanf; only used by the PassEndurance placement) */
 static inline float rsxo_atan_f32(float x) {
@@ -231,6 +226,7 @@ static inline float rsxo_atan2_f32(float y, float x) {
 #define R_LOG(x) rsxo_log_f32(x)
 #define R_SQRT(x) sqrtf(x)
 #define R_FABS(x) fabsf(x)
+#define R_FMA(a, b, c) fmaf((a), (b), (c))
 #include "rsx_oracle_impl.h"
 #undef R
 #undef SUF
@@ -238,6 +234,7 @@ static inline float rsxo_atan2_f32(float y, float x) {
 #undef R_LOG
 #undef R_SQRT
 #undef R_FABS
+#undef R_FMA
 #undef R_ATAN2
 
 /* ---- instantiate: double ---- */
@@ -248,5 +245,6 @@ static inline void rsxo_sincos_f64(double a, double* s, double* c) { *s = sin(a)
 #define R_LOG(x) log(x)
 #define R_SQRT(x) sqrt(x)
 #define R_FABS(x) fabs(x)
+#define R_FMA(a, b, c) fma((a), (b), (c))
 #define R_ATAN2(y, x) atan2((y), (x))
 #include "rsx_oracle_impl.h"

@@ -163,6 +163,17 @@ static void SUF(walls)(const SUF(rsxo_env)* e, R r, R rest, R* px, R* py, R* pvx
     *px = x; *py = y; *pvx = vx; *pvy = vy;
 }
 
+/* heading after a small turn d (rad): rotate (c, s) by sin / cos of d (|d| < 0.5; odd / even
+ * Taylor polynomials, error < 1e-8) — one exact sincos per step(), cheap rotations per sub-step */
+static inline void SUF(rotate_heading)(R d, R* c, R* s) {
+    R d2 = d * d;
+    R sd = d * R_FMA(d2, R_FMA(d2, RC(8.3333333333333333e-3), RC(-1.6666666666666667e-1)), RC(1));
+    R cd = R_FMA(d2, R_FMA(d2, R_FMA(d2, RC(-1.3888888888888889e-3), RC(4.1666666666666664e-2)), RC(-0.5)), RC(1));
+    R c0 = *c, s0 = *s;
+    *c = R_FMA(c0, cd, -(s0 * sd));
+    *s = R_FMA(s0, cd, c0 * sd);
+}
+
 /* per-body working record */
 typedef struct SUF(body) {
     R x, y, vx, vy;        /* all */
@@ -179,13 +190,13 @@ static inline int SUF(rb_geom)(const SUF(rsxo_env)* e, const SUF(body)* a, const
     *mouth = 0;
     if (b->z >= e->robot_h) { *pen = RC(-1); *nx = RC(0); *ny = RC(0); return 0; }
     if (e->cfg.kind == 1) {
-        R lx = dx * a->c + dy * a->s, ly = dy * a->c - dx * a->s;
+        R lx = R_FMA(dx, a->c, dy * a->s), ly = R_FMA(dy, a->c, -(dx * a->s));
         if (R_FABS(ly) < e->half_kw && lx > RC(0)) {
             *mouth = 1; *pen = e->dck_rb - lx; *nx = a->c; *ny = a->s;
             return *pen > RC(0);
         }
     }
-    R d2 = dx * dx + dy * dy;
+    R d2 = R_FMA(dx, dx, dy * dy);
     if (d2 < e->rs_rb2 && d2 > RC(0)) {
         R d = R_SQRT(d2), inv = RC(1) / d;
         *nx = dx * inv; *ny = dy * inv; *pen = e->rs_rb - d;
@@ -245,7 +256,7 @@ static void SUF(step_core)(SUF(rsxo_env)* e, const R* cmds) {
     /* rolling resistance: a constant deceleration, applied once for the whole step() while the
      * ball is on the ground (exact stop, never reverses) */
     if (c->n_sub && !(ball->z > RC(0) || ball->vz > RC(0))) {
-        R sp2 = ball->vx * ball->vx + ball->vy * ball->vy;
+        R sp2 = R_FMA(ball->vx, ball->vx, ball->vy * ball->vy);
         if (sp2 > RC(0)) {
             R sp = R_SQRT(sp2), ns = sp - e->mu_g_dt;
             if (ns < RC(0)) ns = RC(0);
@@ -258,39 +269,39 @@ static void SUF(step_core)(SUF(rsxo_env)* e, const R* cmds) {
         /* ---- A: actuation + integration ---- */
         for (int k = 0; k < N; ++k) {
             SUF(body)* o = &b[k];
-            R vf = o->vx * o->c + o->vy * o->s;
-            R vl = o->vy * o->c - o->vx * o->s;
+            R vf = R_FMA(o->vy, o->s, o->vx * o->c);
+            R vl = R_FMA(o->vy, o->c, -(o->vx * o->s));
             if (!ssl) {
                 vf = vf + SUF(clampr)(o->t0 - vf, -e->a_lin_h, e->a_lin_h);
                 vl = vl - SUF(clampr)(vl, -e->a_lat_h, e->a_lat_h);
                 o->om = o->om + SUF(clampr)(o->t1 - o->om, -e->a_ang_h, e->a_ang_h);
             } else {
                 R dx = o->t0 - vf, dy = o->t1 - vl;
-                R d2 = dx * dx + dy * dy;
+                R d2 = R_FMA(dx, dx, dy * dy);
                 if (d2 > e->a_lin_h2) { R sc = e->a_lin_h / R_SQRT(d2); dx = dx * sc; dy = dy * sc; }
                 vf = vf + dx; vl = vl + dy;
                 o->om = o->om + SUF(clampr)(o->t2 - o->om, -e->a_ang_h, e->a_ang_h);
             }
-            o->vx = vf * o->c - vl * o->s;
-            o->vy = vf * o->s + vl * o->c;
-            o->x = o->x + o->vx * e->h;
-            o->y = o->y + o->vy * e->h;
-            o->th = o->th + o->om * e->h_deg;
+            o->vx = R_FMA(vf, o->c, -(vl * o->s));
+            o->vy = R_FMA(vf, o->s, vl * o->c);
+            o->x = R_FMA(o->vx, e->h, o->x);
+            o->y = R_FMA(o->vy, e->h, o->y);
+            o->th = R_FMA(o->om, e->h_deg, o->th);
             if (o->th > RC(180)) o->th = o->th - RC(360);
             else if (o->th < RC(-180)) o->th = o->th + RC(360);
-            R_SINCOS(o->th * e->deg2rad, &o->s, &o->c);
+            SUF(rotate_heading)(o->om * e->h, &o->c, &o->s);
         }
         if (ball->z > RC(0) || ball->vz > RC(0)) {
             ball->vz = ball->vz - e->g_h;
-            ball->z = ball->z + ball->vz * e->h;
+            ball->z = R_FMA(ball->vz, e->h, ball->z);
             if (ball->z <= RC(0)) {
                 ball->z = RC(0);
                 ball->vz = -ball->vz * e->e_ground;
                 if (ball->vz < e->vz_min) ball->vz = RC(0);
             }
         }
-        ball->x = ball->x + ball->vx * e->h;
-        ball->y = ball->y + ball->vy * e->h;
+        ball->x = R_FMA(ball->vx, e->h, ball->x);
+        ball->y = R_FMA(ball->vy, e->h, ball->y);
 
         /* ---- B: contacts, Jacobi over the post-integration snapshot ---- */
         R dvx[MAXBOD], dvy[MAXBOD], dpx[MAXBOD], dpy[MAXBOD];
@@ -301,33 +312,38 @@ static void SUF(step_core)(SUF(rsxo_env)* e, const R* cmds) {
                 if (j == i) continue;
                 if (i < N && j < N) { /* robot - robot */
                     R dx = b[j].x - b[i].x, dy = b[j].y - b[i].y;
-                    R d2 = dx * dx + dy * dy;
+                    R d2 = R_FMA(dx, dx, dy * dy);
                     if (d2 < e->rs_rr2 && d2 > RC(0)) {
                         R d = R_SQRT(d2), inv = RC(1) / d;
                         R nx = dx * inv, ny = dy * inv, pen = e->rs_rr - d;
-                        R vn = (b[j].vx - b[i].vx) * nx + (b[j].vy - b[i].vy) * ny;
-                        if (vn < RC(0)) { R q = e->ope_rr * vn * e->w_rr; avx = avx + q * nx; avy = avy + q * ny; }
+                        R vn = R_FMA(b[j].vx - b[i].vx, nx, (b[j].vy - b[i].vy) * ny);
+                        if (vn < RC(0)) { R q = e->ope_rr * vn * e->w_rr; avx = R_FMA(q, nx, avx); avy = R_FMA(q, ny, avy); }
                         R pc = e->beta * pen * e->w_rr;
-                        apx = apx - pc * nx; apy = apy - pc * ny;
+                        apx = R_FMA(-pc, nx, apx); apy = R_FMA(-pc, ny, apy);
                     }
                 } else if (i < N) { /* robot i, ball j */
                     R nx, ny, pen; int mouth;
                     int touch = SUF(rb_geom)(e, &b[i], ball, &nx, &ny, &pen, &mouth);
                     if (touch) {
-                        R vn = (ball->vx - b[i].vx) * nx + (ball->vy - b[i].vy) * ny;
-                        if (vn < RC(0)) { R q = e->ope_rb * vn * e->w_rb_r; avx = avx + q * nx; avy = avy + q * ny; }
+                        R vn = R_FMA(ball->vx - b[i].vx, nx, (ball->vy - b[i].vy) * ny);
+                        if (vn < RC(0)) { R q = e->ope_rb * vn * e->w_rb_r; avx = R_FMA(q, nx, avx); avy = R_FMA(q, ny, avy); }
                         R pc = e->beta * pen * e->w_rb_r;
-                        apx = apx - pc * nx; apy = apy - pc * ny;
+                        apx = R_FMA(-pc, nx, apx); apy = R_FMA(-pc, ny, apy);
                     }
                     b[i].ir = mouth && pen > -e->ir_tol;
                 } else { /* ball i, robot j */
                     R nx, ny, pen; int mouth;
                     int touch = SUF(rb_geom)(e, &b[j], ball, &nx, &ny, &pen, &mouth);
                     if (touch) {
-                        R vn = (ball->vx - b[j].vx) * nx + (ball->vy - b[j].vy) * ny;
-                        if (vn < RC(0)) { R q = e->ope_rb * vn * e->w_rb_b; avx = avx - q * nx; avy = avy - q * ny; }
+                        R vn = R_FMA(ball->vx - b[j].vx, nx, (ball->vy - b[j].vy) * ny);
+                        if (vn < RC(0)) {
+                            R q = e->ope_rb * vn * e->w_rb_b;
+                            if (ssl) { avx = avx - q * nx; avy = avy - q * ny; }       /* summed from the robots' records */
+                            else { avx = R_FMA(-q, nx, avx); avy = R_FMA(-q, ny, avy); } /* computed in place */
+                        }
                         R pc = e->beta * pen * e->w_rb_b;
-                        apx = apx + pc * nx; apy = apy + pc * ny;
+                        if (ssl) { apx = apx + pc * nx; apy = apy + pc * ny; }
+                        else { apx = R_FMA(pc, nx, apx); apy = R_FMA(pc, ny, apy); }
                     }
                     if (mouth && pen > -e->ir_tol) { /* infrared: kicker / dribbler act */
                         if (b[j].kick_x > RC(0) || b[j].kick_z > RC(0)) {

@@ -162,14 +162,14 @@ __device__ __forceinline__ void circle_contact(const Body& o, const float4 oj, c
                                                float& avy, float& apx, float& apy) {
     // a body never touches itself: its own slot gives d2 == 0, rejected by d2 > 0
     float dx = oj.x - o.x, dy = oj.y - o.y;
-    float d2 = dx * dx + dy * dy;
+    float d2 = fma_(dx, dx, dy * dy);
     if ((d2 < rs2) & (d2 > 0.0f) & enabled) {
         float d = sqrtf(d2), inv = 1.0f / d;
         float nx = dx * inv, ny = dy * inv, pen = rs - d;
-        float vn = (oj.z - o.vx) * nx + (oj.w - o.vy) * ny;
-        if (vn < 0.0f) { float q = ope * vn * w; avx = avx + q * nx; avy = avy + q * ny; }
+        float vn = fma_(oj.z - o.vx, nx, (oj.w - o.vy) * ny);
+        if (vn < 0.0f) { float q = ope * vn * w; avx = fma_(q, nx, avx); avy = fma_(q, ny, avy); }
         float pc = beta * pen * w;
-        apx = apx - pc * nx; apy = apy - pc * ny;
+        apx = fma_(-pc, nx, apx); apy = fma_(-pc, ny, apy);
     }
 }
 
@@ -181,10 +181,10 @@ __device__ __forceinline__ void contact_response(const Body& o, const float4 oj,
     float dx = oj.x - o.x, dy = oj.y - o.y;
     float d = sqrtf(d2), inv = 1.0f / d;
     float nx = dx * inv, ny = dy * inv, pen = rs - d;
-    float vn = (oj.z - o.vx) * nx + (oj.w - o.vy) * ny;
-    if (vn < 0.0f) { float q = ope * vn * w; avx = avx + q * nx; avy = avy + q * ny; }
+    float vn = fma_(oj.z - o.vx, nx, (oj.w - o.vy) * ny);
+    if (vn < 0.0f) { float q = ope * vn * w; avx = fma_(q, nx, avx); avy = fma_(q, ny, avy); }
     float pc = beta * pen * w;
-    apx = apx - pc * nx; apy = apy - pc * ny;
+    apx = fma_(-pc, nx, apx); apy = fma_(-pc, ny, apy);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -206,7 +206,7 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
     // ball is on the ground (exact stop, never reverses) — keeps the sqrt + divide chain out of
     // the sub-step loop, where the ball lane's branch is serialised with the robots' work
     if (is_ball && P.n_sub && !(o.z > 0.0f || o.vz > 0.0f)) {
-        float sp2 = o.vx * o.vx + o.vy * o.vy;
+        float sp2 = fma_(o.vx, o.vx, o.vy * o.vy);
         if (sp2 > 0.0f) {
             float sp = sqrtf(sp2), ns = sp - P.mu_g_dt;
             if (ns < 0.0f) ns = 0.0f;
@@ -218,39 +218,39 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
     for (int sub = 0; sub < P.n_sub; ++sub) {
         // ---- A: actuation + integration ----
         if (is_robot) {
-            float vf = o.vx * o.c + o.vy * o.s;
-            float vl = o.vy * o.c - o.vx * o.s;
+            float vf = fma_(o.vy, o.s, o.vx * o.c);
+            float vl = fma_(o.vy, o.c, -(o.vx * o.s));
             if (KIND == RSX_KIND_VSS) {
                 vf = vf + clampf(o.t0 - vf, -P.a_lin_h, P.a_lin_h);
                 vl = vl - clampf(vl, -P.a_lat_h, P.a_lat_h);
                 o.om = o.om + clampf(o.t1 - o.om, -P.a_ang_h, P.a_ang_h);
             } else {
                 float dx = o.t0 - vf, dy = o.t1 - vl;
-                float d2 = dx * dx + dy * dy;
+                float d2 = fma_(dx, dx, dy * dy);
                 if (d2 > P.a_lin_h2) { float sc = P.a_lin_h / sqrtf(d2); dx = dx * sc; dy = dy * sc; }
                 vf = vf + dx; vl = vl + dy;
                 o.om = o.om + clampf(o.t2 - o.om, -P.a_ang_h, P.a_ang_h);
             }
-            o.vx = vf * o.c - vl * o.s;
-            o.vy = vf * o.s + vl * o.c;
-            o.x = o.x + o.vx * P.h;
-            o.y = o.y + o.vy * P.h;
-            o.th = o.th + o.om * P.h_deg;
+            o.vx = fma_(vf, o.c, -(vl * o.s));
+            o.vy = fma_(vf, o.s, vl * o.c);
+            o.x = fma_(o.vx, P.h, o.x);
+            o.y = fma_(o.vy, P.h, o.y);
+            o.th = fma_(o.om, P.h_deg, o.th);
             if (o.th > 180.0f) o.th = o.th - 360.0f;
             else if (o.th < -180.0f) o.th = o.th + 360.0f;
-            sincos_f32(o.th * K::deg2rad, o.s, o.c);
+            rotate_heading(o.om * P.h, o.c, o.s);
         } else if (is_ball) {
             if (o.z > 0.0f || o.vz > 0.0f) {
                 o.vz = o.vz - P.g_h;
-                o.z = o.z + o.vz * P.h;
+                o.z = fma_(o.vz, P.h, o.z);
                 if (o.z <= 0.0f) {
                     o.z = 0.0f;
                     o.vz = -o.vz * K::e_ground;
                     if (o.vz < K::vz_min) o.vz = 0.0f;
                 }
             }
-            o.x = o.x + o.vx * P.h;
-            o.y = o.y + o.vy * P.h;
+            o.x = fma_(o.vx, P.h, o.x);
+            o.y = fma_(o.vy, P.h, o.y);
         }
 
         // ---- B: contacts, Jacobi over the post-integration snapshot ----
@@ -275,7 +275,7 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                     for (int j = 0; j <= NR; ++j) {
                         const bool rb = is_ball || j == NR;
                         float dx = oth[j].x - o.x, dy = oth[j].y - o.y;
-                        float d2 = dx * dx + dy * dy;
+                        float d2 = fma_(dx, dx, dy * dy);
                         const bool t = (d2 < (rb ? K::rs_rb2 : K::rs_rr2)) & (d2 > 0.0f) & (!rb | ball_low);
                         d2s[j] = t ? d2 : -1.0f;
                         any |= t;
@@ -317,7 +317,7 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
 #pragma unroll
                     for (int j = 0; j < NR; ++j) {
                         float dx = oth[j].x - o.x, dy = oth[j].y - o.y;
-                        float d2 = dx * dx + dy * dy;
+                        float d2 = fma_(dx, dx, dy * dy);
                         const bool t = (d2 < K::rs_rr2) & (d2 > 0.0f);
                         d2s[j] = t ? d2 : -1.0f;
                         any |= t;
@@ -341,11 +341,11 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                 float nx = 0.0f, ny = 0.0f, pen = -1.0f;
                 bool mouth = false, touch = false;
                 if (ball_low) {
-                    float lx = dx * o.c + dy * o.s, ly = dy * o.c - dx * o.s;
+                    float lx = fma_(dx, o.c, dy * o.s), ly = fma_(dy, o.c, -(dx * o.s));
                     if (fabsf(ly) < K::half_kw && lx > 0.0f) {
                         mouth = true; pen = K::dck_rb - lx; nx = o.c; ny = o.s; touch = pen > 0.0f;
                     } else {
-                        float d2 = dx * dx + dy * dy;
+                        float d2 = fma_(dx, dx, dy * dy);
                         if (d2 < K::rs_rb2 && d2 > 0.0f) {
                             float d = sqrtf(d2), inv = 1.0f / d;
                             nx = dx * inv; ny = dy * inv; pen = K::rs_rb - d; touch = true;
@@ -355,13 +355,13 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                 float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 int fl = 0;
                 if (touch) {
-                    float vn = (ob.z - o.vx) * nx + (ob.w - o.vy) * ny;
+                    float vn = fma_(ob.z - o.vx, nx, (ob.w - o.vy) * ny);
                     if (vn < 0.0f) {
-                        float q = K::ope_rb * vn * K::w_rb_r; avx = avx + q * nx; avy = avy + q * ny;
+                        float q = K::ope_rb * vn * K::w_rb_r; avx = fma_(q, nx, avx); avy = fma_(q, ny, avy);
                         float qb = K::ope_rb * vn * K::w_rb_b; r0.x = qb * nx; r0.y = qb * ny; fl |= 1;
                     }
                     float pc = K::beta * pen * K::w_rb_r;
-                    apx = apx - pc * nx; apy = apy - pc * ny;
+                    apx = fma_(-pc, nx, apx); apy = fma_(-pc, ny, apy);
                     float pb = K::beta * pen * K::w_rb_b; r0.z = pb * nx; r0.w = pb * ny; fl |= 2;
                 }
                 o.ir = mouth && pen > -K::ir_tol;
@@ -874,9 +874,11 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
                 od = o.th; wd = o.om * K::rad2deg;
                 if (KIND == RSX_KIND_SSL) wheel_speeds<KIND>(P, o, wheels);
                 // omega lives in HBM as deg/s: keep the lane's copy equal to what a reload gives.
-                // (o.s, o.c) already are sin / cos of the stored heading: reused by the
-                // observation and by the next step of a multi-step launch.
                 o.om = wd * K::deg2rad;
+                // the sub-steps carried (c, s) by small rotations; re-derive them exactly from the
+                // stored heading: this is what the observation reports and what a reload (the next
+                // launch, or the next step of a multi-step launch) starts from
+                sincos_f32(o.th * K::deg2rad, o.s, o.c);
             } else if (is_ball) {
                 o.z = (K::r_ball + o.z) - K::r_ball;  // height goes through the wire format too
             }

@@ -2,10 +2,11 @@
 //
 // The step engine promises results that are bit-identical to the scalar model in fp32, on any
 // batch size / lane mapping.  libm-style device functions (ocml sinf/cosf/logf) carry no such
-// promise, so the few transcendental functions the model needs are spelled out here as plain
-// mul/add sequences (Cephes single-precision coefficients).  The translation unit is compiled
-// with -ffp-contract=off: no multiply-add is ever fused behind the source's back; IEEE sqrt and
-// divide are correctly rounded by hipcc's default expansion.
+// promise, so the few transcendental functions the model needs are spelled out here as fixed
+// mul / add / explicit-fma sequences (Cephes single-precision coefficients).  The translation
+// unit is compiled with -ffp-contract=off: no multiply-add is ever fused behind the source's
+// back (fused ones are written as fma_()); IEEE sqrt and divide are correctly rounded by hipcc's
+// default expansion.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -33,22 +34,37 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// fused multiply-add, written out: the translation unit is built with -ffp-contract=off, so an
+// FMA exists exactly where the model says so (one rounding: v_fma_f32 == fmaf on the CPU side)
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
 // sin and cos of an angle already reduced to about [-pi, pi] (any |a| < 1e4 works).
 __device__ __forceinline__ void sincos_f32(float a, float& s, float& c) {
     float t = a * 0.636619772f;                       // 2/pi
     int k = (int)(t + (t >= 0.0f ? 0.5f : -0.5f));    // nearest quadrant
     float fk = (float)k;
     // three-term Cody-Waite reduction by pi/2
-    float r = ((a - fk * 1.5703125f) - fk * 4.837512969970703125e-4f) - fk * 7.54978995489188e-8f;
+    float r = fma_(fk, -7.54978995489188e-8f, fma_(fk, -4.837512969970703125e-4f, fma_(fk, -1.5703125f, a)));
     float z = r * r;
-    float ps = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
-    float pc = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f)
-                   * z * z - 0.5f * z + 1.0f;
+    float ps = fma_(fma_(fma_(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+    float pc = fma_(fma_(fma_(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z,
+                    fma_(-0.5f, z, 1.0f));
     int q = k & 3;
     float ss = (q & 1) ? pc : ps;
     float cc = (q & 1) ? ps : pc;
     s = (q & 2) ? -ss : ss;
     c = (q == 1 || q == 2) ? -cc : cc;
+}
+
+// heading after a small turn d (rad): rotate (c, s) by sin / cos of d (|d| < 0.5; odd / even
+// Taylor polynomials, error < 1e-8) — one exact sincos per step(), cheap rotations per sub-step
+__device__ __forceinline__ void rotate_heading(float d, float& c, float& s) {
+    float d2 = d * d;
+    float sd = d * fma_(d2, fma_(d2, 8.3333333333333333e-3f, -1.6666666666666667e-1f), 1.0f);
+    float cd = fma_(d2, fma_(d2, fma_(d2, -1.3888888888888889e-3f, 4.1666666666666664e-2f), -0.5f), 1.0f);
+    float c0 = c, s0 = s;
+    c = fma_(c0, cd, -(s0 * sd));
+    s = fma_(s0, cd, c0 * sd);
 }
 
 // natural log for x in [2^-24, 1]
@@ -58,14 +74,14 @@ __device__ __forceinline__ float log_f32(float x) {
     float m = __uint_as_float((ix & 0x007fffffu) | 0x3f800000u);
     if (m > 1.41421356f) { m = m * 0.5f; e = e + 1; }
     float f = m - 1.0f, z = f * f;
-    float p = ((((((((7.0376836292e-2f * f - 1.1514610310e-1f) * f + 1.1676998740e-1f) * f
-                    - 1.2420140846e-1f) * f + 1.4249322787e-1f) * f - 1.6668057665e-1f) * f
-                 + 2.0000714765e-1f) * f - 2.4999993993e-1f) * f + 3.3333331174e-1f) * f * z;
+    float p = fma_(fma_(fma_(fma_(fma_(fma_(fma_(fma_(7.0376836292e-2f, f, -1.1514610310e-1f), f, 1.1676998740e-1f), f,
+                    -1.2420140846e-1f), f, 1.4249322787e-1f), f, -1.6668057665e-1f), f, 2.0000714765e-1f), f,
+                    -2.4999993993e-1f), f, 3.3333331174e-1f) * f * z;
     float fe = (float)e;
-    p = p + fe * -2.12194440e-4f;
-    p = p - 0.5f * z;
+    p = fma_(fe, -2.12194440e-4f, p);
+    p = fma_(-0.5f, z, p);
     float r = f + p;
-    r = r + fe * 0.693359375f;
+    r = fma_(fe, 0.693359375f, r);
     return r;
 }
 
