@@ -716,7 +716,12 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
     const bool is_robot = live && b < N, is_ball = live && b == N;
     const size_t B = (size_t)P.num_envs;
     const uint32_t env_id = P.env_id_base + (uint32_t)e;
-    const int OD = P.obs_dim;
+    // observation width: a compile-time constant when the team sizes are (lets the copy-out unroll)
+    constexpr int OD_C = NR == 0 ? 0
+        : TASK == RSX_TASK_VSS_V0 ? 40                        // 3v3: 4 + 7*3 + 5*3 (vss_gym.py:64-67)
+        : TASK == RSX_TASK_SSL_STATIC_DEFENDERS ? 4 + 8 + 2 * (NR - 1)
+        : TASK == RSX_TASK_SSL_DRIBBLING ? 21 : TASK == RSX_TASK_SSL_CONTESTED ? 14 : 16;
+    const int OD = OD_C ? OD_C : P.obs_dim;
     float* const auxe = bufs.aux + e;  // column of this env in the scalar arena
 
 #ifdef RSX_TIMING
@@ -1050,8 +1055,17 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
         {
             const size_t base = (size_t)tile * G * OD;
             const size_t lim = B * (size_t)OD;
-            for (int i = lane; i < G * OD; i += 64)
-                if (base + i < lim) bufs.obs[base + i] = sh.stage[i];
+            if (OD_C) {  // all staging reads in flight together, then the stores
+                constexpr int NCH = (G * (OD_C ? OD_C : 1) + 63) / 64;
+                float v[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) { const int i = lane + 64 * c; v[c] = i < G * OD_C ? sh.stage[i] : 0.0f; }
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) { const int i = lane + 64 * c; if (i < G * OD_C && base + i < lim) bufs.obs[base + i] = v[c]; }
+            } else {
+                for (int i = lane; i < G * OD; i += 64)
+                    if (base + i < lim) bufs.obs[base + i] = sh.stage[i];
+            }
         }
         wave_sync();
     }
