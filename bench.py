@@ -48,7 +48,7 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(envs, budget_s=12.0):
+def cpu_baseline(envs, budget_s=12.0, single_s=1.5):
     """Times the CPU oracle (oracle/, float instantiation, OpenMP over envs) on a bounded sample
     of the same workload.  This is the only place bench.py touches oracle/."""
     from oracle import oracle as O
@@ -64,7 +64,7 @@ def cpu_baseline(envs, budget_s=12.0):
     # one-thread figure on a slice (mirrors the reference's one-simulator-per-env design)
     t0 = time.perf_counter()
     n1 = 0
-    while time.perf_counter() - t0 < 1.5:
+    while time.perf_counter() - t0 < single_s:
         for _ in range(200):
             es[0].task_step(None)
         n1 += 200

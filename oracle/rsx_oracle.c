@@ -200,6 +200,13 @@ static inline float rsxo_log_f32(float x) { /* x in [2^-24, 1] */
     return r;
 }
 
+#ifdef _OPENMP
+#include <omp.h>
+void rsxo_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+#else
+void rsxo_set_threads(int n) { (void)n; }
+#endif
+
 /* atan2 for the float instantiation (Cephes atanf; only used by the PassEndurance placement) */
 static inline float rsxo_atan_f32(float x) {
     float sgn = x < 0.0f ? -1.0f : 1.0f;

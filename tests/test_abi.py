@@ -79,3 +79,11 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.replace("no oracle", ""), os.path.join(dirpath, f)
+
+
+def test_bench_cpu_baseline_leg_runs(oracle_mod):
+    """bench.py's cpu_baseline (the only place outside tests/ and smoke() that may touch oracle/)"""
+    import bench
+    r = bench.cpu_baseline(64, budget_s=0.3, single_s=0.1)
+    assert r["kind"] == "port" and r["cores"] >= 1 and r["value"] > 1e4 and r["single_thread_value"] > 1e4
+    assert "64 envs" in r["sample"]
