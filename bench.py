@@ -196,7 +196,7 @@ def main():
                        "envs_per_gpu": B, "launch_mode": args.mode, "sub_steps": 5, "time_step_ms": 25},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "rsx::task_step_kernel<0, 8, 1, 6>",
+                         "kernel": "rsx::task_step_kernel<0, 8, 1, 6, 0>" if args.mode == "step" else "rsx::task_step_kernel<0, 8, 1, 6, 3>",
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
                          "avg_launch_us": launch_us},
             "episodes": int(metrics[1]), "env_steps_counted": int(metrics[0]),
