@@ -12,6 +12,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _native_libs_are_built():
+    """Build librsx_hip.so / the oracle when missing or older than their sources (hipcc
+    cross-compiles without a GPU; a prebuilt, up-to-date library is used as is)."""
+    import __graft_entry__ as g
+    g.build()
+
+
 @pytest.fixture(scope="session")
 def oracle_mod():
     from oracle import oracle as O
