@@ -420,32 +420,56 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
 // ---------------------------------------------------------------------------------------------
 // SoA state access
 // ---------------------------------------------------------------------------------------------
+// Raw wire values of the lane's body.  Robot and ball lanes run the SAME load instructions (only
+// the row index differs: ball rows 0..4 + the vz row, robot rows 5+RS*b .. +5), so all loads of a
+// wave are in flight together; nothing is computed here (a use would park the wave on vmcnt
+// between the two roles' loads).
+struct RawBody { float v0, v1, v2, v3, v4, v5, ir, w[4]; };
+
 template <int KIND>
-__device__ __forceinline__ void load_body(const Params& P, const float* __restrict__ st, int e,
-                                          int b, bool is_robot, bool is_ball, Body& o,
-                                          float& th_deg, float& om_deg, float w[4]) {
-    using K = KC<KIND>;
+__device__ __forceinline__ RawBody load_raw(const Params& P, const float* __restrict__ st, int e,
+                                            int b, bool is_robot, bool is_ball) {
     constexpr int RS = ModelD<KIND>::rs;
     const size_t B = (size_t)P.num_envs;
+    RawBody r{};
+    if (is_robot || is_ball) {
+        const int row0 = is_ball ? 0 : 5 + RS * b;
+        const int row5 = is_ball ? P.state_dim : row0 + 5;
+        const float* p = st + (size_t)row0 * B + e;
+        r.v0 = p[0]; r.v1 = p[B]; r.v2 = p[2 * B]; r.v3 = p[3 * B]; r.v4 = p[4 * B];
+        r.v5 = st[(size_t)row5 * B + e];
+    }
+    if (KIND == RSX_KIND_SSL && is_robot) {
+        const float* p = st + (size_t)(5 + RS * b + 6) * B + e;
+        r.ir = p[0];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r.w[i] = p[(1 + i) * B];
+    }
+    return r;
+}
+
+// wire values -> the lane's working record (heading in degrees, rate in rad/s, exact sin / cos)
+template <int KIND>
+__device__ __forceinline__ void interpret_body(const RawBody& r, bool is_robot, bool is_ball, Body& o,
+                                               float& th_deg, float& om_deg, float w[4]) {
+    using K = KC<KIND>;
     o = Body{};
     th_deg = 0.0f; om_deg = 0.0f;
     w[0] = w[1] = w[2] = w[3] = 0.0f;
+    o.x = r.v0; o.y = r.v1; o.vx = r.v3; o.vy = r.v4;
     if (is_robot) {
-        const float* r = st + (size_t)(5 + RS * b) * B + e;
-        o.x = r[0]; o.y = r[B]; th_deg = r[2 * B]; o.vx = r[3 * B]; o.vy = r[4 * B];
-        om_deg = r[5 * B];
+        th_deg = r.v2; om_deg = r.v5;
         if (KIND == RSX_KIND_SSL) {
-            o.ir = r[6 * B] != 0.0f;
+            o.ir = r.ir != 0.0f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) w[i] = r[(7 + i) * B];
+            for (int i = 0; i < 4; ++i) w[i] = r.w[i];
         }
         o.th = th_deg;
         o.om = om_deg * K::deg2rad;
         sincos_f32(o.th * K::deg2rad, o.s, o.c);
     } else if (is_ball) {
-        const float* r = st + e;
-        o.x = r[0]; o.y = r[B]; o.z = r[2 * B] - K::r_ball; o.vx = r[3 * B]; o.vy = r[4 * B];
-        o.vz = r[(size_t)P.state_dim * B];
+        o.z = r.v2 - K::r_ball;
+        o.vz = r.v5;
     }
 }
 
@@ -459,7 +483,8 @@ __device__ __forceinline__ void wheel_speeds(const Params& P, const Body& o, flo
     for (int i = 0; i < 4; ++i) w[i] = ((vl * P.wc[i] - vf * P.ws[i]) + o.om * K::r_robot) * K::inv_rw;
 }
 
-// store in wire format; th_deg / om_deg / w are the values to write for a robot
+// store in wire format; th_deg / om_deg / w are the values to write for a robot.  Same row
+// trick as load_raw: one store sequence for both roles.
 template <int KIND>
 __device__ __forceinline__ void store_body(const Params& P, float* __restrict__ st, int e, int b,
                                            bool is_robot, bool is_ball, const Body& o,
@@ -468,18 +493,18 @@ __device__ __forceinline__ void store_body(const Params& P, float* __restrict__ 
     using K = KC<KIND>;
     constexpr int RS = ModelD<KIND>::rs;
     const size_t B = (size_t)P.num_envs;
-    if (is_robot) {
-        float* r = st + (size_t)(5 + RS * b) * B + e;
-        r[0] = o.x; r[B] = o.y; r[2 * B] = th_deg; r[3 * B] = o.vx; r[4 * B] = o.vy; r[5 * B] = om_deg;
-        if (KIND == RSX_KIND_SSL) {
-            if (write_ir) r[6 * B] = o.ir ? 1.0f : 0.0f;
+    if (is_robot || is_ball) {
+        const int row0 = is_ball ? 0 : 5 + RS * b;
+        const int row5 = is_ball ? P.state_dim : row0 + 5;
+        float* p = st + (size_t)row0 * B + e;
+        p[0] = o.x; p[B] = o.y; p[2 * B] = is_ball ? K::r_ball + o.z : th_deg; p[3 * B] = o.vx; p[4 * B] = o.vy;
+        st[(size_t)row5 * B + e] = is_ball ? o.vz : om_deg;
+    }
+    if (KIND == RSX_KIND_SSL && is_robot) {
+        float* p = st + (size_t)(5 + RS * b + 6) * B + e;
+        if (write_ir) p[0] = o.ir ? 1.0f : 0.0f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) r[(7 + i) * B] = w[i];
-        }
-    } else if (is_ball) {
-        float* r = st + e;
-        r[0] = o.x; r[B] = o.y; r[2 * B] = K::r_ball + o.z; r[3 * B] = o.vx; r[4 * B] = o.vy;
-        r[(size_t)P.state_dim * B] = o.vz;
+        for (int i = 0; i < 4; ++i) p[(1 + i) * B] = w[i];
     }
 }
 
@@ -508,14 +533,15 @@ __global__ __launch_bounds__(64) void sim_step_kernel(const Params P, const Buff
     const size_t B = (size_t)P.num_envs;
 
     Body o; float od, wd, w[4];
-    load_body<KIND>(P, bufs.state, e, b, is_robot, is_ball, o, od, wd, w);
+    const RawBody raw = load_raw<KIND>(P, bufs.state, e, b, is_robot, is_ball);
+    float q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (is_robot) {
-        float q[8];
         const float* c = bufs.cmds + (size_t)(b * CD) * B + e;
 #pragma unroll
         for (int i = 0; i < CD; ++i) q[i] = c[i * B];
-        robot_targets<KIND>(P, o, q);
     }
+    interpret_body<KIND>(raw, is_robot, is_ball, o, od, wd, w);
+    if (is_robot) robot_targets<KIND>(P, o, q);
     physics<KIND, L, NR>(P, o, b, g, live, sh);
     if (is_robot) {
         od = o.th; wd = o.om * K::rad2deg;
@@ -732,7 +758,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
     RSX_STAMP(0);
     // ---- load ----
     Body o; float od, wd, wheels[4];
-    load_body<KIND>(P, bufs.state, e, b, is_robot, is_ball, o, od, wd, wheels);
+    const RawBody raw = load_raw<KIND>(P, bufs.state, e, b, is_robot, is_ball);
     int steps = 0; uint32_t episode = 0;
     if (live) {
         steps = __float_as_int(auxe[(size_t)ROW_STEPS * B]);
@@ -767,6 +793,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
     // counters that wait also drains the previous trip's global STORES: one HBM write round
     // trip per env step in the multi-step (rollout) launches.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    interpret_body<KIND>(raw, is_robot, is_ball, o, od, wd, wheels);
     RSX_STAMP(1);
 
     for (int it = 0; it < n_steps; ++it) {
