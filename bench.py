@@ -48,6 +48,23 @@ def usable_cores():
     return max(1, n)
 
 
+def ensure_built(local_rank):
+    """The HIP library normally travels prebuilt (__graft_entry__.build()); on a checkout without
+    it, local rank 0 compiles it (atomic rename) and the other ranks wait for the file."""
+    so = os.path.join(ROOT, "rsoccer_amd", "librsx_hip.so")
+    if os.path.exists(so):
+        return
+    if local_rank == 0:
+        import __graft_entry__ as g
+        g.build()
+        return
+    t0 = time.time()
+    while not os.path.exists(so):
+        if time.time() - t0 > 900:
+            raise SystemExit(f"{so} did not appear (local rank 0 builds it)")
+        time.sleep(0.5)
+
+
 def cpu_baseline(envs, budget_s=12.0, single_s=1.5):
     """Times the CPU oracle (oracle/, float instantiation, OpenMP over envs) on a bounded sample
     of the same workload.  This is the only place bench.py touches oracle/."""
@@ -91,13 +108,14 @@ def main():
     ap.add_argument("--no-rollout", action="store_true", help="skip the extra one-launch rollout leg")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-    from rsoccer_amd import _lib as L
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    ensure_built(local_rank)
+
+    import torch
+    import torch.distributed as dist
+    from rsoccer_amd import _lib as L
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torchrun with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
