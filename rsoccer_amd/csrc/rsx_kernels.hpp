@@ -79,6 +79,9 @@ struct Shared {
     int flag[64 / L];          // episode-end flag per env
     float stage[(64 / L) * 64];  // obs staging, [env][obs_dim], obs_dim <= 64
     float2 draws[64 / L][L < 16 ? 16 : L];  // placement: speculative Philox draws of an ended env
+#ifdef RSX_TIMING
+    unsigned long long* dbg;   // development builds: where the sub-step stamps go (nullptr = none)
+#endif
 };
 
 // clamp a circle (radius r, restitution rest) into the playable region
@@ -281,13 +284,24 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                         any |= t;
                     }
                     if (any) {
+                        // Each lane walks ITS partners in body-index order; lanes with different
+                        // partners share an iteration, so a wave pays for the deepest lane (one
+                        // response, rarely two) instead of one response block per distinct partner
+                        // index present anywhere in the wave.  The wave that finishes last sets a
+                        // single-step launch's duration, and it is always one with contacts.
+                        unsigned todo = 0;
 #pragma unroll
-                        for (int j = 0; j <= NR; ++j) {
+                        for (int j = 0; j <= NR; ++j) todo |= d2s[j] > 0.0f ? 1u << j : 0u;
+                        while (todo) {
+                            const int j = __builtin_ctz(todo);
+                            todo &= todo - 1;
+                            const float4 oj = sh.A[j * G + g];
+                            const float dx = oj.x - o.x, dy = oj.y - o.y;
+                            const float d2 = fma_(dx, dx, dy * dy);   // the value the sweep above saw
                             const bool rb = is_ball || j == NR;
-                            if (d2s[j] > 0.0f)
-                                contact_response(o, oth[j], d2s[j], rb ? K::rs_rb : K::rs_rr, rb ? K::ope_rb : K::ope_rr,
-                                                 is_ball ? K::w_rb_b : (j == NR ? K::w_rb_r : K::w_rr), K::beta,
-                                                 avx, avy, apx, apy);
+                            contact_response(o, oj, d2, rb ? K::rs_rb : K::rs_rr, rb ? K::ope_rb : K::ope_rr,
+                                             is_ball ? K::w_rb_b : (j == NR ? K::w_rb_r : K::w_rr), K::beta,
+                                             avx, avy, apx, apy);
                         }
                     }
                 } else {
@@ -322,11 +336,17 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                         d2s[j] = t ? d2 : -1.0f;
                         any |= t;
                     }
-                    if (any) {
+                    if (any) {   // per-lane partner walk, see the VSS sweep
+                        unsigned todo = 0;
 #pragma unroll
-                        for (int j = 0; j < NR; ++j)
-                            if (d2s[j] > 0.0f)
-                                contact_response(o, oth[j], d2s[j], K::rs_rr, K::ope_rr, K::w_rr, K::beta, avx, avy, apx, apy);
+                        for (int j = 0; j < NR; ++j) todo |= d2s[j] > 0.0f ? 1u << j : 0u;
+                        while (todo) {
+                            const int j = __builtin_ctz(todo);
+                            todo &= todo - 1;
+                            const float4 oj = sh.A[j * G + g];
+                            const float dx = oj.x - o.x, dy = oj.y - o.y;
+                            contact_response(o, oj, fma_(dx, dx, dy * dy), K::rs_rr, K::ope_rr, K::w_rr, K::beta, avx, avy, apx, apy);
+                        }
                     }
                 } else {
                     for (int j = 0; j < N; ++j) {
@@ -414,6 +434,9 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
         if (is_robot || is_ball)
             walls<KIND>(P, is_ball ? K::r_ball : K::r_robot, is_ball ? K::e_wb : K::e_wr, o.x, o.y, o.vx, o.vy);
         wave_sync();  // A / Bq / Cq are rewritten by the next sub-step
+#ifdef RSX_TIMING
+        if (threadIdx.x == 0 && sh.dbg) sh.dbg[(size_t)(8 + sub) * gridDim.x + blockIdx.x] = __builtin_readcyclecounter();
+#endif
     }
 }
 
@@ -524,6 +547,9 @@ __global__ __launch_bounds__(64) void sim_step_kernel(const Params P, const Buff
     constexpr int G = 64 / L;
     constexpr int CD = ModelD<KIND>::cmd_dim;
     __shared__ Shared<L> sh;
+#ifdef RSX_TIMING
+    if (threadIdx.x == 0) sh.dbg = nullptr;
+#endif
     const int lane = threadIdx.x;
     const int b = lane / G, g = lane % G;
     const int e = tile_of_block() * G + g;
@@ -754,6 +780,9 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
 #define RSX_STAMP(i) do { if (lane == 0) bufs.dbg[(size_t)(i) * gridDim.x + blockIdx.x] = __builtin_readcyclecounter(); } while (0)
 #else
 #define RSX_STAMP(i) do {} while (0)
+#endif
+#ifdef RSX_TIMING
+    if (lane == 0) { sh.dbg = bufs.dbg; bufs.dbg[(size_t)13 * gridDim.x + blockIdx.x] = __builtin_amdgcn_s_memrealtime(); }  // 100 MHz, chip-wide
 #endif
     RSX_STAMP(0);
     // ---- load ----
@@ -1112,6 +1141,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
 #ifdef RSX_TIMING
     __builtin_amdgcn_s_waitcnt(0x0F70);
     RSX_STAMP(7);
+    if (lane == 0) bufs.dbg[(size_t)14 * gridDim.x + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 

@@ -21,6 +21,11 @@ def run(B, kind=0, ft=0, nb=3, ny=3, task=1, K=2000):
     sim.close()
     print(f"B={B:8d} kind={kind} N={nb+ny} " + "  ".join(f"{k}: {v[0]:8.2f} us/step {v[1]/1e6:9.1f} M env-steps/s" for k, v in out.items()), "episodes", m[1], flush=True)
 
+if __name__ == "__main__" and len(sys.argv) > 1:
+    for a in sys.argv[1:]:
+        run(int(a), K=2000 if int(a) <= 32768 else 200)
+    sys.exit(0)
+
 if __name__ == "__main__":
     for B in (4096, 32768, 262144, 1048576):
         run(B, K=2000 if B <= 32768 else 200)
