@@ -76,7 +76,6 @@ struct Shared {
     float4 Cq[64];  // SSL robot -> ball record 1: flags, ovx, ovy, ovz
     float zb[64 / L];          // ball height per env
     float x0[64 / L][12];      // robot 0 -> reward lane exchange
-    int flag[64 / L];          // episode-end flag per env
     float stage[(64 / L) * 64];  // obs staging, [env][obs_dim], obs_dim <= 64
     float2 draws[64 / L][L < 16 ? 16 : L];  // placement: speculative Philox draws of an ended env
 #ifdef RSX_TIMING
@@ -1057,9 +1056,10 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
             }
             steps += 1;
             trunc = steps >= P.max_steps;
-            if (is_ball) sh.flag[g] = term | trunc;
-            wave_sync();
-            ended = live && sh.flag[g] != 0;
+            // episode-end flag of the env: held by its ball lane (lane N*G + g), spread with one
+            // ballot instead of an LDS round trip
+            const unsigned long long endm = __ballot(is_ball && (term | trunc));
+            ended = live && ((endm >> (N * G + g)) & 1ull) != 0;
             if (is_ball) {
                 // info is reported as it stands after this step (cleared lazily at the next
                 // episode's first step), like the dict the reference returns with `done`

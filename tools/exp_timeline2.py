@@ -21,7 +21,9 @@ def collect(fn, n):
         fn(); torch.cuda.synchronize()
         acc.append(dbg.cpu().numpy().reshape(NS, nb).astype(np.float64))
     return np.stack(acc)
-for label, fn in (("single-step launch", lambda: sim.task_step(None, s)), ("last step of a 6-step launch", lambda: sim.task_rollout(6, s))):
+for label, fn in (("single-step launch", lambda: sim.task_step(None, s)),
+                  ("single-step launch, last of 50 back-to-back", lambda: sim.task_step_n(50, s)),
+                  ("last step of a 6-step launch", lambda: sim.task_rollout(6, s))):
     d = collect(fn, 100)
     print("==", label)
     seq = [("cmds (philox, OU, targets)", 1, 2), ("sub0", 2, 8), ("sub1", 8, 9), ("sub2", 9, 10), ("sub3", 10, 11), ("sub4", 11, 12),
