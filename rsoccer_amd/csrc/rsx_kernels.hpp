@@ -1087,10 +1087,13 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
                 atomicAdd(&bufs.metrics[5], (unsigned long long)steps);
                 if (trunc && !term) atomicAdd(&bufs.metrics[6], 1ull);
             }
+            RSX_STAMP(15);
             if (ended) place_predraw<L>(P, env_id, episode, b, sh.draws[g]);
             wave_sync();  // draws published; stage rows of ended envs are about to be overwritten
+            RSX_STAMP(16);
             if (ended && is_ball) place_env<TASK, L>(P, N, env_id, episode, g, sh.A, sh.draws[g]);
             wave_sync();
+            RSX_STAMP(17);
             if (ended) {
                 steps = 0; ou0 = 0.0f; ou1 = 0.0f; was_reset = true;
                 if (TASK >= RSX_TASK_SSL_DRIBBLING) prev_pot = 0.0f;  // checkpoints_count / stopped_steps
@@ -1105,6 +1108,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
                 write_obs<KIND, TASK>(P, sh.stage + g * OD, b, is_robot, is_ball, o.x, o.y, o.vx, o.vy, o.s, o.c, wd, 0, 0.0f);
             }
             wave_sync();
+            RSX_STAMP(18);
         }
 
         // ---- observation out, coalesced: the tile's G rows are one contiguous run ----

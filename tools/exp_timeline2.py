@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from rsoccer_amd import _lib as L
 B = int(os.environ.get("B", 4096))
-NS = 16
+NS = 20
 nb = ((B + 7) // 8 + 7) // 8 * 8
 dbg = torch.zeros(NS * nb, dtype=torch.int64, device="cuda")
 torch.cuda.synchronize()
@@ -48,6 +48,11 @@ for label, fn in (("single-step launch", lambda: sim.task_step(None, s)),
         last = d[:, 14].argmax(axis=1)
         print("  the last-finishing wave started at rank %.0f of %d, %.0f ns after the first" % (
             np.mean([(d[i, 13] < d[i, 13, last[i]]).sum() for i in it]), d.shape[2], np.mean(d[it, 13, last] - t0) * 10))
+        rs = d[:, 18] > d[:, 4]     # waves that went through an episode end in this launch
+        if rs.any():
+            for n_, a_, b_ in (("reset: terminal obs + metrics", 4, 15), ("reset: predraw", 15, 16), ("reset: placement", 16, 17), ("reset: new obs", 17, 18), ("obs copy-out after reset", 18, 5)):
+                x = (d[:, b_] - d[:, a_])[rs]
+                print(f"    {n_:34s} mean {x.mean():8.0f} over {rs.sum() / d.shape[0]:.1f} waves per launch")
         print("  wave duration ns: mean %.0f, of the last-finishing wave %.0f" % (((d[:, 14] - d[:, 13]) * 10).mean(), ((d[it, 14, last] - d[it, 13, last]) * 10).mean()))
         print("  last wave to finish (avg over launches), shader cycles per region:")
         for n, a, b in seq:
