@@ -103,22 +103,31 @@ __device__ __forceinline__ void walls(const Params& P, const float r, const floa
         y = hy ? ny : y; vy = fy ? -rest * vy : vy;
         x = hx ? nx : x; vx = fx ? -rest * vx : vx;
     } else {
-        float yl = (P.half_wid + K::margin) - r;
-        if (ay > yl) { y = sy * yl; if (vy * sy > 0.0f) vy = -rest * vy; ay = yl; }
-        float xl = (P.half_len + K::margin) - r;
-        if (ax > xl) { x = sx * xl; if (vx * sx > 0.0f) vx = -rest * vx; ax = xl; }
-        if (ax > P.half_len) {
-            float back = P.half_len + P.gd;
-            if (ay < P.ghw) {
-                if (ax < back) {  // inside the goal
-                    if (ax > back - r) { x = sx * (back - r); if (vx * sx > 0.0f) vx = -rest * vx; }
-                    if (ay > P.ghw - r) { y = sy * (P.ghw - r); if (vy * sy > 0.0f) vy = -rest * vy; }
-                } else if (ax < back + r) {  // behind the back wall
-                    x = sx * (back + r); if (vx * sx < 0.0f) vx = -rest * vx;
-                }
-            } else if (ay < P.ghw + r && ax < back) {  // outside, touching a side wall
-                y = sy * (P.ghw + r); if (vy * sy < 0.0f) vy = -rest * vy;
-            }
+        // predicated like the VSS clamp: conditional stores to x / y / vx / vy inside nested
+        // branches get merged by the compiler into stores through a selected POINTER, which
+        // pins the body's velocity in scratch memory (a global-memory round trip per access)
+        const float yl = (P.half_wid + K::margin) - r, xl = (P.half_len + K::margin) - r;
+        const bool hy = ay > yl;
+        const bool fy0 = hy & (vy * sy > 0.0f);
+        y = hy ? sy * yl : y; vy = fy0 ? -rest * vy : vy; ay = hy ? yl : ay;
+        const bool hx = ax > xl;
+        const bool fx0 = hx & (vx * sx > 0.0f);
+        x = hx ? sx * xl : x; vx = fx0 ? -rest * vx : vx; ax = hx ? xl : ax;
+        if (ax > P.half_len) {   // beyond a goal line: the goal's walls (rare)
+            const float back = P.half_len + P.gd;
+            const bool in_mouth = ay < P.ghw;
+            const bool inside = in_mouth & (ax < back);
+            const bool c1 = inside & (ax > back - r);                       // back wall, from inside
+            const bool c2 = inside & (ay > P.ghw - r);                      // side wall, from inside
+            const bool c3 = in_mouth & !(ax < back) & (ax < back + r);      // behind the back wall
+            const bool c4 = !in_mouth & (ay < P.ghw + r) & (ax < back);     // outside, touching a side wall
+            const float vxs = vx * sx, vys = vy * sy;
+            const bool fx = (c1 & (vxs > 0.0f)) | (c3 & (vxs < 0.0f));
+            const bool fy = (c2 & (vys > 0.0f)) | (c4 & (vys < 0.0f));
+            x = c1 ? sx * (back - r) : (c3 ? sx * (back + r) : x);
+            y = c2 ? sy * (P.ghw - r) : (c4 ? sy * (P.ghw + r) : y);
+            vx = fx ? -rest * vx : vx;
+            vy = fy ? -rest * vy : vy;
         }
     }
 }

@@ -10,7 +10,8 @@ nb = ((B + 7) // 8 + 7) // 8 * 8
 dbg = torch.zeros(NS * nb, dtype=torch.int64, device="cuda")
 torch.cuda.synchronize()
 L.load().rsx_dbg_set(ctypes.c_void_p(dbg.data_ptr()))
-sim = L.Sim(0, 0, 3, 3, 25, B); sim.task_attach(1, 0, 0, 1 << 30); sim.task_reset()
+CFG = {"vss": (0, 0, 3, 3, 1), "sd": (1, 2, 1, 6, 2), "drib": (1, 2, 1, 4, 3), "cont": (1, 2, 1, 1, 4), "pass": (1, 2, 2, 0, 5)}[os.environ.get("CFG", "vss")]
+sim = L.Sim(CFG[0], CFG[1], CFG[2], CFG[3], 25, B); sim.task_attach(CFG[4], 0, 0, 0); sim.task_reset()
 s = torch.cuda.current_stream().cuda_stream
 sim.task_step_n(500, s); torch.cuda.synchronize()
 names = ["entry", "loads landed", "cmds done", "physics done", "epilogue done", "before stores", "stores issued", "stores acked",
