@@ -748,6 +748,98 @@ __device__ __forceinline__ void place_env(const Params& P, const int N, uint32_t
     }
 }
 
+// The same placement, run by all lanes of the env together (VSS-v0 and static defenders, whose
+// placements are rejection loops).  The sequential algorithm consumes draws in order, so the
+// draw index of robot k depends on how many candidates were rejected before it; here every
+// robot k >= m (m = first robot not yet fixed) proposes its candidate ASSUMING no further
+// rejection (draw n + 2(k-m) for the position, the next one for theta), each tests itself against
+// the ball and all robots q < k (fixed or proposed), and the lowest failing robot f decides:
+// m..f-1 were tested against accepted poses only, exactly as the sequential loop would have, and
+// are fixed; f has used one more try and the draw indices behind it shift by one; robots > f
+// propose again.  One round per rejection (+1) instead of ~2N dependent LDS round trips on a
+// single lane; draws, candidates, tests and therefore results are those of place_env.
+template <int TASK, int L, int NRC>
+__device__ __forceinline__ float4 place_env_parallel(const Params& P, const int N, const uint32_t env_id,
+                                                      const uint32_t episode, const int b, const int g,
+                                                      const bool is_robot, float4* A, const float2* draws) {
+    constexpr int G = 64 / L;
+    constexpr int NPRE = L < 16 ? 16 : L;
+    auto getdraw = [&](uint32_t i) -> float2 {
+        if (i < (uint32_t)NPRE) return draws[i];
+        const u32x4 u = philox4x32_10(env_id, episode, i, DOM_PLACE, P.key0, P.key1);
+        return make_float2(u01(u.x), u01(u.y));
+    };
+    uint32_t n = 0;
+    float bx = 0.0f, by = 0.0f;
+    int m = 0;
+    float x = 0.0f, y = 0.0f, th = 0.0f;   // this lane's robot
+    if (TASK == RSX_TASK_SSL_STATIC_DEFENDERS) {
+        for (int t = 0; t < 64; ++t) {
+            const float2 u = getdraw(n++);
+            bx = P.pl_xlo + P.pl_xspan * u.x;
+            by = P.pl_ylo + P.pl_yspan * u.y;
+            if (!(bx > P.pen_x && fabsf(by) < P.half_pen_wid)) break;
+        }
+        if (b == 0) A[0 * G + g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // blue 0 at the origin
+        m = 1;
+    } else {
+        const float2 u = getdraw(n++);
+        bx = P.pl_xlo + P.pl_xspan * u.x;
+        by = P.pl_ylo + P.pl_yspan * u.y;
+    }
+    // lanes of this env: body j sits at lane j * G + g
+    unsigned long long envmask = 0;
+#pragma unroll
+    for (int j = 0; j < L; ++j) envmask |= 1ull << (j * G);
+    envmask <<= g;
+    int t = 0;   // tries robot m has used
+    while (m < N) {
+        const bool spec = is_robot && b >= m;
+        if (spec) {
+            const uint32_t c = n + 2u * (uint32_t)(b - m);
+            const float2 u = getdraw(c), v = getdraw(c + 1u);
+            x = P.pl_xlo + P.pl_xspan * u.x;
+            y = P.pl_ylo + P.pl_yspan * u.y;
+            th = 360.0f * v.x;
+            A[b * G + g] = make_float4(x, y, th, 0.0f);
+        }
+        wave_sync();
+        bool bad = false;
+        if (spec) {
+            {
+                float dx = x - bx, dy = y - by;
+                if (dx * dx + dy * dy < P.pl_min_d2) bad = true;
+            }
+            if (NRC) {
+                float4 pq[NRC ? NRC : 1];
+#pragma unroll
+                for (int q = 0; q < NRC; ++q) pq[q] = A[q * G + g];
+#pragma unroll
+                for (int q = 0; q < NRC; ++q) {
+                    float dx = x - pq[q].x, dy = y - pq[q].y;
+                    if ((q < b) & (dx * dx + dy * dy < P.pl_min_d2)) bad = true;
+                }
+            } else {
+                for (int q = 0; q < b; ++q) {
+                    const float4 pq = A[q * G + g];
+                    float dx = x - pq.x, dy = y - pq.y;
+                    if (dx * dx + dy * dy < P.pl_min_d2) bad = true;
+                }
+            }
+            if (b == m && t == 63) bad = false;   // the 64th candidate is taken as it is
+        }
+        wave_sync();   // the next round overwrites A
+        const unsigned long long bm = __ballot(bad) & envmask;
+        const int f = bm ? (int)(__builtin_ctzll(bm) / G) : N;   // lowest failing robot
+        if (f < N) {
+            t = f == m ? t + 1 : 1;
+            n += 2u * (uint32_t)(f - m) + 1u;
+        }
+        m = f;
+    }
+    return is_robot ? make_float4(x, y, th, 0.0f) : make_float4(bx, by, 0.0f, 0.0f);
+}
+
 // MODE (compile-time, so the per-step launch carries no loop and none of the reset-only code):
 //   MODE_STEP    one step(action) per launch
 //   MODE_ROLLOUT n_steps random-action steps per launch (state stays in registers)
@@ -1100,14 +1192,22 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
             if (ended) place_predraw<L>(P, env_id, episode, b, sh.draws[g]);
             wave_sync();  // draws published; stage rows of ended envs are about to be overwritten
             RSX_STAMP(16);
-            if (ended && is_ball) place_env<TASK, L>(P, N, env_id, episode, g, sh.A, sh.draws[g]);
-            wave_sync();
+            float4 pz = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            // A single-step launch waits for its slowest wave, which is one that resets an env:
+            // there the placement runs in its parallel form.  A multi-step launch pays for the
+            // average wave instead, and the sequential form issues fewer instructions.
+            if ((TASK == RSX_TASK_VSS_V0 || TASK == RSX_TASK_SSL_STATIC_DEFENDERS) && MODE != MODE_ROLLOUT) {
+                if (ended) pz = place_env_parallel<TASK, L, NR>(P, N, env_id, episode, b, g, is_robot, sh.A, sh.draws[g]);
+            } else {
+                if (ended && is_ball) place_env<TASK, L>(P, N, env_id, episode, g, sh.A, sh.draws[g]);
+                wave_sync();
+                if (ended && (is_robot || is_ball)) pz = sh.A[b * G + g];
+            }
             RSX_STAMP(17);
             if (ended) {
                 steps = 0; ou0 = 0.0f; ou1 = 0.0f; was_reset = true;
                 if (TASK >= RSX_TASK_SSL_DRIBBLING) prev_pot = 0.0f;  // checkpoints_count / stopped_steps
                 if (is_robot || is_ball) {
-                    const float4 pz = sh.A[b * G + g];
                     o = Body{};
                     o.x = pz.x; o.y = pz.y;
                     od = pz.z; wd = 0.0f;

@@ -43,7 +43,7 @@ for label, fn in (("single-step launch", lambda: sim.task_step(None, s)),
         t0 = d[:, 13].min(axis=1)
         st = np.sort(d[:, 13] - t0[:, None], axis=1).mean(axis=0) * 10.0
         en = np.sort(d[:, 14] - t0[:, None], axis=1).mean(axis=0) * 10.0
-        q = [0, 1, 2, 4, 8, 16, 32, 64, 128, 256, 384, 448, 496, len(st) - 1]
+        q = [i for i in (0, 1, 2, 4, 8, 16, 32, 64, 128, 256, 384, 448, 496) if i < len(st) - 1] + [len(st) - 1]
         print("  wave start offsets ns (sorted, avg): ", [int(st[i]) for i in q])
         print("  wave end offsets ns   (sorted, avg): ", [int(en[i]) for i in q])
         last = d[:, 14].argmax(axis=1)
