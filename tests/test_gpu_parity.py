@@ -192,6 +192,38 @@ def test_task_fed_actions_and_modes_bitexact(oracle_mod, task, kind, ft, nb, ny,
     sim.close()
 
 
+@pytest.mark.parametrize("task,kind,ft,nb,ny", [(1, 0, 0, 3, 3), (2, 1, 2, 1, 6), (1, 0, 1, 5, 5)])
+def test_many_resets_placement_bitexact(oracle_mod, task, kind, ft, nb, ny):
+    """TimeLimit = 1: every env is re-placed in every step, 20k+ placements per case.  The kernel
+    places in parallel rounds (one per rejection), the oracle with the reference's sequential
+    rejection loop (vss_gym.py:194-233, static_defenders.py:214-254); this many placements reach
+    several rejections in one env and draw indices beyond the pre-drawn block."""
+    import torch
+    L = _lib()
+    O = oracle_mod
+    B, steps, seed = 2048, 10, 99
+    sim = L.Sim(kind, ft, nb, ny, 25, B)
+    sim.task_attach(task, seed, 0, 1)
+    tens = sim.task_tensors()
+    refs = _mk_oracles(O, kind, ft, nb, ny, B)
+    for e, r in enumerate(refs):
+        r.task_attach(task, seed, e, 1)
+        r.task_reset()
+    sim.task_reset()
+    for t in range(steps):
+        sim.task_step(None)
+        O.vec_task_step(refs, 1)
+        torch.cuda.synchronize()
+        st = sim.get_state_full()
+        obs = tens["obs"].cpu().numpy()
+        want = np.stack([r.get_state_full() for r in refs])
+        assert f32_equal(st, want), mismatch_report(st, want, f"state after step {t}")
+        wobs = np.stack([r.task_out()["obs"] for r in refs])
+        assert f32_equal(obs, wobs), mismatch_report(obs, wobs, f"obs after step {t}")
+    assert sim.read_metrics()[1] == B * steps
+    sim.close()
+
+
 def test_batch_position_and_shard_invariance():
     """env i's trajectory depends only on (seed, global env id): not on batch size, position
     in the batch, or how the batch is split over handles (= over GPUs)."""
