@@ -329,6 +329,7 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
         } else {
             bool ovr = false, okick = false;
             float ovx = 0.0f, ovy = 0.0f, ovz = 0.0f;
+            int fl = 0;   // what this robot does to the ball in this sub-step (0 = nothing)
             if (is_robot) {
                 if (NR) {
                     float4 oth[NR ? NR : 1];  // all reads in flight together, one wait
@@ -381,7 +382,6 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                     }
                 }
                 float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                int fl = 0;
                 if (touch) {
                     float vn = fma_(ob.z - o.vx, nx, (ob.w - o.vy) * ny);
                     if (vn < 0.0f) {
@@ -408,26 +408,30 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                     }
                 }
                 r1.x = __int_as_float(fl);
-                if (fl) sh.Bq[lane] = r0;
-                sh.Cq[lane] = r1;
+                if (fl) { sh.Bq[lane] = r0; sh.Cq[lane] = r1; }
             }
+            // which robots wrote a record: one ballot; the ball lane visits only those, in index
+            // order (usually none: no LDS read at all on the ball's side)
+            const unsigned long long wrote = __ballot(fl != 0);
             wave_sync();
             if (is_ball) {
-                auto take = [&](int j) {  // ball: sum the robots' records in index order
-                    const float4 r1 = sh.Cq[j * G + g];
-                    const int fl = __float_as_int(r1.x);
-                    if (fl) {
-                        const float4 r0 = sh.Bq[j * G + g];
-                        if (fl & 1) { avx = avx - r0.x; avy = avy - r0.y; }
-                        if (fl & 2) { apx = apx + r0.z; apy = apy + r0.w; }
-                        if (fl & 4) { ovr = true; okick = (fl & 8) != 0; ovx = r1.y; ovy = r1.z; ovz = r1.w; }
-                    }
-                };
-                if (NR) {
+                unsigned long long todo = 0;   // lanes j * G + g, j < N
+                if (L <= 32) {
 #pragma unroll
-                    for (int j = 0; j < NR; ++j) take(j);
+                    for (int j = 0; j < L; ++j) todo |= 1ull << (j * G);
+                    todo = (todo << g) & wrote;
                 } else {
-                    for (int j = 0; j < N; ++j) take(j);
+                    todo = wrote;   // one env per wave
+                }
+                while (todo) {
+                    const int lj = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const float4 r1 = sh.Cq[lj];
+                    const float4 r0 = sh.Bq[lj];
+                    const int flj = __float_as_int(r1.x);
+                    if (flj & 1) { avx = avx - r0.x; avy = avy - r0.y; }
+                    if (flj & 2) { apx = apx + r0.z; apy = apy + r0.w; }
+                    if (flj & 4) { ovr = true; okick = (flj & 8) != 0; ovx = r1.y; ovy = r1.z; ovz = r1.w; }
                 }
             }
             o.vx = o.vx + avx; o.vy = o.vy + avy;
