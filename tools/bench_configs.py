@@ -73,10 +73,30 @@ for B in (256, 1024, 16384, 65536, 262144, 1048576, 4194304):
 for B in (16384, 262144):
     fused("sweep SSLStaticDefenders-v0 fused", 1, 2, 1, 6, 2, B, 981, K=500 if B <= 65536 else 100)
 
+# The robosim-shaped host path (rsx_step + rsx_get_state): float64 host arrays in and out, i.e.
+# the PCIe-inclusive rate of the boundary when a caller keeps its data on the host.
+host_rows = []
+for kind, ft, nb, ny, B in ((0, 0, 3, 3, 1), (0, 0, 3, 3, 4096), (1, 2, 1, 6, 2048)):
+    sim = L.Sim(kind, ft, nb, ny, 25, B)
+    N, C = nb + ny, (2 if kind == 0 else 8)
+    cmds = np.random.default_rng(1).uniform(-1, 1, (B, N, C)) * (30.0 if kind == 0 else 1.0)
+    if kind == 1:
+        cmds[..., 0] = 0.0; cmds[..., 5:] = 0.0
+    def run(n):
+        for _ in range(n):
+            sim.step(cmds); sim.get_state()
+    us = timeit(run, 300)
+    host_rows.append((("VSS 3v3" if kind == 0 else "SSL 1v6"), B, us, B / us))
+    sim.close()
+
 lines = ["| config | envs | us / step (1 launch per step) | M env-steps/s | algorithmic GB/s | frac of 8 TB/s | us / step (one launch) | M env-steps/s (one launch) |",
          "|---|---|---|---|---|---|---|---|"]
 for name, B, us, rate, gbs, ur, rr in rows:
     lines.append(f"| {name} | {B} | {us:.2f} | {rate:.1f} | {gbs:.1f} | {gbs / 8000 * 100:.2f} % | {ur:.2f} | {rr:.1f} |")
+lines += ["", "Host-format path (`rsx_step` + `rsx_get_state`, float64 host arrays, synchronous, PCIe both ways):", "",
+          "| simulator | envs | us / step+get_state | M env-steps/s |", "|---|---|---|---|"]
+for name, B, us, rate in host_rows:
+    lines.append(f"| {name} | {B} | {us:.1f} | {rate:.3f} |")
 text = "\n".join(lines)
 print(text)
 if len(sys.argv) > 1:
