@@ -224,6 +224,51 @@ def test_many_resets_placement_bitexact(oracle_mod, task, kind, ft, nb, ny):
     sim.close()
 
 
+@pytest.mark.parametrize("task,kind,ft,nb,ny,B,steps", [(1, 0, 0, 3, 3, 4096, 6000), (2, 1, 2, 1, 6, 2048, 3000),
+                                                       (3, 1, 2, 1, 4, 2048, 2000), (4, 1, 2, 1, 1, 2048, 2000),
+                                                       (5, 1, 2, 2, 0, 2048, 2000)])
+def test_full_size_soak_invariants(task, kind, ft, nb, ny, B, steps):
+    """BASELINE.json's batch sizes, thousands of steps (tens of millions of env-steps, thousands of
+    contacts and resets): size-independent properties instead of the oracle.  Everything stays
+    finite, bodies stay inside the walls, observations inside the clip range, the counters add up,
+    and a second run from the same seed reproduces every buffer bit for bit."""
+    import torch
+    L = _lib()
+    out = []
+    for rep in range(2):
+        sim = L.Sim(kind, ft, nb, ny, 25, B)
+        sim.task_attach(task, 4242, 0, 0)
+        tens = sim.task_tensors()
+        sim.task_reset()
+        done_seen = 0
+        for chunk in range(steps // 500):
+            sim.task_step_n(499)
+            sim.task_step(None)
+            torch.cuda.synchronize()
+            done_seen += int((tens["terminated"] | tens["truncated"]).sum().item())   # sampled every 500th step
+            obs = tens["obs"]
+            assert torch.isfinite(obs).all() and obs.abs().max().item() <= float(np.float32(1.2))
+            assert torch.isfinite(tens["reward"]).all()
+        st = sim.get_state_full()
+        assert np.isfinite(st).all()
+        f = sim.get_field_params()
+        margin = 0.0 if kind == 0 else 0.35
+        xmax = f["length"] / 2 + f["goal_depth"] + margin + 1e-4
+        ymax = f["width"] / 2 + margin + 1e-4
+        N = nb + ny
+        rs = 6 if kind == 0 else 11
+        xs = np.concatenate([st[:, 0:1]] + [st[:, 5 + rs * k: 6 + rs * k] for k in range(N)], 1)
+        ys = np.concatenate([st[:, 1:2]] + [st[:, 6 + rs * k: 7 + rs * k] for k in range(N)], 1)
+        assert np.abs(xs).max() <= xmax and np.abs(ys).max() <= ymax, (np.abs(xs).max(), np.abs(ys).max())
+        th = np.stack([st[:, 7 + rs * k] for k in range(N)], 1)
+        assert np.abs(th).max() <= 360.0
+        m = sim.read_metrics()
+        assert m[0] == B * steps and m[1] > 0 and m[5] <= m[0] and m[6] <= m[1]
+        out.append(np.concatenate([st.ravel(), tens["obs"].cpu().numpy().astype(np.float64).ravel(), m.astype(np.float64)]))
+        sim.close()
+    assert np.array_equal(out[0], out[1])
+
+
 def test_batch_position_and_shard_invariance():
     """env i's trajectory depends only on (seed, global env id): not on batch size, position
     in the batch, or how the batch is split over handles (= over GPUs)."""
