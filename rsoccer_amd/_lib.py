@@ -249,9 +249,11 @@ class Sim:
                                          self._stream(stream)))
 
     def task_step(self, actions_ptr=None, stream=None):
-        """actions_ptr: device address of a [B][act_dim] float32 array, or None = random."""
-        p = None if actions_ptr is None else C.c_void_p(int(actions_ptr))
-        _chk(self._lib.rsx_task_step(self._h, p, self._stream(stream)))
+        """actions_ptr: device address of a [B][act_dim] float32 array, or None = random.
+        Hot path of the Python API: plain ints go straight to ctypes (argtypes are c_void_p)."""
+        rc = self._lib.rsx_task_step(self._h, actions_ptr, stream)
+        if rc:
+            _chk(rc)
 
     def task_step_n(self, n, stream=None):
         _chk(self._lib.rsx_task_step_n(self._h, int(n), self._stream(stream)))

@@ -171,6 +171,8 @@ void launch_task(const rsx_sim* h, const float* actions, int n_steps, int mode, 
 
 int check(const rsx_sim* h) {
     if (!h) return fail(RSX_ERR_ARG, "null handle");
+    int cur = -1;   // the per-step calls come through here: switch devices only when needed
+    if (hipGetDevice(&cur) == hipSuccess && cur == h->device) return RSX_OK;
     hipError_t e = hipSetDevice(h->device);
     if (e != hipSuccess) return fail(RSX_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
     return RSX_OK;

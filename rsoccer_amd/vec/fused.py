@@ -43,6 +43,7 @@ class VecFusedEnv:
         self.sim.task_attach(self.TASK, int(seed), int(env_id_base), int(max_episode_steps or 0))
         self.max_episode_steps = self.sim.max_episode_steps
         self._t = self.sim.task_tensors()
+        self._info_views = None
         self.field = self.sim.get_field_params()
         self.single_action_space = gym.spaces.Box(low=-1, high=1, shape=(self.sim.act_dim,), dtype=np.float32)
         self.single_observation_space = gym.spaces.Box(low=-1.2, high=1.2, shape=(self.sim.obs_dim,), dtype=np.float32)
@@ -50,14 +51,23 @@ class VecFusedEnv:
 
     # ---- gym-like surface ----
     def _stream(self):
-        return self._torch.cuda.current_stream(self.device).cuda_stream
+        # raw handle of torch's current stream on the env's device (the private getter skips the
+        # Stream object; the public API is the fallback)
+        try:
+            return self._torch._C._cuda_getCurrentRawStream(self.device.index)
+        except AttributeError:
+            return self._torch.cuda.current_stream(self.device).cuda_stream
 
     def _info(self):
-        t = self._t
-        info = {k: t["info"][i] for i, k in enumerate(self.INFO_KEYS)}
-        info["final_obs"] = t["final_obs"]
-        info["episode_steps"] = t["steps"]
-        return info
+        """The info dict of step(): tensor VIEWS of the engine's buffers, so one dict serves every
+        step (a fresh shallow copy is returned: callers may add keys)."""
+        if self._info_views is None:
+            t = self._t
+            info = {k: t["info"][i] for i, k in enumerate(self.INFO_KEYS)}
+            info["final_obs"] = t["final_obs"]
+            info["episode_steps"] = t["steps"]
+            self._info_views = info
+        return dict(self._info_views)
 
     def reset(self, *, seed=None, options=None):
         """New random placement for every env.  ``seed`` is accepted for API compatibility; the
