@@ -137,12 +137,24 @@ class Sim:
         self.kind, self.field_type = kind, field_type
         self.n_blue, self.n_yellow = n_blue, n_yellow
         self.num_envs, self.device_id = int(num_envs), int(device_id)
-        v = DevView()
-        _chk(self._lib.rsx_dev_view_get(self._h, C.byref(v)))
-        self.n_robots, self.state_dim, self.cmd_dim = v.n_robots, v.state_dim, v.cmd_dim
-        self._view = v
+        self.n_robots = n_blue + n_yellow
+        self.cmd_dim = 2 if kind == KIND_VSS else 8              # rsim.py:92-101 / :137-153
+        self.state_dim = 5 + (6 if kind == KIND_VSS else 11) * self.n_robots   # Entities/Frame.py:20-47,55-92
+        self._view_cache = None   # raw device pointers are fetched on first use (see _view)
         self._tview = None
         self.task = TASK_NONE
+
+    @property
+    def _view(self):
+        # asking for the raw pointers tells the library that the state can change behind its back
+        # (it then stops serving rsx_get_state from the copy rsx_step brought home), so the
+        # single-env robosim classes, which never touch device memory, do not ask
+        if self._view_cache is None:
+            v = DevView()
+            _chk(self._lib.rsx_dev_view_get(self._h, C.byref(v)))
+            assert (v.n_robots, v.state_dim, v.cmd_dim) == (self.n_robots, self.state_dim, self.cmd_dim)
+            self._view_cache = v
+        return self._view_cache
 
     # ---- lifetime ----
     def close(self):

@@ -50,6 +50,14 @@ struct rsx_sim {
     hipStream_t cap_stream = nullptr;
     std::map<int, hipGraphExec_t> graphs;
     std::vector<float> h_f32;
+    // host-format path: pinned staging; rsx_step() brings the new state back with its own
+    // synchronisation, so the rsx_get_state() that follows it (rsim.py:102 then :105) is a pure
+    // host conversion.  The copy is trusted only while every state change went through this API:
+    // handing out raw device pointers (rsx_dev_view_get) switches the shortcut off for good.
+    float* pin_cmds = nullptr;
+    float* pin_state = nullptr;
+    bool host_state_valid = false;
+    bool host_state_cache = true;
 };
 
 namespace {
@@ -178,14 +186,16 @@ int check(const rsx_sim* h) {
     return RSX_OK;
 }
 
-int check_task(const rsx_sim* h) {
+int check_task(rsx_sim* h) {
     if (int rc = check(h)) return rc;
+    h->host_state_valid = false;   // every task call may change the state
     if (h->P.task == RSX_TASK_NONE) return fail(RSX_ERR_STATE, "no task attached (rsx_task_attach)");
     return RSX_OK;
 }
 
 // host f64 AoS [B][S'] <-> device f32 SoA [S'][B]
 int upload_state(rsx_sim* h, const std::vector<float>& soa, hipStream_t s) {
+    h->host_state_valid = false;
     HIP_TRY(hipMemcpyAsync(h->d_state, soa.data(), soa.size() * sizeof(float), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));
     return RSX_OK;
@@ -223,6 +233,9 @@ void free_all(rsx_sim* h) {
     for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
     h->graphs.clear();
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    if (h->pin_cmds) (void)hipHostFree(h->pin_cmds);
+    if (h->pin_state) (void)hipHostFree(h->pin_state);
+    h->pin_cmds = h->pin_state = nullptr;
     if (h->arena_sim) (void)hipFree(h->arena_sim);
     if (h->arena_task) (void)hipFree(h->arena_task);
     h->arena_sim = h->arena_task = nullptr;
@@ -277,6 +290,8 @@ int rsx_create(rsx_sim** out, int kind, int field_type, int n_blue, int n_yellow
     h->d_state = (float*)h->arena_sim;
     h->d_cmds = (float*)(h->arena_sim + align_up(sbytes));
     if ((e = hipMemset(h->d_cmds, 0, cbytes)) != hipSuccess) return bail(e, "hipMemset(cmds)");
+    if ((e = hipHostMalloc((void**)&h->pin_cmds, cbytes ? cbytes : 4, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc(cmds)");
+    if ((e = hipHostMalloc((void**)&h->pin_state, sbytes, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc(state)");
     if ((e = hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     // the adapter's dummy line-up, rsim.py:20-24
     std::vector<float> soa((size_t)(h->P.state_dim + 1) * B, 0.0f);
@@ -324,20 +339,27 @@ int rsx_step(rsx_sim* h, const double* cmds, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const Params& P = h->P;
     const size_t B = (size_t)P.num_envs, NC = (size_t)P.n_robots * h->M.cmd_dim;
-    h->h_f32.resize(NC * B);
     for (size_t e = 0; e < B; ++e)
-        for (size_t j = 0; j < NC; ++j) h->h_f32[j * B + e] = (float)cmds[e * NC + j];
-    HIP_TRY(hipMemcpyAsync(h->d_cmds, h->h_f32.data(), NC * B * sizeof(float), hipMemcpyHostToDevice, s));
+        for (size_t j = 0; j < NC; ++j) h->pin_cmds[j * B + e] = (float)cmds[e * NC + j];
+    h->host_state_valid = false;
+    HIP_TRY(hipMemcpyAsync(h->d_cmds, h->pin_cmds, NC * B * sizeof(float), hipMemcpyHostToDevice, s));
     launch_sim(h, s);
     HIP_TRY(hipGetLastError());
+    if (h->host_state_cache)
+        HIP_TRY(hipMemcpyAsync(h->pin_state, h->d_state, (size_t)(P.state_dim + 1) * B * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    h->host_state_valid = h->host_state_cache;
     return RSX_OK;
 }
 
 static int get_state_impl(rsx_sim* h, double* out, int rows, hipStream_t s) {
-    std::vector<float> soa;
-    if (int rc = download_state(h, soa, s)) return rc;
     const size_t B = (size_t)h->P.num_envs;
+    if (!h->host_state_valid) {
+        HIP_TRY(hipMemcpyAsync(h->pin_state, h->d_state, (size_t)(h->P.state_dim + 1) * B * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        h->host_state_valid = h->host_state_cache;
+    }
+    const float* soa = h->pin_state;
     for (size_t e = 0; e < B; ++e)
         for (int f = 0; f < rows; ++f) out[e * rows + f] = (double)soa[(size_t)f * B + e];
     return RSX_OK;
@@ -371,11 +393,13 @@ int rsx_dev_view_get(rsx_sim* h, rsx_dev_view* out) {
     out->num_envs = h->P.num_envs; out->n_robots = h->P.n_robots;
     out->state_dim = h->P.state_dim; out->cmd_dim = h->M.cmd_dim;
     out->state = h->d_state; out->cmds = h->d_cmds;
+    h->host_state_cache = false; h->host_state_valid = false;   // the caller can now write the state behind our back
     return RSX_OK;
 }
 
 int rsx_step_dev(rsx_sim* h, void* stream) {
     if (int rc = check(h)) return rc;
+    h->host_state_valid = false;
     launch_sim(h, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return RSX_OK;
