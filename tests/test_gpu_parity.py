@@ -387,6 +387,30 @@ def test_one_wavefront_per_env_layout_gives_identical_results():
     assert np.array_equal(res[0], res[1])
 
 
+def test_get_state_after_device_side_writes_is_not_served_from_the_step_copy():
+    """rsx_step brings the new state home for the rsx_get_state that follows it; that copy must
+    not survive a change made behind the host API (torch writing through the device view, a
+    device-side step, a fused task step)."""
+    import torch
+    L = _lib()
+    sim = L.Sim(0, 0, 3, 3, 25, 5)
+    cmds = np.zeros((5, 6, 2))
+    sim.step(cmds)
+    a = sim.get_state()
+    sim.step_dev()                       # device-side step: state changes without the host path
+    sim.step(cmds)
+    st = sim.state_tensor()              # raw pointers handed out
+    st[0, :] = 0.123                     # ball x of every env, written by torch
+    torch.cuda.synchronize()
+    b = sim.get_state()
+    assert np.allclose(b[:, 0], 0.123) and not np.allclose(a[:, 0], 0.123)
+    sim.step(cmds)
+    st[1, :] = -0.2
+    torch.cuda.synchronize()
+    assert np.allclose(sim.get_state()[:, 1], -0.2)
+    sim.close()
+
+
 def test_api_errors_are_reported_not_crashed():
     L = _lib()
     sim = L.Sim(0, 0, 3, 3, 25, 8)
