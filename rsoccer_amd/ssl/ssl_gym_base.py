@@ -11,3 +11,4 @@ from rsoccer_amd.vss.vss_gym_base import VSSBaseEnv
 class SSLBaseEnv(VSSBaseEnv):
     _SIM_ADAPTER = RSimSSL
     _LEVER_ARM = 0.095
+    _RENDER_VIEW = "SSL_VIEW"   # Render/field.py:252-264

@@ -23,6 +23,7 @@ class VSSBaseEnv(gym.Env):
                 "render_fps": 60, "render.fps": 60}
     NORM_BOUNDS = 1.2
     _SIM_ADAPTER = RSimVSS
+    _RENDER_VIEW = "VSS_VIEW"   # Render/field.py:189-201
     _LEVER_ARM = 0.04  # robot radius 0.0375 + wheel thickness 0.0025 (vss_gym_base.py:57-58)
 
     def __init__(self, field_type: int, n_robots_blue: int, n_robots_yellow: int, time_step: float,
@@ -73,8 +74,18 @@ class VSSBaseEnv(gym.Env):
         return obs, {}
 
     def render(self):
-        raise NotImplementedError(
-            "rendering (pygame) is outside the scope of the step engine; run with render_mode=None")
+        """``rgb_array``: the current frame as uint8 [H, W, 3] in the reference's window geometry
+        (numpy rasteriser, rsoccer_amd/Render/raster.py).  ``human`` needs pygame and a display,
+        which are outside the scope of the step engine."""
+        if self.render_mode != "rgb_array":
+            raise NotImplementedError(
+                "render_mode='human' (pygame window) is outside the scope of the step engine; "
+                "use render_mode='rgb_array' or None")
+        if getattr(self, "_raster", None) is None:
+            from rsoccer_amd import Render
+            self._raster = Render.FieldRaster(getattr(Render, self._RENDER_VIEW))
+            self.window_size = self._raster.window_size
+        return self._raster.draw(self.frame)
 
     def close(self):
         if self.rsim is not None:

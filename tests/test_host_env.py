@@ -311,3 +311,36 @@ def test_all_five_reference_ids_are_registered():
         assert rsoccer_amd.registry[env_id]["kwargs"] == spec["kwargs"]
         # same class name behind the id as in the reference
         assert rsoccer_amd.registry[env_id]["entry_point"].split(":")[1] == spec["entry_point"].split(":")[1]
+
+
+def test_rgb_array_render_has_the_reference_window_geometry(oracle_mod):
+    """render_mode='rgb_array' (numpy rasteriser): the frame shapes of the reference's pygame
+    surfaces (Render/field.py:189-264 -> VSS 750 x 850, SSL 670 x 970), robots and ball drawn
+    where the world -> pixel map of vss_gym_base.py:110-113 puts them; 'human' is refused."""
+    from rsoccer_amd.Render.raster import BALL, BLUE, YELLOW
+    from rsoccer_amd.ssl.ssl_hw_challenge import SSLHWStaticDefendersEnv
+    from rsoccer_amd.vss.env_vss import VSSEnv
+    fake_robosim.arm()
+    env = VSSEnv(render_mode="rgb_array", sim_backend=fake_robosim)
+    env.reset(seed=3)
+    img = env.render()
+    assert img.shape == (750, 850, 3) and img.dtype == np.uint8
+    bx = int(env.frame.ball.x * 500 + 425)
+    by = int(env.frame.ball.y * 500 + 375)
+    assert tuple(img[by, bx]) == BALL
+    assert (img == np.array(BLUE, np.uint8)).all(-1).sum() > 3 * 1000      # three 40 x 40 px robots
+    assert (img == np.array(YELLOW, np.uint8)).all(-1).sum() > 3 * 1000
+    env.step(env.action_space.sample())
+    assert env.render().shape == (750, 850, 3)
+    env.close()
+    fake_robosim.arm()
+    env = SSLHWStaticDefendersEnv(field_type=2, render_mode="rgb_array", sim_backend=fake_robosim)
+    env.reset(seed=1)
+    assert env.render().shape == (670, 970, 3)
+    env.close()
+    fake_robosim.arm()
+    env = VSSEnv(render_mode=None, sim_backend=fake_robosim)
+    env.reset(seed=0)
+    with pytest.raises(NotImplementedError):
+        env.render()
+    env.close()
