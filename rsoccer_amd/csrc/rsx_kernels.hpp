@@ -657,10 +657,20 @@ __device__ __forceinline__ float vss_wheel(float a) {
 // env's ball lane; the expensive part, the Philox blocks, is hoisted: draws 0..NPRE-1 were
 // computed speculatively by all lanes of the env (place_predraw) and are only read here.
 // Poses go to A[body slot] = (x, y, theta_deg, 0).
-template <int L>
+// how many placement draws are computed ahead by the env's lanes: the rejection-sampled tasks
+// use >= 13 (VSS-v0) / >= 15 (static defenders), pass endurance two plus its rejections (about
+// half of its candidates; measured faster with the full block than with 4 or 8); contested
+// possession uses exactly one, dribbling none (fixed course).  Later draws are computed where
+// they are needed.
+template <int TASK, int L>
+__host__ __device__ constexpr int predraw_count() {
+    return TASK == RSX_TASK_SSL_DRIBBLING ? 0 : TASK == RSX_TASK_SSL_CONTESTED ? 1 : (L < 16 ? 16 : L);
+}
+
+template <int TASK, int L>
 __device__ __forceinline__ void place_predraw(const Params& P, uint32_t env_id, uint32_t episode,
                                               int b, float2* __restrict__ draws) {
-    constexpr int NPRE = L < 16 ? 16 : L;
+    constexpr int NPRE = predraw_count<TASK, L>();
 #pragma unroll
     for (int n = b; n < NPRE; n += L) {
         const u32x4 u = philox4x32_10(env_id, episode, (uint32_t)n, DOM_PLACE, P.key0, P.key1);
@@ -672,7 +682,7 @@ template <int TASK, int L>
 __device__ __forceinline__ void place_env(const Params& P, const int N, uint32_t env_id,
                                           uint32_t episode, int g, float4* A, const float2* draws) {
     constexpr int G = 64 / L;
-    constexpr int NPRE = L < 16 ? 16 : L;
+    constexpr int NPRE = predraw_count<TASK, L>();
     uint32_t n = 0;
     auto draw = [&]() -> float2 {
         const uint32_t i = n++;
@@ -767,7 +777,7 @@ __device__ __forceinline__ float4 place_env_parallel(const Params& P, const int 
                                                       const uint32_t episode, const int b, const int g,
                                                       const bool is_robot, float4* A, const float2* draws) {
     constexpr int G = 64 / L;
-    constexpr int NPRE = L < 16 ? 16 : L;
+    constexpr int NPRE = predraw_count<TASK, L>();
     auto getdraw = [&](uint32_t i) -> float2 {
         if (i < (uint32_t)NPRE) return draws[i];
         const u32x4 u = philox4x32_10(env_id, episode, i, DOM_PLACE, P.key0, P.key1);
@@ -1217,7 +1227,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
                 }
             }
             RSX_STAMP(15);
-            if (ended) place_predraw<L>(P, env_id, episode, b, sh.draws[g]);
+            if (ended) place_predraw<TASK, L>(P, env_id, episode, b, sh.draws[g]);
             wave_sync();  // draws published; stage rows of ended envs are about to be overwritten
             RSX_STAMP(16);
             float4 pz = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
