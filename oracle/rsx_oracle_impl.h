@@ -770,9 +770,9 @@ void SUF(rsxo_task_step)(void* p, const float* action) {
     else {
         SUF(draw)(e, t, RSXO_DOM_ACT, u);
         for (int i = 0; i < 4 && i < e->act_dim; ++i) a[i] = SUF(u01)(u[i]) * RC(2) - RC(1);
-        if (e->act_dim > 4) {
-            SUF(draw)(e, t, RSXO_DOM_ACT | (1u << 8), u);
-            a[4] = SUF(u01)(u[0]) * RC(2) - RC(1);
+        if (e->act_dim > 4) { /* fifth component: the low bytes u01 leaves unused in words 0..2 of the same block */
+            uint32_t w = (u[0] & 0xFFu) | ((u[1] & 0xFFu) << 8) | ((u[2] & 0xFFu) << 16);
+            a[4] = SUF(u01)(w << 8) * RC(2) - RC(1);
         }
     }
     R cmds[MAXROB * 8];

@@ -1009,9 +1009,9 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
                         a[0] = u01(u.x) * 2.0f - 1.0f; a[1] = u01(u.y) * 2.0f - 1.0f;
                         a[2] = u01(u.z) * 2.0f - 1.0f;
                         if (AD > 3) a[3] = u01(u.w) * 2.0f - 1.0f;
-                        if (AD > 4) {
-                            u32x4 v = philox4x32_10(env_id, episode, t, DOM_ACT | (1u << 8), P.key0, P.key1);
-                            a[4] = u01(v.x) * 2.0f - 1.0f;
+                        if (AD > 4) {   // fifth component: the low bytes u01 leaves unused in x, y, z (one block per step)
+                            const uint32_t w = (u.x & 0xFFu) | ((u.y & 0xFFu) << 8) | ((u.z & 0xFFu) << 16);
+                            a[4] = u01(w << 8) * 2.0f - 1.0f;
                         }
                     }
                     if (TASK == RSX_TASK_SSL_PASS_ENDURANCE) {  // pass_endurance.py:106-130
