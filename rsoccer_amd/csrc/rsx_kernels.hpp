@@ -83,10 +83,14 @@ struct Shared {
 #endif
 };
 
-// Marks a branch as seldom taken so that its body is laid out away from the hot path.  Measured
-// per simulator class: the SSL kernels gain (static defenders 10.7 -> 10.5 us, pass endurance
-// 11.2 -> 10.9), the VSS kernel loses 0.05 us, so the hint is applied to SSL only.
-#define RSX_RARE(KIND, c) ((KIND) == RSX_KIND_SSL ? __builtin_expect(!!(c), 0) : !!(c))
+// Marks a branch as seldom taken so that its body is laid out away from the hot path.  Which hints
+// pay off was measured per simulator class (single-step launch): SSL takes all three (static
+// defenders 10.7 -> 10.5 us, pass endurance 11.2 -> 10.85); VSS takes the contact sweep (2) and
+// the episode end (4) but not the airborne-ball test (1): 8.55 -> 8.47 us (all three: 8.62).
+#ifndef RSX_VSS_HINTS
+#define RSX_VSS_HINTS 6
+#endif
+#define RSX_RARE_B(KIND, bit, c) (((KIND) == RSX_KIND_SSL || (RSX_VSS_HINTS & (bit))) ? __builtin_expect(!!(c), 0) : !!(c))
 
 // clamp a circle (radius r, restitution rest) into the playable region
 template <int KIND>
@@ -256,7 +260,7 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
             else if (o.th < -180.0f) o.th = o.th + 360.0f;
             rotate_heading(o.om * P.h, o.c, o.s);
         } else if (is_ball) {
-            if (RSX_RARE(KIND, o.z > 0.0f || o.vz > 0.0f)) {
+            if (RSX_RARE_B(KIND, 1, o.z > 0.0f || o.vz > 0.0f)) {
                 o.vz = o.vz - P.g_h;
                 o.z = fma_(o.vz, P.h, o.z);
                 if (o.z <= 0.0f) {
@@ -296,7 +300,7 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                         d2s[j] = t ? d2 : -1.0f;
                         any |= t;
                     }
-                    if (RSX_RARE(KIND, any)) {
+                    if (RSX_RARE_B(KIND, 2, any)) {
                         // Each lane walks ITS partners in body-index order; lanes with different
                         // partners share an iteration, so a wave pays for the deepest lane (one
                         // response, rarely two) instead of one response block per distinct partner
@@ -350,7 +354,7 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                         d2s[j] = t ? d2 : -1.0f;
                         any |= t;
                     }
-                    if (RSX_RARE(KIND, any)) {   // per-lane partner walk, see the VSS sweep
+                    if (RSX_RARE_B(KIND, 2, any)) {   // per-lane partner walk, see the VSS sweep
                         unsigned todo = 0;
 #pragma unroll
                         for (int j = 0; j < NR; ++j) todo |= d2s[j] > 0.0f ? 1u << j : 0u;
@@ -1192,7 +1196,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
 
         RSX_STAMP(4);
         // ---- episode end: same-step auto-reset (or reset()) ----
-        if (RSX_RARE(KIND, __any(ended))) {
+        if (RSX_RARE_B(KIND, 4, __any(ended))) {
             if (ended && mode == 0) {  // terminal observation
                 for (int i = b; i < OD; i += L) bufs.final_obs[(size_t)e * OD + i] = sh.stage[g * OD + i];
             }
