@@ -287,19 +287,26 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                     float4 oth[NR + 1];  // all reads in flight together, one wait
 #pragma unroll
                     for (int j = 0; j <= NR; ++j) oth[j] = sh.A[j * G + g];
-                    // overlap tests for the whole sweep first; contacts are rare, so the common
-                    // case is one untaken branch per sub-step
-                    float d2s[NR + 1];
-                    bool any = false;
+                    // Overlap test of the whole sweep, exact and with ONE compare per partner class:
+                    // d2 is a sum of squares (>= +0), and non-negative floats order like their bit
+                    // patterns, so with u = bits(d2) - 1 (d2 == 0, the lane's own slot, wraps to
+                    // 0xFFFFFFFF)   0 < d2 < thr   <=>   u < bits(thr) - 1   (unsigned).
+                    // The minimum of u over the robot slots is compared once; contacts are rare, so
+                    // the common case is ~5 instructions per partner and one untaken branch.
+                    constexpr uint32_t T_RR = __builtin_bit_cast(uint32_t, K::rs_rr2) - 1u;
+                    constexpr uint32_t T_RB = __builtin_bit_cast(uint32_t, K::rs_rb2) - 1u;
+                    uint32_t u[NR + 1];
 #pragma unroll
                     for (int j = 0; j <= NR; ++j) {
-                        const bool rb = is_ball || j == NR;
                         float dx = oth[j].x - o.x, dy = oth[j].y - o.y;
-                        float d2 = fma_(dx, dx, dy * dy);
-                        const bool t = (d2 < (rb ? K::rs_rb2 : K::rs_rr2)) & (d2 > 0.0f) & (!rb | ball_low);
-                        d2s[j] = t ? d2 : -1.0f;
-                        any |= t;
+                        u[j] = __float_as_uint(fma_(dx, dx, dy * dy)) - 1u;
                     }
+                    uint32_t um = u[0];
+#pragma unroll
+                    for (int j = 1; j < NR; ++j) um = min(um, u[j]);
+                    // robot lane: robot slots are robot-robot pairs, slot NR the ball; ball lane:
+                    // every robot slot is a robot-ball pair, slot NR itself (u = 0xFFFFFFFF)
+                    const bool any = ((um < (is_ball ? T_RB : T_RR)) & (!is_ball | ball_low)) | ((u[NR] < T_RB) & ball_low);
                     if (RSX_RARE_B(KIND, 2, any)) {
                         // Each lane walks ITS partners in body-index order; lanes with different
                         // partners share an iteration, so a wave pays for the deepest lane (one
@@ -308,7 +315,10 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                         // single-step launch's duration, and it is always one with contacts.
                         unsigned todo = 0;
 #pragma unroll
-                        for (int j = 0; j <= NR; ++j) todo |= d2s[j] > 0.0f ? 1u << j : 0u;
+                        for (int j = 0; j <= NR; ++j) {
+                            const bool rb = is_ball || j == NR;
+                            todo |= ((u[j] < (rb ? T_RB : T_RR)) & (!rb | ball_low)) ? 1u << j : 0u;
+                        }
                         while (todo) {
                             const int j = __builtin_ctz(todo);
                             todo &= todo - 1;
@@ -344,20 +354,21 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                     float4 oth[NR ? NR : 1];  // all reads in flight together, one wait
 #pragma unroll
                     for (int j = 0; j < NR; ++j) oth[j] = sh.A[j * G + g];
-                    float d2s[NR ? NR : 1];
-                    bool any = false;
+                    // exact integer form of 0 < d2 < rs_rr^2, see the VSS sweep
+                    constexpr uint32_t T_RR = __builtin_bit_cast(uint32_t, K::rs_rr2) - 1u;
+                    uint32_t u[NR ? NR : 1];
 #pragma unroll
                     for (int j = 0; j < NR; ++j) {
                         float dx = oth[j].x - o.x, dy = oth[j].y - o.y;
-                        float d2 = fma_(dx, dx, dy * dy);
-                        const bool t = (d2 < K::rs_rr2) & (d2 > 0.0f);
-                        d2s[j] = t ? d2 : -1.0f;
-                        any |= t;
+                        u[j] = __float_as_uint(fma_(dx, dx, dy * dy)) - 1u;
                     }
-                    if (RSX_RARE_B(KIND, 2, any)) {   // per-lane partner walk, see the VSS sweep
+                    uint32_t um = u[0];
+#pragma unroll
+                    for (int j = 1; j < NR; ++j) um = min(um, u[j]);
+                    if (RSX_RARE_B(KIND, 2, um < T_RR)) {   // per-lane partner walk, see the VSS sweep
                         unsigned todo = 0;
 #pragma unroll
-                        for (int j = 0; j < NR; ++j) todo |= d2s[j] > 0.0f ? 1u << j : 0u;
+                        for (int j = 0; j < NR; ++j) todo |= u[j] < T_RR ? 1u << j : 0u;
                         while (todo) {
                             const int j = __builtin_ctz(todo);
                             todo &= todo - 1;
