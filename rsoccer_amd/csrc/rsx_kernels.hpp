@@ -21,8 +21,14 @@
 //     together and their latency is paid once.  All sub-steps of one env.step() run out of
 //     registers + LDS; HBM is touched once for the load and once for the store of the state.
 //   * SSL: the robot lane evaluates its own robot-ball contact (kicker-mouth geometry) and
-//     publishes the ball-side impulse / dribbler / kick record; the ball lane only sums the
-//     N records in index order.  No lane re-derives another lane's geometry.
+//     publishes the ball-side impulse / dribbler / kick record; the ball lane learns from one
+//     ballot which robots wrote one and sums those in index order.  No lane re-derives another
+//     lane's geometry.
+//   * a single-step launch lasts as long as its slowest wave, so the rare paths are shaped for
+//     the wave that takes them: the overlap test of a sweep is one integer minimum and one
+//     compare, each lane then walks only ITS partners (lanes with different partners share an
+//     iteration), and the reset placement of an ended env is done by all of its lanes together
+//     (place_env_parallel).
 //   * 64-thread workgroups (one wave): a 4096-env VSS batch is 512 workgroups, two per CU,
 //     so all 256 CUs work; block b runs on XCD b % 8 and is mapped to tile
 //     (b % 8) * tiles_per_xcd + b / 8 so each XCD's L2 sees one contiguous 1/8 of every row.
