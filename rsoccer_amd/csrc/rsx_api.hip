@@ -103,20 +103,24 @@ void pick_variant(rsx_sim* h) {
     if (h->P.kind == RSX_KIND_SSL && N == 22 && h->L == 32) h->NR = 22;
 }
 
-#define RSX_LAUNCH(kernel, ...) hipLaunchKernelGGL((kernel), grid, dim3(64), 0, s, __VA_ARGS__)
+// hot arguments first (preloaded into SGPRs, see RSX_HOT_ARGS), then the by-value structs
+#define RSX_LAUNCH_SIM(kernel, P, b) hipLaunchKernelGGL((kernel), grid, dim3(64), 0, s, (b).state, (b).aux, (b).cmds, (b).flags, \
+                                                        (P).num_envs, (P).state_dim, (int)(grid.x >> 3), 1, (P), (b))
+#define RSX_LAUNCH(kernel, P, b, n) hipLaunchKernelGGL((kernel), grid, dim3(64), 0, s, (b).state, (b).aux, (b).actions, (b).flags, \
+                                                       (P).num_envs, (P).state_dim, (int)(grid.x >> 3), (n), (P), (b))
 
 template <int KIND>
 void launch_sim_k(const rsx_sim* h, hipStream_t s) {
     const dim3 grid = grid_for(h);
     const Buffers b = buffers_of(h, nullptr);
-    if (KIND == RSX_KIND_VSS && h->NR == 6) { RSX_LAUNCH((sim_step_kernel<KIND, 8, (KIND == RSX_KIND_VSS ? 6 : 0)>), h->P, b); return; }
-    if (KIND == RSX_KIND_SSL && h->NR == 7) { RSX_LAUNCH((sim_step_kernel<KIND, 8, (KIND == RSX_KIND_SSL ? 7 : 0)>), h->P, b); return; }
-    if (KIND == RSX_KIND_SSL && h->NR == 22) { RSX_LAUNCH((sim_step_kernel<KIND, 32, (KIND == RSX_KIND_SSL ? 22 : 0)>), h->P, b); return; }
+    if (KIND == RSX_KIND_VSS && h->NR == 6) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 8, (KIND == RSX_KIND_VSS ? 6 : 0)>), h->P, b); return; }
+    if (KIND == RSX_KIND_SSL && h->NR == 7) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 8, (KIND == RSX_KIND_SSL ? 7 : 0)>), h->P, b); return; }
+    if (KIND == RSX_KIND_SSL && h->NR == 22) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 32, (KIND == RSX_KIND_SSL ? 22 : 0)>), h->P, b); return; }
     switch (h->L) {
-        case 8: RSX_LAUNCH((sim_step_kernel<KIND, 8, 0>), h->P, b); break;
-        case 16: RSX_LAUNCH((sim_step_kernel<KIND, 16, 0>), h->P, b); break;
-        case 32: RSX_LAUNCH((sim_step_kernel<KIND, 32, 0>), h->P, b); break;
-        default: RSX_LAUNCH((sim_step_kernel<KIND, 64, 0>), h->P, b); break;
+        case 8: RSX_LAUNCH_SIM((sim_step_kernel<KIND, 8, 0>), h->P, b); break;
+        case 16: RSX_LAUNCH_SIM((sim_step_kernel<KIND, 16, 0>), h->P, b); break;
+        case 32: RSX_LAUNCH_SIM((sim_step_kernel<KIND, 32, 0>), h->P, b); break;
+        default: RSX_LAUNCH_SIM((sim_step_kernel<KIND, 64, 0>), h->P, b); break;
     }
 }
 

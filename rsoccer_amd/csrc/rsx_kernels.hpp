@@ -571,16 +571,27 @@ __device__ __forceinline__ void store_body(const Params& P, float* __restrict__ 
 
 // block -> tile map: block b runs on XCD b % 8 (observed dispatch order; used for L2 affinity
 // only, never for correctness), so give each XCD one contiguous range of tiles.
-__device__ __forceinline__ int tile_of_block() {
-    const int per = gridDim.x >> 3;  // grid is a multiple of 8
+__device__ __forceinline__ int tile_of_block(const int per /* gridDim.x / 8: the grid is a multiple of 8 */) {
     return (blockIdx.x & 7) * per + (blockIdx.x >> 3);
 }
+
+// Kernel arguments.  The first twelve dwords are plain pointers / ints so that the command
+// processor PRELOADS them into SGPRs (-amdgpu-kernarg-preload-count=12, gfx940+): what the first
+// global loads of a wave need (base pointers, row stride, tile map) is then in registers when
+// the wave starts, instead of behind a scalar-cache miss on the kernarg segment — with two waves
+// per CU nearly every wave would pay that miss on its critical path.  The by-value structs that
+// follow carry everything else and are fetched while the state loads are in flight.
+#define RSX_HOT_ARGS float* hp_state, float* hp_aux, const float* hp_in, uint8_t* hp_flags, \
+                     const int hp_num_envs, const int hp_state_dim, const int hp_per_xcd, const int hp_n_steps
 
 // =============================================================================================
 // raw simulator step: robosim.step(cmds) + get_state() on the SoA buffers
 // =============================================================================================
 template <int KIND, int L, int NR>
-__global__ __launch_bounds__(64) void sim_step_kernel(const Params P, const Buffers bufs) {
+__global__ __launch_bounds__(64) void sim_step_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
+    Params P = P_; P.num_envs = hp_num_envs; P.state_dim = hp_state_dim;
+    Buffers bufs = bufs_; bufs.state = hp_state; bufs.cmds = hp_in;   // hp_in: the command buffer
+    (void)hp_aux; (void)hp_flags; (void)hp_n_steps;
     using K = KC<KIND>;
     constexpr int G = 64 / L;
     constexpr int CD = ModelD<KIND>::cmd_dim;
@@ -590,7 +601,7 @@ __global__ __launch_bounds__(64) void sim_step_kernel(const Params P, const Buff
 #endif
     const int lane = threadIdx.x;
     const int b = lane / G, g = lane % G;
-    const int e = tile_of_block() * G + g;
+    const int e = tile_of_block(hp_per_xcd) * G + g;
     const int N = NR ? NR : P.n_robots;
     const bool live = e < P.num_envs;
     const bool is_robot = live && b < N, is_ball = live && b == N;
@@ -889,8 +900,17 @@ __device__ __forceinline__ float4 place_env_parallel(const Params& P, const int 
 constexpr int MODE_STEP = 0, MODE_RESET = 1, MODE_REFRESH = 2, MODE_ROLLOUT = 3;
 
 template <int KIND, int L, int TASK, int NR, int MODE>
-__global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buffers bufs,
-                                                       const int n_steps_arg) {
+__global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
+    // A multi-step launch is short of SGPRs, not of start-up latency: there the preloaded copies
+    // are left dead and everything is fetched from the kernarg segment when it is needed.
+    constexpr bool HOT = MODE != MODE_ROLLOUT;
+    Params P = P_;
+    Buffers bufs = bufs_;
+    if (HOT) {
+        P.num_envs = hp_num_envs; P.state_dim = hp_state_dim;
+        bufs.state = hp_state; bufs.aux = hp_aux; bufs.actions = hp_in; bufs.flags = hp_flags;
+    }
+    const int n_steps_arg = hp_n_steps;
     constexpr int mode = MODE == MODE_ROLLOUT ? MODE_STEP : MODE;
     const int n_steps = MODE == MODE_ROLLOUT ? n_steps_arg : 1;
     using K = KC<KIND>;
@@ -901,7 +921,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(const Params P, const Buf
     __shared__ Shared<L> sh;
     const int lane = threadIdx.x;
     const int b = lane / G, g = lane % G;
-    const int tile = tile_of_block();
+    const int tile = tile_of_block(HOT ? hp_per_xcd : (int)(gridDim.x >> 3));
     const int e = tile * G + g;
     const int N = NR ? NR : P.n_robots;
     const bool live = e < P.num_envs;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Prints VGPR / SGPR / scratch / LDS / occupancy per kernel of librsx_hip (hipcc remarks).
 cd "$(dirname "$0")/.."
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -mllvm -amdgpu-sched-strategy=max-ilp -Iinclude -Irsoccer_amd/csrc \
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -mllvm -amdgpu-sched-strategy=max-ilp -mllvm -amdgpu-kernarg-preload-count=12 -Iinclude -Irsoccer_amd/csrc \
   -Rpass-analysis=kernel-resource-usage -o /tmp/_rsx_probe.so rsoccer_amd/csrc/rsx_api.hip 2>&1 | python3 -c '
 import sys,re
 cur=None;rows={}
