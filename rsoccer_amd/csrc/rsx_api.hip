@@ -14,6 +14,7 @@
 
 #include "rsx.h"
 #include "rsx_kernels.hpp"
+#include "rsx_epl.hpp"
 
 using namespace rsx;
 
@@ -32,12 +33,18 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 }  // namespace
 
+// smallest batch stepped by the one-lane-per-env VSS-v0 kernel (measured crossover, profiles/)
+#ifndef RSX_EPL_MIN_ENVS
+#define RSX_EPL_MIN_ENVS 131072
+#endif
+
 struct rsx_sim {
     Params P;
     HostModel M;
     int device = 0;
     int L = 8;   // lanes per env
     int NR = 0;  // compile-time robot count of the selected kernel variant (0 = generic)
+    bool epl = false;  // VSS-v0 3v3 step / rollout launches use the one-lane-per-env kernel (large batches)
     // one allocation per lifetime stage (few pages -> few TLB entries per launch)
     char* arena_sim = nullptr;   // state | cmds
     char* arena_task = nullptr;  // aux | obs | final_obs | flags | actions | metrics
@@ -131,8 +138,14 @@ void launch_sim(const rsx_sim* h, hipStream_t s) {
 
 template <int KIND, int TASK, int NRS, int MODE>
 void launch_task_m(const rsx_sim* h, const float* actions, int n_steps, hipStream_t s) {
-    const dim3 grid = grid_for(h);
     const Buffers b = buffers_of(h, actions);
+    if (TASK == RSX_TASK_VSS_V0 && (MODE == MODE_STEP || MODE == MODE_ROLLOUT) && h->epl && h->NR == 6 && h->L == 8) {
+        const int tiles = (h->P.num_envs + 63) / 64;
+        const dim3 grid((unsigned)(((tiles + 7) / 8) * 8));
+        RSX_LAUNCH((vss_epl_kernel<(MODE == MODE_ROLLOUT ? MODE_ROLLOUT : MODE_STEP)>), h->P, b, n_steps);
+        return;
+    }
+    const dim3 grid = grid_for(h);
     if (h->NR == NRS && h->L == 8) { RSX_LAUNCH((task_step_kernel<KIND, 8, TASK, NRS, MODE>), h->P, b, n_steps); return; }
     switch (h->L) {
         case 8: RSX_LAUNCH((task_step_kernel<KIND, 8, TASK, 0, MODE>), h->P, b, n_steps); break;
@@ -438,6 +451,15 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
     HIP_TRY(hipMemset(h->d_aux + (size_t)ROW_EPISODE * B, 0xFF, B * sizeof(uint32_t)));
     h->P = P;
     h->env_steps = 0;
+    // VSS-v0 3v3: which tile layout steps the envs.  Both give identical results; the one-lane-
+    // per-env kernel needs enough envs to fill the chip with its long waves.
+    h->epl = false;
+    if (task == RSX_TASK_VSS_V0 && h->NR == 6 && h->L == 8) {
+        const char* lay = std::getenv("RSX_LAYOUT");
+        if (lay && std::strcmp(lay, "epl") == 0) h->epl = true;
+        else if (lay && std::strcmp(lay, "lanes") == 0) h->epl = false;
+        else h->epl = P.num_envs >= RSX_EPL_MIN_ENVS;
+    }
     return RSX_OK;
 }
 

@@ -1,0 +1,397 @@
+// rsx_epl.hpp — VSS-v0 3v3 fused step, "one lane per env" layout for LARGE batches.
+//
+// Same path, same buffers, same arithmetic as task_step_kernel<VSS, 8, VSS_V0, 6, ...> in
+// rsx_kernels.hpp (reference: vss_gym.py:93-311 around robosim.VSS.step, rsim.py:102,105), other
+// mapping: lane = env, a wave owns 64 envs and walks the 7 bodies of each one after the other with
+// the whole env in registers.  What it buys at scale:
+//   * no role divergence and no idle slot: every lane runs "robot k" (or the ball, or the reward)
+//     at the same time, so a wave issues each instruction for 64 envs instead of 8 — about half
+//     the VALU work per env-step of the 8-lanes-per-env layout, which is VALU-bound there;
+//   * a pair of bodies is tested once (21 tests per sub-step instead of 49 lane-pair tests);
+//   * every SoA row access of a wave is 256 contiguous bytes.
+// What it costs: a wave's critical path is seven times longer, so the layout only pays when
+// there are enough envs to fill the chip with such waves (>= ~64 k; the host picks it by batch
+// size, RSX_LAYOUT=lanes|epl overrides).  Results are bit-identical to the other layout: every
+// body's contact sum is accumulated in partner-index order, each side of a pair evaluates the
+// response from its own point of view with the same expressions, draws use the same Philox
+// counters (tests/test_gpu_parity.py::test_env_per_lane_layout_is_bit_identical).
+#pragma once
+#include "rsx_kernels.hpp"
+
+namespace rsx {
+
+constexpr int EPL_NR = 6;           // VSS 3v3
+constexpr int EPL_NB = EPL_NR + 1;  // + ball (body index EPL_NR)
+constexpr int EPL_OD = 40, EPL_ODP = 41;
+
+struct EplShared {
+    // phase 1 (contacts of a sub-step, only when some lane touches something): snapshot + sums,
+    // phase 2 (after the physics): observation rows; the two never live together
+    union {
+        struct { float snap[4][EPL_NB][64]; float acc[4][EPL_NB][64]; } c;
+        float stage[64 * EPL_ODP];
+    } u;
+    float px[EPL_NB][64], py[EPL_NB][64], pth[EPL_NB][64];   // reset placement (x, y, theta_deg)
+};
+
+// pair p -> (i, j), i < j, lexicographic: every body then receives its partners in index order
+__device__ __forceinline__ void epl_pair(int p, int& i, int& j) {
+    // rows of the upper triangle of a 7 x 7 matrix start at 0, 6, 11, 15, 18, 20
+    i = p >= 20 ? 5 : p >= 18 ? 4 : p >= 15 ? 3 : p >= 11 ? 2 : p >= 6 ? 1 : 0;
+    const int start = i == 0 ? 0 : i == 1 ? 6 : i == 2 ? 11 : i == 3 ? 15 : i == 4 ? 18 : 20;
+    j = i + 1 + (p - start);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void vss_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
+    constexpr int KIND = RSX_KIND_VSS, TASK = RSX_TASK_VSS_V0, N = EPL_NR;
+    using K = KC<KIND>;
+    using T = TC<TASK>;
+    constexpr int ID = T::info_dim;
+    Params P = P_; P.num_envs = hp_num_envs; P.state_dim = hp_state_dim;
+    Buffers bufs = bufs_; bufs.state = hp_state; bufs.aux = hp_aux; bufs.actions = hp_in; bufs.flags = hp_flags;
+    const int n_steps = MODE == MODE_ROLLOUT ? hp_n_steps : 1;
+    __shared__ EplShared sh;
+    const int lane = threadIdx.x;
+    const int tile = tile_of_block(hp_per_xcd);
+    const int e = tile * 64 + lane;
+    const bool live = e < P.num_envs;
+    const size_t B = (size_t)P.num_envs;
+    const uint32_t env_id = P.env_id_base + (uint32_t)e;
+    float* const st = bufs.state + e;
+    float* const auxe = bufs.aux + e;
+
+    // ---- load: every row access of the wave is 256 contiguous bytes ----
+    Body r[N];
+    Body ball = Body{};
+    float od[N], wd[N];
+    float ou[N][2];
+    float info[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float prev_pot = 0.0f, ep_ret = 0.0f;
+    int steps = 0; uint32_t episode = 0;
+    float raw[N][6], rawb[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+#pragma unroll
+        for (int f = 0; f < 6; ++f) raw[k][f] = live ? st[(size_t)(5 + 6 * k + f) * B] : 0.0f;
+        ou[k][0] = ou[k][1] = 0.0f;
+        if (k >= 1 && live) { ou[k][0] = auxe[(size_t)(ROW_OU + 2 * k) * B]; ou[k][1] = auxe[(size_t)(ROW_OU + 2 * k + 1) * B]; }
+    }
+    if (live) {
+#pragma unroll
+        for (int f = 0; f < 5; ++f) rawb[f] = st[(size_t)f * B];
+        rawb[5] = st[(size_t)P.state_dim * B];
+        steps = __float_as_int(auxe[(size_t)ROW_STEPS * B]);
+        episode = __float_as_uint(auxe[(size_t)ROW_EPISODE * B]);
+#pragma unroll
+        for (int i = 0; i < ID; ++i) info[i] = auxe[(size_t)(ROW_INFO + i) * B];
+        prev_pot = auxe[(size_t)ROW_PREV_POT * B]; ep_ret = auxe[(size_t)ROW_EP_RET * B];
+    }
+    const bool fed = MODE == MODE_STEP && bufs.actions != nullptr;
+    float act0 = 0.0f, act1 = 0.0f;
+    if (fed && live) { act0 = bufs.actions[(size_t)e * 2]; act1 = bufs.actions[(size_t)e * 2 + 1]; }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): all loads land once, before the step loop
+#pragma unroll
+    for (int k = 0; k < N; ++k) {   // interpret_body, robot
+        r[k] = Body{};
+        r[k].x = raw[k][0]; r[k].y = raw[k][1]; r[k].vx = raw[k][3]; r[k].vy = raw[k][4];
+        od[k] = raw[k][2]; wd[k] = raw[k][5];
+        r[k].th = od[k];
+        r[k].om = wd[k] * K::deg2rad;
+        sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
+    }
+    ball.x = rawb[0]; ball.y = rawb[1]; ball.vx = rawb[3]; ball.vy = rawb[4];
+    ball.z = rawb[2] - K::r_ball; ball.vz = rawb[5];
+
+    float reward = 0.0f; int term = 0, trunc = 0;
+
+    for (int it = 0; it < n_steps; ++it) {
+        const bool first_step = steps == 0;
+        const uint32_t t = (uint32_t)steps;
+        if (first_step) {
+#pragma unroll
+            for (int i = 0; i < 10; ++i) info[i] = 0.0f;
+            ep_ret = 0.0f;
+        }
+        // ---- actions -> commands (vss_gym.py:119-142,235-254) ----
+        float q0[N], q1[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            float a0, a1;
+            const u32x4 u = philox4x32_10(env_id, episode, t, k == 0 ? DOM_ACT : (DOM_OU | ((uint32_t)k << 8)), P.key0, P.key1);
+            if (k == 0) {
+                if (fed) { a0 = act0; a1 = act1; }
+                else { a0 = u01(u.x) * 2.0f - 1.0f; a1 = u01(u.y) * 2.0f - 1.0f; }
+            } else {  // Ornstein-Uhlenbeck noise, Utils/Utils.py:14-21 (Box-Muller on Philox)
+                float u1 = (float)((u.x >> 8) + 1u) * 5.9604644775390625e-08f;
+                float ang = (u01(u.y) - 0.5f) * 6.283185307179586f;
+                float rad = sqrtf(-2.0f * log_f32(u1));
+                float sn, cs;
+                sincos_f32(ang, sn, cs);
+                float n0 = rad * cs, n1 = rad * sn;
+                ou[k][0] = (ou[k][0] + P.ou_theta_dt * (0.0f - ou[k][0])) + P.ou_sig_sqdt * n0;
+                ou[k][1] = (ou[k][1] + P.ou_theta_dt * (0.0f - ou[k][1])) + P.ou_sig_sqdt * n1;
+                a0 = ou[k][0]; a1 = ou[k][1];
+            }
+            q0[k] = vss_wheel(a0); q1[k] = vss_wheel(a1);
+            const float qq[2] = {q0[k], q1[k]};
+            robot_targets<KIND>(P, r[k], qq);
+        }
+
+        // ---- physics: n_sub sub-steps, the whole env in registers ----
+        if (P.n_sub && !(ball.z > 0.0f || ball.vz > 0.0f)) {   // rolling resistance, once per step()
+            float sp2 = fma_(ball.vx, ball.vx, ball.vy * ball.vy);
+            if (sp2 > 0.0f) {
+                float sp = sqrtf(sp2), ns = sp - P.mu_g_dt;
+                if (ns < 0.0f) ns = 0.0f;
+                float kk = ns / sp;
+                ball.vx = ball.vx * kk; ball.vy = ball.vy * kk;
+            }
+        }
+        for (int sub = 0; sub < P.n_sub; ++sub) {
+            // A: actuation + integration
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                Body& o = r[k];
+                float vf = fma_(o.vy, o.s, o.vx * o.c);
+                float vl = fma_(o.vy, o.c, -(o.vx * o.s));
+                vf = vf + clampf(o.t0 - vf, -P.a_lin_h, P.a_lin_h);
+                vl = vl - clampf(vl, -P.a_lat_h, P.a_lat_h);
+                o.om = o.om + clampf(o.t1 - o.om, -P.a_ang_h, P.a_ang_h);
+                o.vx = fma_(vf, o.c, -(vl * o.s));
+                o.vy = fma_(vf, o.s, vl * o.c);
+                o.x = fma_(o.vx, P.h, o.x);
+                o.y = fma_(o.vy, P.h, o.y);
+                o.th = fma_(o.om, P.h_deg, o.th);
+                if (o.th > 180.0f) o.th = o.th - 360.0f;
+                else if (o.th < -180.0f) o.th = o.th + 360.0f;
+                rotate_heading(o.om * P.h, o.c, o.s);
+            }
+            if (ball.z > 0.0f || ball.vz > 0.0f) {
+                ball.vz = ball.vz - P.g_h;
+                ball.z = fma_(ball.vz, P.h, ball.z);
+                if (ball.z <= 0.0f) {
+                    ball.z = 0.0f;
+                    ball.vz = -ball.vz * K::e_ground;
+                    if (ball.vz < K::vz_min) ball.vz = 0.0f;
+                }
+            }
+            ball.x = fma_(ball.vx, P.h, ball.x);
+            ball.y = fma_(ball.vy, P.h, ball.y);
+
+            // B: contacts, Jacobi over the post-integration snapshot.  Every pair once; the exact
+            // integer form of 0 < d2 < thr (see rsx_kernels.hpp) gives one bit per touching pair.
+            const bool ball_low = ball.z < K::robot_h;
+            constexpr uint32_t T_RR = __builtin_bit_cast(uint32_t, K::rs_rr2) - 1u;
+            constexpr uint32_t T_RB = __builtin_bit_cast(uint32_t, K::rs_rb2) - 1u;
+            unsigned touching = 0;
+            {
+                int p = 0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+#pragma unroll
+                    for (int j = i + 1; j <= N; ++j, ++p) {
+                        const float xj = j == N ? ball.x : r[j < N ? j : 0].x, yj = j == N ? ball.y : r[j < N ? j : 0].y;
+                        const float dx = xj - r[i].x, dy = yj - r[i].y;
+                        const uint32_t u = __float_as_uint(fma_(dx, dx, dy * dy)) - 1u;
+                        const bool tch = j == N ? ((u < T_RB) & ball_low) : (u < T_RR);
+                        touching |= tch ? 1u << p : 0u;
+                    }
+                }
+            }
+            float avx[EPL_NB], avy[EPL_NB], apx[EPL_NB], apy[EPL_NB];
+#pragma unroll
+            for (int k = 0; k < EPL_NB; ++k) { avx[k] = 0.0f; avy[k] = 0.0f; apx[k] = 0.0f; apy[k] = 0.0f; }
+            if (__any(touching != 0)) {
+                // some env of the wave has a contact: bodies are addressed by index from here on,
+                // so the snapshot and the sums go through LDS (column = lane, conflict free)
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    sh.u.c.snap[0][k][lane] = r[k].x; sh.u.c.snap[1][k][lane] = r[k].y;
+                    sh.u.c.snap[2][k][lane] = r[k].vx; sh.u.c.snap[3][k][lane] = r[k].vy;
+                }
+                sh.u.c.snap[0][N][lane] = ball.x; sh.u.c.snap[1][N][lane] = ball.y;
+                sh.u.c.snap[2][N][lane] = ball.vx; sh.u.c.snap[3][N][lane] = ball.vy;
+#pragma unroll
+                for (int k = 0; k < EPL_NB; ++k) {
+                    sh.u.c.acc[0][k][lane] = 0.0f; sh.u.c.acc[1][k][lane] = 0.0f;
+                    sh.u.c.acc[2][k][lane] = 0.0f; sh.u.c.acc[3][k][lane] = 0.0f;
+                }
+                wave_sync();
+                unsigned todo = touching;
+                while (todo) {   // each lane walks ITS touching pairs, in pair order
+                    const int p = __builtin_ctz(todo);
+                    todo &= todo - 1;
+                    int i, j;
+                    epl_pair(p, i, j);
+                    const bool rb = j == N;
+                    Body bi = Body{}, bj = Body{};
+                    bi.x = sh.u.c.snap[0][i][lane]; bi.y = sh.u.c.snap[1][i][lane]; bi.vx = sh.u.c.snap[2][i][lane]; bi.vy = sh.u.c.snap[3][i][lane];
+                    bj.x = sh.u.c.snap[0][j][lane]; bj.y = sh.u.c.snap[1][j][lane]; bj.vx = sh.u.c.snap[2][j][lane]; bj.vy = sh.u.c.snap[3][j][lane];
+                    const float rs = rb ? K::rs_rb : K::rs_rr, ope = rb ? K::ope_rb : K::ope_rr;
+                    // body i sees j ...
+                    {
+                        const float dx = bj.x - bi.x, dy = bj.y - bi.y;
+                        const float d2 = fma_(dx, dx, dy * dy);
+                        float a0 = sh.u.c.acc[0][i][lane], a1 = sh.u.c.acc[1][i][lane], a2 = sh.u.c.acc[2][i][lane], a3 = sh.u.c.acc[3][i][lane];
+                        contact_response(bi, make_float4(bj.x, bj.y, bj.vx, bj.vy), d2, rs, ope, rb ? K::w_rb_r : K::w_rr, K::beta, a0, a1, a2, a3);
+                        sh.u.c.acc[0][i][lane] = a0; sh.u.c.acc[1][i][lane] = a1; sh.u.c.acc[2][i][lane] = a2; sh.u.c.acc[3][i][lane] = a3;
+                    }
+                    // ... and j sees i, from its own point of view (what its lane computes in the other layout)
+                    {
+                        const float dx = bi.x - bj.x, dy = bi.y - bj.y;
+                        const float d2 = fma_(dx, dx, dy * dy);
+                        float a0 = sh.u.c.acc[0][j][lane], a1 = sh.u.c.acc[1][j][lane], a2 = sh.u.c.acc[2][j][lane], a3 = sh.u.c.acc[3][j][lane];
+                        contact_response(bj, make_float4(bi.x, bi.y, bi.vx, bi.vy), d2, rs, ope, rb ? K::w_rb_b : K::w_rr, K::beta, a0, a1, a2, a3);
+                        sh.u.c.acc[0][j][lane] = a0; sh.u.c.acc[1][j][lane] = a1; sh.u.c.acc[2][j][lane] = a2; sh.u.c.acc[3][j][lane] = a3;
+                    }
+                }
+                wave_sync();
+#pragma unroll
+                for (int k = 0; k < EPL_NB; ++k) {
+                    avx[k] = sh.u.c.acc[0][k][lane]; avy[k] = sh.u.c.acc[1][k][lane];
+                    apx[k] = sh.u.c.acc[2][k][lane]; apy[k] = sh.u.c.acc[3][k][lane];
+                }
+                wave_sync();
+            }
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                r[k].vx = r[k].vx + avx[k]; r[k].vy = r[k].vy + avy[k];
+                r[k].x = r[k].x + apx[k]; r[k].y = r[k].y + apy[k];
+                // C: walls
+                walls<KIND>(P, K::r_robot, K::e_wr, r[k].x, r[k].y, r[k].vx, r[k].vy);
+            }
+            ball.vx = ball.vx + avx[N]; ball.vy = ball.vy + avy[N];
+            ball.x = ball.x + apx[N]; ball.y = ball.y + apy[N];
+            walls<KIND>(P, K::r_ball, K::e_wb, ball.x, ball.y, ball.vx, ball.vy);
+        }
+
+        // ---- wire-format values, observation, reward ----
+        float* const row = sh.u.stage + lane * EPL_ODP;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            od[k] = r[k].th; wd[k] = r[k].om * K::rad2deg;
+            r[k].om = wd[k] * K::deg2rad;
+            sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
+            write_obs<KIND, TASK>(P, row, k, true, false, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, wd[k], 0, prev_pot);
+        }
+        ball.z = (K::r_ball + ball.z) - K::r_ball;
+        write_obs<KIND, TASK>(P, row, N, false, true, ball.x, ball.y, ball.vx, ball.vy, 0.0f, 0.0f, 0.0f, 0, prev_pot);
+        {   // vss_gym.py:144-192,256-311
+            reward = 0.0f; term = 0;
+            const float bx = ball.x, by = ball.y;
+            if (bx > P.half_len) { info[0] += 1.0f; info[4] += 1.0f; reward = 10.0f; term = 1; }
+            else if (bx < -P.half_len) { info[0] -= 1.0f; info[5] += 1.0f; reward = -10.0f; term = 1; }
+            else {
+                float dx_d = (P.hl_goal + bx) * 100.0f, dx_a = (P.hl_goal - bx) * 100.0f, dy = by * 100.0f;
+                float dy2 = 2.0f * (dy * dy);
+                float dist_1 = -sqrtf(dx_a * dx_a + dy2), dist_2 = sqrtf(dx_d * dx_d + dy2);
+                float pot = ((dist_1 + dist_2) * P.inv_len_cm - 1.0f) * 0.5f;
+                float grad = 0.0f;
+                if (!first_step) grad = clampf((pot - prev_pot) * 3.0f * P.inv_dt, -5.0f, 5.0f);
+                prev_pot = pot;
+                float rbx = bx - r[0].x, rby = by - r[0].y;
+                float nrm = sqrtf(rbx * rbx + rby * rby);
+                float mv = (rbx / nrm) * r[0].vx + (rby / nrm) * r[0].vy;
+                float move = clampf(mv * 2.5f, -5.0f, 5.0f);
+                float energy = -(fabsf(q0[0]) + fabsf(q1[0]));
+                float t_move = 0.2f * move, t_grad = 0.8f * grad, t_en = 2e-4f * energy;
+                reward = (t_move + t_grad) + t_en;
+                info[1] += t_move; info[2] += t_grad; info[3] += t_en;
+            }
+            ep_ret = ep_ret + reward;
+        }
+        steps += 1;
+        trunc = steps >= P.max_steps;
+        const bool ended = live && (term | trunc);
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < ID; ++i) auxe[(size_t)(ROW_INFO + i) * B] = info[i];
+            auxe[(size_t)ROW_REWARD * B] = reward;
+            bufs.flags[e] = (uint8_t)term; bufs.flags[B + e] = (uint8_t)trunc;
+        }
+
+        // ---- episode end: same-step auto-reset, one lane = one env ----
+        if (__any(ended)) {
+            if (ended) {
+                for (int i = 0; i < EPL_OD; ++i) bufs.final_obs[(size_t)e * EPL_OD + i] = row[i];
+                episode += 1;
+                atomicAdd(&bufs.metrics[1], 1ull);
+                if (info[4] > 0.0f) atomicAdd(&bufs.metrics[2], 1ull);
+                if (info[5] > 0.0f) atomicAdd(&bufs.metrics[3], 1ull);
+                atomicAdd(&bufs.metrics[4], (unsigned long long)__float2ll_rn(ep_ret * 1048576.0f));
+                atomicAdd(&bufs.metrics[5], (unsigned long long)steps);
+                if (trunc && !term) atomicAdd(&bufs.metrics[6], 1ull);
+                // placement: the reference's sequential rejection sampling (vss_gym.py:194-233)
+                uint32_t n = 0;
+                auto draw = [&]() -> float2 {
+                    const u32x4 u = philox4x32_10(env_id, episode, n++, DOM_PLACE, P.key0, P.key1);
+                    return make_float2(u01(u.x), u01(u.y));
+                };
+                float bx, by;
+                { const float2 u = draw(); bx = P.pl_xlo + P.pl_xspan * u.x; by = P.pl_ylo + P.pl_yspan * u.y; }
+                for (int k = 0; k < N; ++k) {
+                    float x = 0.0f, y = 0.0f;
+                    for (int tt = 0; tt < 64; ++tt) {
+                        const float2 u = draw();
+                        x = P.pl_xlo + P.pl_xspan * u.x;
+                        y = P.pl_ylo + P.pl_yspan * u.y;
+                        bool ok = true;
+                        { float dx = x - bx, dy = y - by; if (dx * dx + dy * dy < P.pl_min_d2) ok = false; }
+                        for (int q = 0; q < k; ++q) {
+                            float dx = x - sh.px[q][lane], dy = y - sh.py[q][lane];
+                            if (dx * dx + dy * dy < P.pl_min_d2) ok = false;
+                        }
+                        if (ok) break;
+                    }
+                    const float2 u = draw();
+                    sh.px[k][lane] = x; sh.py[k][lane] = y; sh.pth[k][lane] = 360.0f * u.x;
+                }
+                steps = 0; prev_pot = prev_pot;   // VSS-v0 keeps prev_pot (cleared lazily by first_step)
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    ou[k][0] = 0.0f; ou[k][1] = 0.0f;
+                    r[k] = Body{};
+                    r[k].x = sh.px[k][lane]; r[k].y = sh.py[k][lane];
+                    od[k] = sh.pth[k][lane]; wd[k] = 0.0f;
+                    r[k].th = od[k];
+                    sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
+                    write_obs<KIND, TASK>(P, row, k, true, false, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, wd[k], 0, 0.0f);
+                }
+                ball = Body{};
+                ball.x = bx; ball.y = by;
+                write_obs<KIND, TASK>(P, row, N, false, true, ball.x, ball.y, ball.vx, ball.vy, 0.0f, 0.0f, 0.0f, 0, 0.0f);
+            }
+        }
+        wave_sync();
+        // ---- observation out, coalesced: 64 rows of 40 floats are one contiguous run ----
+        {
+            const size_t base = (size_t)tile * 64 * EPL_OD;
+            const size_t lim = B * (size_t)EPL_OD;
+#pragma unroll 8
+            for (int c = 0; c < EPL_OD; ++c) {
+                const int i = lane + 64 * c;
+                const float v = sh.u.stage[(i / EPL_OD) * EPL_ODP + i % EPL_OD];
+                if (base + i < lim) bufs.obs[base + i] = v;
+            }
+        }
+        wave_sync();
+    }
+
+    // ---- store (wire format) ----
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            float* p = st + (size_t)(5 + 6 * k) * B;
+            p[0] = r[k].x; p[B] = r[k].y; p[2 * B] = od[k]; p[3 * B] = r[k].vx; p[4 * B] = r[k].vy; p[5 * B] = wd[k];
+            if (k >= 1) { auxe[(size_t)(ROW_OU + 2 * k) * B] = ou[k][0]; auxe[(size_t)(ROW_OU + 2 * k + 1) * B] = ou[k][1]; }
+        }
+        st[0] = ball.x; st[B] = ball.y; st[2 * B] = K::r_ball + ball.z; st[3 * B] = ball.vx; st[4 * B] = ball.vy;
+        st[(size_t)P.state_dim * B] = ball.vz;
+        auxe[(size_t)ROW_STEPS * B] = __int_as_float(steps);
+        auxe[(size_t)ROW_EPISODE * B] = __uint_as_float(episode);
+        auxe[(size_t)ROW_PREV_POT * B] = prev_pot; auxe[(size_t)ROW_EP_RET * B] = ep_ret;
+    }
+}
+
+}  // namespace rsx

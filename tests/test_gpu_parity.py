@@ -411,6 +411,59 @@ def test_get_state_after_device_side_writes_is_not_served_from_the_step_copy():
     sim.close()
 
 
+def test_env_per_lane_layout_is_bit_identical(oracle_mod, monkeypatch):
+    """Large VSS-v0 batches are stepped by a second kernel (one lane per env, rsx_epl.hpp).  Forced
+    on a small ragged batch here: it must agree bit for bit with the CPU oracle and with the
+    8-lanes-per-env kernel — fed and random actions, contacts, TimeLimit resets, single-step and
+    multi-step launches, counters."""
+    import torch
+    L = _lib()
+    O = oracle_mod
+    B, seed, base, max_steps = 150, 31337, 77, 45
+    rng = np.random.default_rng(5)
+    outs = {}
+    refs = None
+    for layout in ("epl", "lanes"):
+        monkeypatch.setenv("RSX_LAYOUT", layout)
+        sim = L.Sim(0, 0, 3, 3, 25, B)
+        sim.task_attach(1, seed, base, max_steps)
+        tens = sim.task_tensors()
+        sim.task_reset()
+        if layout == "epl":
+            refs = _mk_oracles(O, 0, 0, 3, 3, B)
+            for e, r in enumerate(refs):
+                r.task_attach(1, seed, base + e, max_steps)
+                r.task_reset()
+        rng = np.random.default_rng(5)
+        for t in range(120):
+            if t % 3 == 0:
+                a = rng.uniform(-1, 1, (B, 2)).astype(np.float32)
+                tens["actions"].copy_(torch.from_numpy(a))
+                sim.task_step(tens["actions"].data_ptr())
+                if layout == "epl":
+                    for e, r in enumerate(refs):
+                        r.task_step(a[e])
+            else:
+                sim.task_step(None)
+                if layout == "epl":
+                    for r in refs:
+                        r.task_step(None)
+            if layout == "epl" and t % 7 == 0:
+                _cmp_task(sim, refs, tens, t)
+        sim.task_rollout(60)
+        if layout == "epl":
+            O.vec_task_step(refs, 60)
+            _cmp_task(sim, refs, tens, "rollout")
+            want = sum(r.task_out()["metrics"] for r in refs)
+            assert np.array_equal(sim.read_metrics(), want)
+        torch.cuda.synchronize()
+        outs[layout] = np.concatenate([sim.get_state_full().ravel()] + [tens[k].cpu().numpy().astype(np.float64).ravel()
+                                      for k in ("obs", "reward", "terminated", "truncated", "info", "final_obs", "steps")]
+                                      + [sim.read_metrics().astype(np.float64)])
+        sim.close()
+    assert np.array_equal(outs["epl"], outs["lanes"], equal_nan=True)
+
+
 def test_api_errors_are_reported_not_crashed():
     L = _lib()
     sim = L.Sim(0, 0, 3, 3, 25, 8)
