@@ -14,7 +14,11 @@
 
 #include "rsx.h"
 #include "rsx_kernels.hpp"
-#include "rsx_epl.hpp"
+
+namespace rsx {
+// rsx_epl.hip (own translation unit, own compiler flags)
+void launch_vss_epl(bool rollout, const Params& P, const Buffers& b, int n_steps, hipStream_t s);
+}
 
 using namespace rsx;
 
@@ -140,9 +144,7 @@ template <int KIND, int TASK, int NRS, int MODE>
 void launch_task_m(const rsx_sim* h, const float* actions, int n_steps, hipStream_t s) {
     const Buffers b = buffers_of(h, actions);
     if (TASK == RSX_TASK_VSS_V0 && (MODE == MODE_STEP || MODE == MODE_ROLLOUT) && h->epl && h->NR == 6 && h->L == 8) {
-        const int tiles = (h->P.num_envs + 63) / 64;
-        const dim3 grid((unsigned)(((tiles + 7) / 8) * 8));
-        RSX_LAUNCH((vss_epl_kernel<(MODE == MODE_ROLLOUT ? MODE_ROLLOUT : MODE_STEP)>), h->P, b, n_steps);
+        launch_vss_epl(MODE == MODE_ROLLOUT, h->P, b, n_steps, s);
         return;
     }
     const dim3 grid = grid_for(h);

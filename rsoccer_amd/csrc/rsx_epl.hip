@@ -1,0 +1,22 @@
+// rsx_epl.hip — the one-lane-per-env VSS-v0 kernel in its own translation unit: it is built with
+// the compiler's default machine scheduler (160 VGPRs -> 3 waves per SIMD next to 14 KB of LDS),
+// while rsx_api.hip is built with -amdgpu-sched-strategy=max-ilp, which suits the short
+// 8-lanes-per-env kernels at small batches but costs this one a wave of occupancy (217 VGPRs).
+#include <hip/hip_runtime.h>
+
+#include "rsx_epl.hpp"
+
+namespace rsx {
+
+void launch_vss_epl(bool rollout, const Params& P, const Buffers& b, int n_steps, hipStream_t s) {
+    const int tiles = (P.num_envs + 63) / 64;
+    const dim3 grid((unsigned)(((tiles + 7) / 8) * 8));
+    if (rollout)
+        hipLaunchKernelGGL((vss_epl_kernel<MODE_ROLLOUT>), grid, dim3(64), 0, s, b.state, b.aux, b.actions, b.flags,
+                           P.num_envs, P.state_dim, (int)(grid.x >> 3), n_steps, P, b);
+    else
+        hipLaunchKernelGGL((vss_epl_kernel<MODE_STEP>), grid, dim3(64), 0, s, b.state, b.aux, b.actions, b.flags,
+                           P.num_envs, P.state_dim, (int)(grid.x >> 3), n_steps, P, b);
+}
+
+}  // namespace rsx

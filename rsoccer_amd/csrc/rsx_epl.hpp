@@ -31,7 +31,8 @@ struct EplShared {
         struct { float snap[4][EPL_NB][64]; float acc[4][EPL_NB][64]; } c;
         float stage[64 * EPL_ODP];
     } u;
-    float px[EPL_NB][64], py[EPL_NB][64], pth[EPL_NB][64];   // reset placement (x, y, theta_deg)
+    // (the reset placement keeps its poses in the resetting env's own observation row: that row
+    // has been copied out as the terminal observation and is rewritten right after)
 };
 
 // pair p -> (i, j), i < j, lexicographic: every body then receives its partners in index order
@@ -330,6 +331,7 @@ __global__ __launch_bounds__(64) void vss_epl_kernel(RSX_HOT_ARGS, const Params 
                 };
                 float bx, by;
                 { const float2 u = draw(); bx = P.pl_xlo + P.pl_xspan * u.x; by = P.pl_ylo + P.pl_yspan * u.y; }
+                float* const px = row, * const py = row + 8, * const pth = row + 16;   // scratch: this env's obs row
                 for (int k = 0; k < N; ++k) {
                     float x = 0.0f, y = 0.0f;
                     for (int tt = 0; tt < 64; ++tt) {
@@ -339,21 +341,24 @@ __global__ __launch_bounds__(64) void vss_epl_kernel(RSX_HOT_ARGS, const Params 
                         bool ok = true;
                         { float dx = x - bx, dy = y - by; if (dx * dx + dy * dy < P.pl_min_d2) ok = false; }
                         for (int q = 0; q < k; ++q) {
-                            float dx = x - sh.px[q][lane], dy = y - sh.py[q][lane];
+                            float dx = x - px[q], dy = y - py[q];
                             if (dx * dx + dy * dy < P.pl_min_d2) ok = false;
                         }
                         if (ok) break;
                     }
                     const float2 u = draw();
-                    sh.px[k][lane] = x; sh.py[k][lane] = y; sh.pth[k][lane] = 360.0f * u.x;
+                    px[k] = x; py[k] = y; pth[k] = 360.0f * u.x;
                 }
-                steps = 0; prev_pot = prev_pot;   // VSS-v0 keeps prev_pot (cleared lazily by first_step)
+                steps = 0;   // VSS-v0 keeps prev_pot (the first step of an episode ignores it)
+                float nx[N], ny[N], nth[N];
+#pragma unroll
+                for (int k = 0; k < N; ++k) { nx[k] = px[k]; ny[k] = py[k]; nth[k] = pth[k]; }   // read all before the row is rewritten
 #pragma unroll
                 for (int k = 0; k < N; ++k) {
                     ou[k][0] = 0.0f; ou[k][1] = 0.0f;
                     r[k] = Body{};
-                    r[k].x = sh.px[k][lane]; r[k].y = sh.py[k][lane];
-                    od[k] = sh.pth[k][lane]; wd[k] = 0.0f;
+                    r[k].x = nx[k]; r[k].y = ny[k];
+                    od[k] = nth[k]; wd[k] = 0.0f;
                     r[k].th = od[k];
                     sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
                     write_obs<KIND, TASK>(P, row, k, true, false, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, wd[k], 0, 0.0f);
