@@ -197,7 +197,7 @@ def main():
         achieved = ALGO_BYTES_PER_ENV_STEP * units_per_launch / (launch_us * 1e-6) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(tp):
+        if os.path.exists(tp) and B == 4096 and args.mode == "step":   # the counters were collected on this configuration
             try:
                 traffic = json.load(open(tp)).get("bytes_per_launch")
             except Exception:
@@ -214,7 +214,8 @@ def main():
                        "envs_per_gpu": B, "launch_mode": args.mode, "sub_steps": 5, "time_step_ms": 25},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "rsx::task_step_kernel<0, 8, 1, 6, 0>" if args.mode == "step" else "rsx::task_step_kernel<0, 8, 1, 6, 3>",
+                         "kernel": ("rsx::vss_epl_kernel<%d>" if B >= 131072 and os.environ.get("RSX_LAYOUT") != "lanes" or os.environ.get("RSX_LAYOUT") == "epl"
+                                    else "rsx::task_step_kernel<0, 8, 1, 6, %d>") % (0 if args.mode == "step" else 3),
                          "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
                          "avg_launch_us": launch_us},
             "episodes": int(metrics[1]), "env_steps_counted": int(metrics[0]),
