@@ -1,5 +1,5 @@
 """In-kernel timeline incl. per-sub-step stamps, single-step launch vs the last step of a
-multi-step launch (needs a -DRSX_TIMING build: RSX_LIB=tools/_dev/librsx_hip_timing.so)."""
+multi-step launch (needs the -DRSX_TIMING build of tools/build_timing.sh: RSX_LIB=tools/_dev/librsx_hip_timing.so)."""
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
