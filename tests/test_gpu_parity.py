@@ -464,6 +464,32 @@ def test_env_per_lane_layout_is_bit_identical(oracle_mod, monkeypatch):
     assert np.array_equal(outs["epl"], outs["lanes"], equal_nan=True)
 
 
+def test_large_batch_switches_layout_and_agrees(monkeypatch):
+    """At 131 072 envs the library picks the one-lane-per-env kernel by itself; forcing the 8-lane
+    kernel on the same seeds must give the same buffers (full size, a few hundred resets)."""
+    import torch
+    L = _lib()
+    B = 131072
+    outs = []
+    for layout in (None, "lanes"):
+        if layout:
+            monkeypatch.setenv("RSX_LAYOUT", layout)
+        else:
+            monkeypatch.delenv("RSX_LAYOUT", raising=False)
+        sim = L.Sim(0, 0, 3, 3, 25, B)
+        sim.task_attach(1, 2025, 0, 0)
+        tens = sim.task_tensors()
+        sim.task_reset()
+        sim.task_step_n(25)
+        sim.task_rollout(15)
+        torch.cuda.synchronize()
+        outs.append((tens["obs"].clone(), tens["reward"].clone(), sim.state_tensor().clone(), sim.read_metrics()))
+        sim.close()
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert torch.equal(a, b)
+    assert np.array_equal(outs[0][3], outs[1][3]) and outs[0][3][1] > 0
+
+
 def test_api_errors_are_reported_not_crashed():
     L = _lib()
     sim = L.Sim(0, 0, 3, 3, 25, 8)
