@@ -4,6 +4,8 @@ The oracle (oracle/rsx_oracle.c, float instantiation) and the HIP kernels are tw
 implementations of the step model; every comparison below is exact equality of float32 bit
 patterns, over whole trajectories (collisions, goals, auto-resets, RNG included).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -462,6 +464,43 @@ def test_env_per_lane_layout_is_bit_identical(oracle_mod, monkeypatch):
                                       + [sim.read_metrics().astype(np.float64)])
         sim.close()
     assert np.array_equal(outs["epl"], outs["lanes"], equal_nan=True)
+
+
+@pytest.mark.parametrize("task,kind,ft,nb,ny,B,steps", [(1, 0, 0, 3, 3, 512, 3000), (2, 1, 2, 1, 6, 384, 2000),
+                                                       (5, 1, 2, 2, 0, 256, 1500)])
+def test_long_horizon_bitexact(oracle_mod, task, kind, ft, nb, ny, B, steps):
+    """Millions of env-steps against the oracle (OpenMP over envs): thousands of contacts, kicks,
+    resets and TimeLimit truncations; the state is compared every 500 steps — any divergence in a
+    chaotic system persists, so agreement at the checkpoints means agreement throughout."""
+    import torch
+    L = _lib()
+    O = oracle_mod
+    O.set_threads(min(16, os.cpu_count() or 1))
+    seed = 20260928
+    sim = L.Sim(kind, ft, nb, ny, 25, B)
+    sim.task_attach(task, seed, 0, 0)
+    tens = sim.task_tensors()
+    refs = _mk_oracles(O, kind, ft, nb, ny, B)
+    for e, r in enumerate(refs):
+        r.task_attach(task, seed, e, 0)
+        r.task_reset()
+    sim.task_reset()
+    done = 0
+    while done < steps:
+        n = min(500, steps - done)
+        sim.task_step_n(n - 1)
+        sim.task_step(None)
+        O.vec_task_step(refs, n)
+        done += n
+        torch.cuda.synchronize()
+        st = sim.get_state_full()
+        want = np.stack([r.get_state_full() for r in refs])
+        assert f32_equal(st, want), mismatch_report(st, want, f"state after {done} steps")
+    got = sim.read_metrics()
+    want = sum(r.task_out()["metrics"] for r in refs)
+    assert np.array_equal(got, want), (got, want)
+    assert got[1] > B // 4
+    sim.close()
 
 
 def test_large_batch_switches_layout_and_agrees(monkeypatch):
