@@ -137,7 +137,6 @@ def test_task_random_actions_bitexact(oracle_mod, task, kind, ft, nb, ny, B, ste
         r.task_attach(task, seed, base + e, max_steps)
         r.task_reset()
     sim.task_reset()
-    _cmp_task(sim, refs, {**tens, "reward": tens["reward"] * 0}, -1) if False else None
     import torch
     torch.cuda.synchronize()
     obs = tens["obs"].cpu().numpy()
