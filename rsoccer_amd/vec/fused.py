@@ -44,6 +44,7 @@ class VecFusedEnv:
         self.max_episode_steps = self.sim.max_episode_steps
         self._t = self.sim.task_tensors()
         self._info_views = None
+        self._pending = None
         self.field = self.sim.get_field_params()
         self.single_action_space = gym.spaces.Box(low=-1, high=1, shape=(self.sim.act_dim,), dtype=np.float32)
         self.single_observation_space = gym.spaces.Box(low=-1.2, high=1.2, shape=(self.sim.obs_dim,), dtype=np.float32)
@@ -101,6 +102,21 @@ class VecFusedEnv:
         self.sim.task_step(ptr, self._stream())
         t = self._t
         return t["obs"], t["reward"], t["terminated"], t["truncated"], self._info()
+
+    def step_async(self, actions=None):
+        """``gymnasium.vector``-style split call: enqueue the step (host-asynchronous, stream-ordered,
+        exactly what ``step`` does)."""
+        self._pending = self.step(actions)
+
+    def step_wait(self, synchronize=False):
+        """Results of the last ``step_async``: device tensors that are valid in stream order;
+        ``synchronize=True`` also blocks the host until the launch has finished."""
+        out, self._pending = self._pending, None
+        if out is None:
+            raise RuntimeError("step_wait() without step_async()")
+        if synchronize:
+            self._torch.cuda.current_stream(self.device).synchronize()
+        return out
 
     def step_random(self, n=1, fused=False):
         """``n`` steps with device-side random actions: ``n`` launches issued from C, or

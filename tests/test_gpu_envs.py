@@ -124,6 +124,23 @@ def test_vec_env_api_and_determinism():
             e.close()
 
 
+def test_step_async_wait_is_the_same_step():
+    import torch
+    from rsoccer_amd.vec import VecVSSEnv
+    a = VecVSSEnv(16, seed=5)
+    b = VecVSSEnv(16, seed=5)
+    a.reset(); b.reset()
+    act = torch.rand(16, 2, device="cuda") * 2 - 1
+    for _ in range(5):
+        o1, r1, t1, u1, _ = a.step(act)
+        b.step_async(act)
+        o2, r2, t2, u2, _ = b.step_wait(synchronize=True)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(t1, t2) and torch.equal(u1, u2)
+    with pytest.raises(RuntimeError):
+        b.step_wait()
+    a.close(); b.close()
+
+
 def test_time_limit_truncates_and_auto_resets():
     import torch
     from rsoccer_amd.vec import VecVSSEnv
