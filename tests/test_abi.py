@@ -87,3 +87,14 @@ def test_bench_cpu_baseline_leg_runs(oracle_mod):
     r = bench.cpu_baseline(64, budget_s=0.3, single_s=0.1)
     assert r["kind"] == "port" and r["cores"] >= 1 and r["value"] > 1e4 and r["single_thread_value"] > 1e4
     assert "64 envs" in r["sample"]
+
+
+def test_header_is_plain_c_and_the_c_example_builds(tmp_path):
+    """include/rsx.h must be usable from C (the reference-side binding could be cgo / JNI / a C
+    extension): examples/rsx_c_host.c includes it and compiles with gcc -Wall -Werror."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "rsx_c_host"
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "rsx_c_host.c"), "-o", str(out), "-ldl"])
+    assert out.exists()

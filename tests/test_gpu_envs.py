@@ -256,3 +256,16 @@ def test_pass_endurance_ball_is_held_and_can_be_passed():
     assert np.hypot(env.frame.ball.v_x, env.frame.ball.v_y) > 3.0
     assert np.hypot(env.frame.ball.x - b0[0], env.frame.ball.y - b0[1]) > 0.1
     env.close()
+
+
+def test_plain_c_host_drives_the_library(tmp_path):
+    """examples/rsx_c_host.c: dlopen + the C-ABI from a C program (no Python, no torch in that
+    process) — robosim-style reset / step / get_state and a fused VSS-v0 run."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "rsx_c_host"
+    subprocess.check_call(["gcc", "-O2", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "rsx_c_host.c"), "-o", str(exe), "-ldl"])
+    res = subprocess.run([str(exe), os.path.join(root, "rsoccer_amd", "librsx_hip.so")], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "ok" in res.stdout
