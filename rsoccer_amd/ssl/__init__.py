@@ -1,0 +1,1 @@
+"""SSL (RoboCup Small Size League) environments served by the MI355X step engine."""
