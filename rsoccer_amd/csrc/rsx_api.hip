@@ -109,7 +109,8 @@ void pick_variant(rsx_sim* h) {
     const int N = h->P.n_robots;
     h->NR = 0;
     if (std::getenv("RSX_GENERIC_KERNELS")) return;
-    if (h->P.kind == RSX_KIND_VSS && N == 6 && h->L == 8) h->NR = 6;
+    if (h->P.kind == RSX_KIND_VSS && N == 6 && h->L == 8 && h->P.n_blue == 3) h->NR = 6;
+    if (h->P.kind == RSX_KIND_VSS && N == 10 && h->L == 16 && h->P.n_blue == 5) h->NR = 10;   // 5v5 field
     if (h->P.kind == RSX_KIND_SSL && N == 7 && h->L == 8) h->NR = 7;
     if (h->P.kind == RSX_KIND_SSL && N == 22 && h->L == 32) h->NR = 22;
 }
@@ -125,6 +126,7 @@ void launch_sim_k(const rsx_sim* h, hipStream_t s) {
     const dim3 grid = grid_for(h);
     const Buffers b = buffers_of(h, nullptr);
     if (KIND == RSX_KIND_VSS && h->NR == 6) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 8, (KIND == RSX_KIND_VSS ? 6 : 0)>), h->P, b); return; }
+    if (KIND == RSX_KIND_VSS && h->NR == 10) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 16, (KIND == RSX_KIND_VSS ? 10 : 0)>), h->P, b); return; }
     if (KIND == RSX_KIND_SSL && h->NR == 7) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 8, (KIND == RSX_KIND_SSL ? 7 : 0)>), h->P, b); return; }
     if (KIND == RSX_KIND_SSL && h->NR == 22) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 32, (KIND == RSX_KIND_SSL ? 22 : 0)>), h->P, b); return; }
     switch (h->L) {
@@ -149,6 +151,10 @@ void launch_task_m(const rsx_sim* h, const float* actions, int n_steps, hipStrea
     }
     const dim3 grid = grid_for(h);
     if (h->NR == NRS && h->L == 8) { RSX_LAUNCH((task_step_kernel<KIND, 8, TASK, NRS, MODE>), h->P, b, n_steps); return; }
+    if (TASK == RSX_TASK_VSS_V0 && h->NR == 10 && h->L == 16) {   // VSS-v0 on the 5v5 field
+        RSX_LAUNCH((task_step_kernel<KIND, 16, TASK, (TASK == RSX_TASK_VSS_V0 ? 10 : 0), MODE>), h->P, b, n_steps);
+        return;
+    }
     switch (h->L) {
         case 8: RSX_LAUNCH((task_step_kernel<KIND, 8, TASK, 0, MODE>), h->P, b, n_steps); break;
         case 16: RSX_LAUNCH((task_step_kernel<KIND, 16, TASK, 0, MODE>), h->P, b, n_steps); break;

@@ -930,7 +930,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
     const uint32_t env_id = P.env_id_base + (uint32_t)e;
     // observation width: a compile-time constant when the team sizes are (lets the copy-out unroll)
     constexpr int OD_C = NR == 0 ? 0
-        : TASK == RSX_TASK_VSS_V0 ? 40                        // 3v3: 4 + 7*3 + 5*3 (vss_gym.py:64-67)
+        : TASK == RSX_TASK_VSS_V0 ? 4 + 6 * NR                // equal teams: 4 + 7*nb + 5*ny (vss_gym.py:64-67): 40 for 3v3, 64 for 5v5
         : TASK == RSX_TASK_SSL_STATIC_DEFENDERS ? 4 + 8 + 2 * (NR - 1)
         : TASK == RSX_TASK_SSL_DRIBBLING ? 21 : TASK == RSX_TASK_SSL_CONTESTED ? 14 : 16;
     const int OD = OD_C ? OD_C : P.obs_dim;
