@@ -112,6 +112,7 @@ void pick_variant(rsx_sim* h) {
     if (h->P.kind == RSX_KIND_VSS && N == 6 && h->L == 8 && h->P.n_blue == 3) h->NR = 6;
     if (h->P.kind == RSX_KIND_VSS && N == 10 && h->L == 16 && h->P.n_blue == 5) h->NR = 10;   // 5v5 field
     if (h->P.kind == RSX_KIND_SSL && N == 7 && h->L == 8) h->NR = 7;
+    if (h->P.kind == RSX_KIND_SSL && N == 12 && h->L == 16) h->NR = 12;   // 6v6 (field_type 0, ssl/README.md:4)
     if (h->P.kind == RSX_KIND_SSL && N == 22 && h->L == 32) h->NR = 22;
 }
 
@@ -128,6 +129,7 @@ void launch_sim_k(const rsx_sim* h, hipStream_t s) {
     if (KIND == RSX_KIND_VSS && h->NR == 6) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 8, (KIND == RSX_KIND_VSS ? 6 : 0)>), h->P, b); return; }
     if (KIND == RSX_KIND_VSS && h->NR == 10) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 16, (KIND == RSX_KIND_VSS ? 10 : 0)>), h->P, b); return; }
     if (KIND == RSX_KIND_SSL && h->NR == 7) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 8, (KIND == RSX_KIND_SSL ? 7 : 0)>), h->P, b); return; }
+    if (KIND == RSX_KIND_SSL && h->NR == 12) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 16, (KIND == RSX_KIND_SSL ? 12 : 0)>), h->P, b); return; }
     if (KIND == RSX_KIND_SSL && h->NR == 22) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 32, (KIND == RSX_KIND_SSL ? 22 : 0)>), h->P, b); return; }
     switch (h->L) {
         case 8: RSX_LAUNCH_SIM((sim_step_kernel<KIND, 8, 0>), h->P, b); break;

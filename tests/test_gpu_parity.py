@@ -28,6 +28,8 @@ CASES = [
     (0, 0, 3, 3, 67, 60, 0.5),     # VSS 3v3 (ragged batch: 67 is not a multiple of 8)
     (0, 1, 5, 5, 33, 40, 0.5),     # VSS 5v5 -> 16 lanes per env
     (1, 2, 1, 6, 41, 60, 0.4),     # SSL 1v6
+    (1, 0, 6, 6, 21, 40, 0.3),     # SSL 6v6 -> 16 lanes per env, fixed-size variant
+    (1, 0, 4, 3, 11, 30, 0.3),     # SSL 4v3 -> run-time robot count
     (1, 1, 11, 11, 19, 40, 0.25),  # SSL 11v11 -> 32 lanes per env, crowded
     (1, 0, 2, 0, 5, 30, 0.2),      # SSL 2v0 (empty yellow team)
 ]
