@@ -181,24 +181,6 @@ __device__ __forceinline__ void robot_targets(const Params& P, Body& o, const fl
     }
 }
 
-// one robot-robot (or, for VSS, any circle-circle) contact seen from body `o`
-__device__ __forceinline__ void circle_contact(const Body& o, const float4 oj, const float rs,
-                                               const float rs2, const float ope, const float w,
-                                               const float beta, const bool enabled, float& avx,
-                                               float& avy, float& apx, float& apy) {
-    // a body never touches itself: its own slot gives d2 == 0, rejected by d2 > 0
-    float dx = oj.x - o.x, dy = oj.y - o.y;
-    float d2 = fma_(dx, dx, dy * dy);
-    if ((d2 < rs2) & (d2 > 0.0f) & enabled) {
-        float d = sqrtf(d2), inv = 1.0f / d;
-        float nx = dx * inv, ny = dy * inv, pen = rs - d;
-        float vn = fma_(oj.z - o.vx, nx, (oj.w - o.vy) * ny);
-        if (vn < 0.0f) { float q = ope * vn * w; avx = fma_(q, nx, avx); avy = fma_(q, ny, avy); }
-        float pc = beta * pen * w;
-        apx = fma_(-pc, nx, apx); apy = fma_(-pc, ny, apy);
-    }
-}
-
 // contact response once a pair is known to overlap (d2 = squared centre distance)
 __device__ __forceinline__ void contact_response(const Body& o, const float4 oj, const float d2,
                                                  const float rs, const float ope, const float w,
@@ -338,14 +320,28 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                         }
                     }
                 } else {
+                    // run-time robot count: same two phases (exact integer overlap test into a bit per
+                    // partner, then the per-lane partner walk), the loops just are not unrolled
+                    constexpr uint32_t T_RR = __builtin_bit_cast(uint32_t, K::rs_rr2) - 1u;
+                    constexpr uint32_t T_RB = __builtin_bit_cast(uint32_t, K::rs_rb2) - 1u;
+                    unsigned todo = 0;
+#pragma unroll 4
                     for (int j = 0; j <= N; ++j) {
-                        if (j == b) continue;
                         const float4 oj = sh.A[j * G + g];
                         const bool rb = is_ball || j == N;
-                        circle_contact(o, oj, rb ? K::rs_rb : K::rs_rr, rb ? K::rs_rb2 : K::rs_rr2,
-                                       rb ? K::ope_rb : K::ope_rr,
-                                       is_ball ? K::w_rb_b : (j == N ? K::w_rb_r : K::w_rr), K::beta,
-                                       !rb || ball_low, avx, avy, apx, apy);
+                        const float dx = oj.x - o.x, dy = oj.y - o.y;
+                        const uint32_t u = __float_as_uint(fma_(dx, dx, dy * dy)) - 1u;   // own slot: 0xFFFFFFFF
+                        todo |= ((u < (rb ? T_RB : T_RR)) & (!rb | ball_low)) ? 1u << j : 0u;
+                    }
+                    while (todo) {
+                        const int j = __builtin_ctz(todo);
+                        todo &= todo - 1;
+                        const float4 oj = sh.A[j * G + g];
+                        const float dx = oj.x - o.x, dy = oj.y - o.y;
+                        const bool rb = is_ball || j == N;
+                        contact_response(o, oj, fma_(dx, dx, dy * dy), rb ? K::rs_rb : K::rs_rr, rb ? K::ope_rb : K::ope_rr,
+                                         is_ball ? K::w_rb_b : (j == N ? K::w_rb_r : K::w_rr), K::beta,
+                                         avx, avy, apx, apy);
                     }
                 }
             }
@@ -384,10 +380,20 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                         }
                     }
                 } else {
+                    constexpr uint32_t T_RR = __builtin_bit_cast(uint32_t, K::rs_rr2) - 1u;
+                    unsigned todo = 0;
+#pragma unroll 4
                     for (int j = 0; j < N; ++j) {
-                        if (j == b) continue;
-                        circle_contact(o, sh.A[j * G + g], K::rs_rr, K::rs_rr2, K::ope_rr, K::w_rr, K::beta,
-                                       true, avx, avy, apx, apy);
+                        const float4 oj = sh.A[j * G + g];
+                        const float dx = oj.x - o.x, dy = oj.y - o.y;
+                        todo |= (__float_as_uint(fma_(dx, dx, dy * dy)) - 1u) < T_RR ? 1u << j : 0u;
+                    }
+                    while (todo) {
+                        const int j = __builtin_ctz(todo);
+                        todo &= todo - 1;
+                        const float4 oj = sh.A[j * G + g];
+                        const float dx = oj.x - o.x, dy = oj.y - o.y;
+                        contact_response(o, oj, fma_(dx, dx, dy * dy), K::rs_rr, K::ope_rr, K::w_rr, K::beta, avx, avy, apx, apy);
                     }
                 }
                 // robot - ball: kicker mouth (flat face at dck) or body circle; n points robot -> ball
