@@ -66,6 +66,7 @@ fused("configs[2] SSLStaticDefenders-v0 1v6 fused", 1, 2, 1, 6, 2, 2048, 981)
 fused("SSLDribbling-v0 1v4 fused", 1, 2, 1, 4, 3, 2048, 2 * 4 * 60 + 4 * 40 + 4 * 21 + 5)
 fused("SSLContestedPossession-v0 1v1 fused", 1, 2, 1, 1, 4, 2048, 2 * 4 * 27 + 4 * 16 + 4 * 14 + 5)
 fused("SSLPassEndurance-v0 2v0 fused", 1, 2, 2, 0, 5, 2048, 2 * 4 * 27 + 4 * 16 + 4 * 16 + 5)
+fused("VSS-v0 on the 5v5 field (field_type 1) fused", 0, 1, 5, 5, 1, 4096, 2 * 4 * 66 + 4 * 20 + 4 * 64 + 5)
 raw_ssl("configs[3] SSL 11v11 raw sim, spread", 1, 11, 11, 1024, False, 2680)
 raw_ssl("configs[3] SSL 11v11 raw sim, crowded (worst-case contacts)", 1, 11, 11, 1024, True, 2680)
 for B in (256, 1024, 16384, 65536, 262144, 1048576, 4194304):
