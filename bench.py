@@ -100,8 +100,8 @@ def cpu_baseline(envs, budget_s=12.0, single_s=1.5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3000)
-    ap.add_argument("--warmup", type=int, default=300)
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--mode", choices=["step", "rollout"], default="step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
