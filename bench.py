@@ -11,7 +11,7 @@ OU noise for the other five robots, 5 physics sub-steps, observation, reward, do
 and same-step auto-reset, in ONE kernel launch per step (mode `step`, the default and the value
 reported).  All inputs are resident in HBM before the timed region.  With N > 1 each rank owns
 envs [rank*B, (rank+1)*B) (weak scaling, no data-path collective); a 64-byte metrics vector is
-all-reduced over RCCL every 200 steps (a ~20 us stream-ordered collective).
+all-reduced over RCCL every 100 steps (a ~20 us stream-ordered collective).
 
 Prints ONE JSON line on rank 0 (see the driver contract); extra keys: `roofline`,
 `cpu_baseline`, `rollout` (the same work with all K steps inside one launch).
@@ -135,7 +135,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     sim.task_reset(stream)
     mbuf = torch.zeros(L.N_METRICS, dtype=torch.int64, device="cuda")
-    ALLREDUCE_EVERY = 200   # steps between metrics all-reduces
+    ALLREDUCE_EVERY = 100   # steps between metrics all-reduces
 
     def allreduce_metrics():
         """The only inter-GPU exchange: sum of the 8-entry int64 metrics vector (64 bytes).
