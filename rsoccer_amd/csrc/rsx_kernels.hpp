@@ -307,16 +307,27 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                             const bool rb = is_ball || j == NR;
                             todo |= ((u[j] < (rb ? T_RB : T_RR)) & (!rb | ball_low)) ? 1u << j : 0u;
                         }
-                        while (todo) {
-                            const int j = __builtin_ctz(todo);
-                            todo &= todo - 1;
-                            const float4 oj = sh.A[j * G + g];
+                        // software-pipelined: the next partner's slot is fetched while the current
+                        // response is being computed
+                        int jn = __builtin_ctz(todo);
+                        todo &= todo - 1;
+                        float4 nxt = sh.A[jn * G + g];
+                        for (;;) {
+                            const int j = jn;
+                            const float4 oj = nxt;
+                            const bool more = todo != 0;
+                            if (more) {
+                                jn = __builtin_ctz(todo);
+                                todo &= todo - 1;
+                                nxt = sh.A[jn * G + g];
+                            }
                             const float dx = oj.x - o.x, dy = oj.y - o.y;
                             const float d2 = fma_(dx, dx, dy * dy);   // the value the sweep above saw
                             const bool rb = is_ball || j == NR;
                             contact_response(o, oj, d2, rb ? K::rs_rb : K::rs_rr, rb ? K::ope_rb : K::ope_rr,
                                              is_ball ? K::w_rb_b : (j == NR ? K::w_rb_r : K::w_rr), K::beta,
                                              avx, avy, apx, apy);
+                            if (!more) break;
                         }
                     }
                 } else {
