@@ -2,6 +2,10 @@
 """Headline benchmark: env-steps/s of the fused VSS-v0 3v3 step at 4096 envs per GPU.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--mode step|rollout] [--envs B]
+
+`--gpus N` with N > 1 starts its own N ranks (one process per GPU, `torch.distributed.run` on
+127.0.0.1) when it is not already running under torchrun; the torchrun form works as well:
+
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -13,12 +17,22 @@ reported).  All inputs are resident in HBM before the timed region.  With N > 1 
 envs [rank*B, (rank+1)*B) (weak scaling, no data-path collective); a 64-byte metrics vector is
 all-reduced over RCCL every 100 steps (a ~20 us stream-ordered collective).
 
-Prints ONE JSON line on rank 0 (see the driver contract); extra keys: `roofline`,
-`cpu_baseline`, `rollout` (the same work with all K steps inside one launch).
+Prints ONE JSON line on rank 0 (see the driver contract).  Besides the contract's keys:
+  roofline      dominant kernel of the timed leg, HIP-event launch average, algorithmic bytes
+  steady        the same per-step launches over >= 2000 steps after >= 200,
+                whatever --steps / --warmup were
+  rollout       the same K steps inside ONE launch
+  sweep         (N = 1) per-step and one-launch legs at 65 536 / 1 048 576 / 4 194 304 envs with their
+                own roofline fractions: where the path is bandwidth-bound
+  python_layer  (N = 1) rate of the Python API on top of the C-ABI, and the reference's Python-layer
+                ceiling restated from SURVEY.md
+  cpu_baseline  (N = 1) the CPU oracle on this box's host cores, bounded sample
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,6 +41,11 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_ENV_STEP = 541   # VSS-v0 fused = 2*164 (state r/w) + 48 (cmds) + 160 (obs) + 4 + 1
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+METRIC = "env-steps/sec (whole node), VSS-v0 3v3 @4096 envs, 1/2/4/8 GPU + CPU ref"
+ALLREDUCE_EVERY = 100           # steps between metrics all-reduces
+STEADY_STEPS, STEADY_WARMUP = 2000, 200
+SWEEP_ENVS = (65536, 1048576, 4194304)
+EPL_MIN_ENVS = 131072           # rsx_api.hip: batches from here on use the one-lane-per-env kernel
 
 
 def usable_cores():
@@ -65,6 +84,27 @@ def ensure_built(local_rank):
         time.sleep(0.5)
 
 
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n_ranks, argv):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks ourselves (one process per
+    GPU, rendezvous on 127.0.0.1) and hand their exit status back.  Rank 0's JSON line is the only
+    thing the children write to stdout."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 def cpu_baseline(envs, budget_s=12.0, single_s=1.5):
     """Times the CPU oracle (oracle/, float instantiation, OpenMP over envs) on a bounded sample
     of the same workload.  This is the only place bench.py touches oracle/."""
@@ -94,7 +134,54 @@ def cpu_baseline(envs, budget_s=12.0, single_s=1.5):
     dt = time.perf_counter() - t0
     return {"value": envs * done / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"{envs} envs x {done} fused VSS-v0 steps, CPU oracle (float), OpenMP over envs",
-            "single_thread_value": one}
+            "single_thread_value": one,
+            "note": "a port of this project's own 2-D model (oracle/), not rc-robosim: the reference's physics "
+                    "engine is not in /root/reference and cannot be built or run here"}
+
+
+def kernel_name(envs, mode):
+    lay = os.environ.get("RSX_LAYOUT")
+    epl = lay == "epl" or (lay != "lanes" and envs >= EPL_MIN_ENVS)
+    return ("rsx::vss_epl_kernel<%d>" if epl else "rsx::task_step_kernel<0, 8, 1, 6, %d>") % (0 if mode == "step" else 3)
+
+
+def roofline_of(envs, launch_us, units_per_launch, mode, traffic=None, traffic_source=None):
+    achieved = ALGO_BYTES_PER_ENV_STEP * units_per_launch / (launch_us * 1e-6) / 1e9
+    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+         "kernel": kernel_name(envs, mode), "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
+         "avg_launch_us": launch_us}
+    if traffic_source:
+        r["traffic_source"] = traffic_source
+    if envs < 65536:
+        waves = (envs + 7) // 8
+        r["regime"] = (f"latency / instruction-issue bound at this batch: {waves} single-wave workgroups on 1024 SIMDs; "
+                       "the HBM roofline is the nominal bound of the path (see `sweep` for the bandwidth-bound batches)")
+    return r
+
+
+def dry_run(args, rank, world):
+    """Launcher / collective plumbing without a GPU (CPU test of `--gpus N`): gloo ranks shard the env
+    ids, all-reduce a metrics vector and rank 0 prints the line."""
+    import torch
+    import torch.distributed as dist
+    from rsoccer_amd import dist as rdist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    base, count = rdist.shard(world * args.envs, rank, world)
+    m = torch.zeros(8, dtype=torch.int64)
+    m[0] = count * args.steps
+    m[7] = base
+    if world > 1:
+        dist.all_reduce(m)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "dry_run": True, "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "env_steps_counted": int(m[0]),
+                          "env_id_bases_sum": int(m[7])}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -106,56 +193,71 @@ def main():
     ap.add_argument("--mode", choices=["step", "rollout"], default="step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rollout", action="store_true", help="skip the extra one-launch rollout leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the steady / sweep / python_layer legs")
+    ap.add_argument("--dry-run", action="store_true", help="launcher + collective plumbing only (no GPU)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and not (args.gpus == 1 and world == 1):
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     ensure_built(local_rank)
 
     import torch
     import torch.distributed as dist
     from rsoccer_amd import _lib as L
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torchrun with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the step engine has no CPU path")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    # RSX_BENCH_SHARE_DEVICE=1 (test mode): more ranks than devices, metrics all-reduced over gloo.
+    # RCCL wants one device per rank, which is also the only configuration that is a benchmark.
+    share = os.environ.get("RSX_BENCH_SHARE_DEVICE") == "1"
+    if world > ndev and not share:
+        raise SystemExit(f"--gpus {world} but only {ndev} device(s) visible")
+    dev = local_rank % ndev
+    torch.cuda.set_device(dev)
     # RSX_BENCH_FORCE_DIST=1 runs the RCCL path even with one rank (used to test it on a 1-GPU box)
     distributed = world > 1 or os.environ.get("RSX_BENCH_FORCE_DIST") == "1"
+    backend = "gloo" if share else "nccl"
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        kw = {"device_id": torch.device("cuda", dev)} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
     B, K, W = args.envs, args.steps, args.warmup
-    sim = L.Sim(L.KIND_VSS, 0, 3, 3, 25, B, local_rank)
+    sim = L.Sim(L.KIND_VSS, 0, 3, 3, 25, B, dev)
     sim.task_attach(L.TASK_VSS_V0, seed=0, env_id_base=rank * B, max_episode_steps=0)
     tens = sim.task_tensors()
     stream = torch.cuda.current_stream().cuda_stream
     sim.task_reset(stream)
-    mbuf = torch.zeros(L.N_METRICS, dtype=torch.int64, device="cuda")
-    ALLREDUCE_EVERY = 100   # steps between metrics all-reduces
+    mbuf = torch.zeros(L.N_METRICS, dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
 
     def allreduce_metrics():
-        """The only inter-GPU exchange: sum of the 8-entry int64 metrics vector (64 bytes).
-        Enqueued on the compute stream as a stream-ordered (host-asynchronous) collective:
-        measured on MI355X, recording a HIP event on a busy stream costs ~200 us of stream time,
-        so the async_op=True / side-stream forms of torch.distributed (which record events) are
-        3 orders of magnitude more expensive than the ~20 us collective itself."""
-        mbuf.copy_(tens["metrics"], non_blocking=True)
+        """The only inter-GPU exchange: sum of the 8-entry int64 metrics vector (64 bytes), all eight
+        entries counted on the device.  Enqueued on the compute stream as a stream-ordered
+        (host-asynchronous) collective: measured on MI355X, recording a HIP event on a busy stream
+        costs ~200 us of stream time, so the async_op=True / side-stream forms of torch.distributed
+        (which record events) are 3 orders of magnitude more expensive than the ~20 us collective."""
+        mbuf.copy_(tens["metrics"], non_blocking=backend == "nccl")
         dist.all_reduce(mbuf)
 
-    def run(n, timed_mode):
+    def run(s, n, timed_mode):
         if timed_mode == "rollout":
-            sim.task_rollout(n, stream)
+            s.task_rollout(n, stream)
             return
         done = 0
         while done < n:
             m = min(ALLREDUCE_EVERY, n - done)
-            sim.task_step_n(m, stream)   # m launches, one per env.step()
+            s.task_step_n(m, stream)   # m launches, one per env.step()
             done += m
-            if distributed and not os.environ.get("RSX_BENCH_NO_ALLREDUCE"):
+            if distributed and s is sim and not os.environ.get("RSX_BENCH_NO_ALLREDUCE"):
                 allreduce_metrics()
 
     def barrier():
@@ -163,47 +265,60 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(mode):
-        run(W, mode)
+    def timed(s, n, warm, mode):
+        """warm untimed steps, then EXACTLY n steps bracketed by barrier + synchronize; returns the
+        max wall time over ranks and this rank's HIP-event time of the same region (ms)."""
+        run(s, warm, mode) if warm else None
         barrier()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record()
-        run(K, mode)
+        run(s, n, mode)
         ev1.record()
         torch.cuda.synchronize()
         barrier()
         wall = time.perf_counter() - t0
         dev_ms = ev0.elapsed_time(ev1)
         if distributed:
-            t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+            t = torch.tensor([wall], dtype=torch.float64, device=mbuf.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             wall = float(t.item())
         return wall, dev_ms
 
-    wall, dev_ms = timed(args.mode)
-    wall_r, dev_ms_r = timed("rollout") if args.mode == "step" and not args.no_rollout else (None, None)
+    wall, dev_ms = timed(sim, K, W, args.mode)
+    per_rank_ms = None
+    if distributed:
+        g = torch.zeros(world, dtype=torch.float64, device=mbuf.device)
+        g[rank] = dev_ms / K
+        dist.all_reduce(g)
+        per_rank_ms = [float(x) for x in g.cpu()]
+    extra = not args.no_extra and args.mode == "step"
+    steady = None
+    if extra and (K < STEADY_STEPS or W < STEADY_WARMUP):
+        steady = timed(sim, STEADY_STEPS, max(0, STEADY_WARMUP - (W + K)), "step")
+    roll = timed(sim, K, W, "rollout") if args.mode == "step" and not args.no_rollout else None
 
     metrics = sim.read_metrics()
     if distributed:
-        mt = torch.from_numpy(metrics).cuda()
+        mt = torch.from_numpy(metrics).to(mbuf.device)
         dist.all_reduce(mt)
         metrics = mt.cpu().numpy()
 
+    line = None
     if rank == 0:
         value = world * B * K / wall
         launch_us = dev_ms * 1e3 / K if args.mode == "step" else dev_ms * 1e3   # per kernel launch
         units_per_launch = B if args.mode == "step" else B * K
-        achieved = ALGO_BYTES_PER_ENV_STEP * units_per_launch / (launch_us * 1e-6) / 1e9
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        traffic, tsrc = None, None
+        tp = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
         if os.path.exists(tp) and B == 4096 and args.mode == "step":   # the counters were collected on this configuration
             try:
                 traffic = json.load(open(tp)).get("bytes_per_launch")
+                tsrc = "profiles/r02_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate pass of this command; not measured in this run)"
             except Exception:
                 traffic = None
         line = {
-            "metric": "env-steps/sec (whole node), VSS-v0 3v3 @4096 envs, 1/2/4/8 GPU + CPU ref",
+            "metric": METRIC,
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": wall * 1e3 / K, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -211,25 +326,119 @@ def main():
                                    f"(BASELINE.json configs[1]); one kernel launch per env.step()"
                                    if args.mode == "step" else
                                    f"VSS-v0 3v3 fused step, {B} envs per GPU, random actions, all {K} steps in one launch",
-                       "envs_per_gpu": B, "launch_mode": args.mode, "sub_steps": 5, "time_step_ms": 25},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("rsx::vss_epl_kernel<%d>" if B >= 131072 and os.environ.get("RSX_LAYOUT") != "lanes" or os.environ.get("RSX_LAYOUT") == "epl"
-                                    else "rsx::task_step_kernel<0, 8, 1, 6, %d>") % (0 if args.mode == "step" else 3),
-                         "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
-                         "avg_launch_us": launch_us},
+                       "envs_per_gpu": B, "launch_mode": args.mode, "sub_steps": 5, "time_step_ms": 25,
+                       "physics": "project-defined 2-D rigid-body model (DESIGN.md 4); not validated against rc-robosim, "
+                                  "whose sources are not part of the reference tree"},
+            "roofline": roofline_of(B, launch_us, units_per_launch, args.mode, traffic, tsrc),
             "episodes": int(metrics[1]), "env_steps_counted": int(metrics[0]),
         }
-        if wall_r is not None:
-            line["rollout"] = {"value": world * B * K / wall_r, "unit": "env-steps/s",
-                               "us_per_step": dev_ms_r * 1e3 / K,
+        if distributed:
+            line["collective"] = {"backend": "rccl" if backend == "nccl" else "gloo (shared device, test mode)",
+                                  "ranks": world, "payload_bytes": 8 * L.N_METRICS, "every_steps": ALLREDUCE_EVERY,
+                                  "per_rank_ms_per_step": per_rank_ms}
+        if steady is not None:
+            sw, sd = steady
+            line["steady"] = {"value": world * B * STEADY_STEPS / sw, "unit": "env-steps/s", "steps": STEADY_STEPS,
+                              "after_steps": max(W + K, STEADY_WARMUP), "us_per_step": sd * 1e3 / STEADY_STEPS,
+                              "roofline_frac": roofline_of(B, sd * 1e3 / STEADY_STEPS, B, "step")["frac"],
+                              "note": "same per-step launches as `value`, SURVEY.md 8(d) config 2 sample size"}
+        elif args.mode == "step":
+            line["steady"] = {"value": value, "unit": "env-steps/s", "steps": K, "after_steps": W,
+                              "us_per_step": launch_us, "roofline_frac": line["roofline"]["frac"],
+                              "note": "the timed leg itself meets SURVEY.md 8(d) config 2 (>= 2000 steps after >= 200)"}
+        if roll is not None:
+            rw, rd = roll
+            line["rollout"] = {"value": world * B * K / rw, "unit": "env-steps/s",
+                               "us_per_step": rd * 1e3 / K,
+                               "roofline_frac": roofline_of(B, rd * 1e3, B * K, "rollout")["frac"],
                                "note": "same K fused steps inside ONE launch (state stays in registers)"}
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(B)
-        print(json.dumps(line), flush=True)
     sim.close()
+
+    if rank == 0 and world == 1 and extra:
+        line["sweep"] = sweep(L, torch, dev, timed)
+        line["python_layer"] = python_layer(torch, dev)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(B)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
     if distributed:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def sweep(L, torch, dev, timed, n=100, warm=30):
+    """Where the path is bandwidth-bound: the same fused step at large batches, one launch per step
+    and all steps in one launch, each with its own roofline fraction (HIP events on the launch stream)."""
+    out = []
+    for B in SWEEP_ENVS:
+        try:
+            free, _ = torch.cuda.mem_get_info()
+            if free < B * 1200:
+                out.append({"envs": B, "skipped": f"only {free >> 20} MiB free"})
+                continue
+            s = L.Sim(L.KIND_VSS, 0, 3, 3, 25, B, dev)
+            s.task_attach(L.TASK_VSS_V0, seed=0, env_id_base=0, max_episode_steps=0)
+            s.task_reset(torch.cuda.current_stream().cuda_stream)
+            w1, d1 = timed(s, n, warm, "step")
+            w2, d2 = timed(s, n, 0, "rollout")
+            s.close()
+            del s
+            torch.cuda.empty_cache()
+            out.append({"envs": B, "kernel": kernel_name(B, "step"),
+                        "step": {"us_per_step": d1 * 1e3 / n, "value": B * n / w1,
+                                 "roofline_frac": roofline_of(B, d1 * 1e3 / n, B, "step")["frac"]},
+                        "rollout": {"us_per_step": d2 * 1e3 / n, "value": B * n / w2,
+                                    "roofline_frac": roofline_of(B, d2 * 1e3, B * n, "rollout")["frac"]},
+                        "steps": n, "warmup": warm})
+        except Exception as ex:   # a failed sweep point must not lose the headline line
+            out.append({"envs": B, "error": repr(ex)})
+    return out
+
+
+def python_layer(torch, dev, B=4096, n=2000):
+    """Rate of the Python API above the C-ABI (what a trainer calls), with device-resident actions;
+    and the reference's own Python-layer ceiling, restated."""
+    out = {"reference_python_layer_ceiling_steps_per_s_per_core": 4900,
+           "reference_note": "SURVEY.md 0-4: the reference's Python hooks alone (no physics) cap it at ~4.9 k env-steps/s/core"}
+    try:
+        from rsoccer_amd.vec import VecVSSEnv
+        env = VecVSSEnv(B, device=dev, seed=0)
+        env.reset()
+        act = torch.zeros(B, 2, device=f"cuda:{dev}").uniform_(-1, 1)
+        for _ in range(200):
+            env.step(act)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            env.step(act)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        env.close()
+        out.update({"vec_api_calls_per_s": n / dt, "vec_api_env_steps_per_s": B * n / dt, "vec_api_envs": B,
+                    "vec_api_note": "VecVSSEnv.step(actions) with a device-resident [B, 2] action tensor, host-asynchronous"})
+    except Exception as ex:
+        out["vec_api_error"] = repr(ex)
+    try:
+        import rsoccer_amd
+        env = rsoccer_amd.make("VSS-v0")
+        env.reset()
+        a = env.action_space.sample()
+        for _ in range(50):
+            env.step(a)
+        m = 500
+        t0 = time.perf_counter()
+        for _ in range(m):
+            _, _, term, trunc, _ = env.step(a)
+            if term or trunc:
+                env.reset()
+        dt = time.perf_counter() - t0
+        env.close()
+        out.update({"single_env_steps_per_s": m / dt,
+                    "single_env_note": "rsoccer_amd.make('VSS-v0'): the reference-shaped class, Python hooks + one host-format "
+                                       "rsx_step (PCIe both ways, synchronous) per step"})
+    except Exception as ex:
+        out["single_env_error"] = repr(ex)
+    return out
 
 
 if __name__ == "__main__":

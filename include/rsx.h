@@ -14,8 +14,12 @@
  *   - "dev" pointers are HIP device memory owned by the handle (valid until rsx_destroy); all
  *     device work is stream-ordered on the hipStream_t passed as `void* stream` (NULL = the
  *     null stream) and never synchronises implicitly, except the host-format calls
- *     (rsx_step / rsx_get_state / rsx_reset / rsx_set_state / rsx_read_metrics) which must
- *     return results to the host and therefore synchronise that stream.
+ *     (rsx_step / rsx_get_state / rsx_get_state_full / rsx_reset / rsx_set_state /
+ *     rsx_task_reset_to / rsx_read_metrics), which take or return host arrays and therefore
+ *     synchronise that stream; rsx_create and rsx_task_attach synchronise the device once
+ *     (their buffers are initialised before any caller stream can touch them).
+ *   - no call changes the calling thread's current HIP device: the handle's device is made
+ *     current for the duration of the call and the previous one is restored on return.
  *   - a handle is not thread-safe; distinct handles are independent.
  *   - there is NO CPU fallback: creation fails (RSX_ERR_NO_DEVICE) without a gfx950 device.
  *
@@ -93,8 +97,8 @@ typedef struct rsx_task_view {
     int32_t* steps;         /* [B] i32: steps taken in the current episode                   */
     float*   actions;       /* [B][act_dim] f32: staging buffer callers may fill and pass to
                                rsx_task_step (any device pointer of that shape works)        */
-    int64_t* metrics;       /* [RSX_METRICS] i64 device counters (entry 0 is host-counted:
-                               read it through rsx_read_metrics)                             */
+    int64_t* metrics;       /* [RSX_METRICS] i64 device counters, all eight maintained by the
+                               step kernels (stream-ordered)                                 */
 } rsx_task_view;
 
 /* ---- diagnostics ---------------------------------------------------------------------- */
@@ -157,7 +161,10 @@ int rsx_task_reset(rsx_sim* h, void* stream);
 int rsx_task_reset_to(rsx_sim* h, const double* ball, const double* blue, const double* yellow,
                       const uint8_t* env_mask, void* stream);
 
-/* step(action): actions_dev [B][act_dim] f32 device memory, or NULL = uniform random actions
+/* The three stepping calls below return RSX_ERR_STATE until rsx_task_reset or
+ * rsx_task_reset_to has opened the first episode.
+ *
+ * step(action): actions_dev [B][act_dim] f32 device memory, or NULL = uniform random actions
  * drawn on device (the "random actions" benchmark configuration).  One kernel launch does
  * action -> commands (+ OU noise for the non-agent robots), physics, observation, reward,
  * done, TimeLimit and same-step auto-reset. */

@@ -57,7 +57,6 @@ struct rsx_sim {
     float *d_aux = nullptr, *d_obs = nullptr, *d_final_obs = nullptr, *d_actions = nullptr;
     uint8_t* d_flags = nullptr;
     unsigned long long* d_metrics = nullptr;
-    long long env_steps = 0;
     hipStream_t cap_stream = nullptr;
     std::map<int, hipGraphExec_t> graphs;
     std::vector<float> h_f32;
@@ -69,6 +68,7 @@ struct rsx_sim {
     float* pin_state = nullptr;
     bool host_state_valid = false;
     bool host_state_cache = true;
+    bool task_ready = false;   // a reset has opened the first episode
 };
 
 namespace {
@@ -204,21 +204,35 @@ void launch_task(const rsx_sim* h, const float* actions, int n_steps, int mode, 
     }
 }
 
-int check(const rsx_sim* h) {
-    if (!h) return fail(RSX_ERR_ARG, "null handle");
-    int cur = -1;   // the per-step calls come through here: switch devices only when needed
-    if (hipGetDevice(&cur) == hipSuccess && cur == h->device) return RSX_OK;
-    hipError_t e = hipSetDevice(h->device);
-    if (e != hipSuccess) return fail(RSX_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
-    return RSX_OK;
-}
+// Makes the handle's device current for the duration of one API call and puts the caller's device
+// back on exit: a C-ABI call must not change the thread's current HIP device (which is also
+// torch's current device) behind the caller's back.  The per-step calls pay one hipGetDevice.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    int enter(int device) {
+        if (hipGetDevice(&prev) == hipSuccess && prev == device) return RSX_OK;
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) return fail(RSX_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+        switched = prev >= 0;
+        return RSX_OK;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
 
-int check_task(rsx_sim* h) {
-    if (int rc = check(h)) return rc;
-    h->host_state_valid = false;   // every task call may change the state
-    if (h->P.task == RSX_TASK_NONE) return fail(RSX_ERR_STATE, "no task attached (rsx_task_attach)");
-    return RSX_OK;
-}
+#define RSX_ENTER(h)                                              \
+    if (!(h)) return fail(RSX_ERR_ARG, "null handle");            \
+    DeviceGuard _guard;                                           \
+    if (int _rc = _guard.enter((h)->device)) return _rc
+
+#define RSX_ENTER_TASK(h)                                                                        \
+    RSX_ENTER(h);                                                                                \
+    (h)->host_state_valid = false; /* every task call may change the state */                    \
+    if ((h)->P.task == RSX_TASK_NONE) return fail(RSX_ERR_STATE, "no task attached (rsx_task_attach)")
+
+// stepping before any reset would run on the dummy line-up with episode id 0xFFFFFFFF
+#define RSX_NEED_RESET(h) \
+    if (!(h)->task_ready) return fail(RSX_ERR_STATE, "rsx_task_reset / rsx_task_reset_to must come before the first step")
 
 // host f64 AoS [B][S'] <-> device f32 SoA [S'][B]
 int upload_state(rsx_sim* h, const std::vector<float>& soa, hipStream_t s) {
@@ -309,7 +323,8 @@ int rsx_create(rsx_sim** out, int kind, int field_type, int n_blue, int n_yellow
         return fail(RSX_ERR_HIP, m);
     };
     hipError_t e;
-    if ((e = hipSetDevice(device_id)) != hipSuccess) return bail(e, "hipSetDevice");
+    DeviceGuard guard;
+    if (guard.enter(device_id)) { free_all(h); delete h; return RSX_ERR_HIP; }
     const size_t B = (size_t)num_envs;
     const size_t sbytes = (size_t)(h->P.state_dim + 1) * B * sizeof(float);
     const size_t cbytes = (size_t)h->P.n_robots * h->M.cmd_dim * B * sizeof(float);
@@ -330,13 +345,17 @@ int rsx_create(rsx_sim** out, int kind, int field_type, int n_blue, int n_yellow
         }
     }
     if ((e = hipMemcpy(h->d_state, soa.data(), sbytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(state)");
+    // the memsets above ran on the null stream; callers step on their own (possibly non-blocking)
+    // streams, which do not order themselves behind it
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return bail(e, "hipDeviceSynchronize");
     *out = h;
     return RSX_OK;
 }
 
 int rsx_destroy(rsx_sim* h) {
     if (!h) return RSX_OK;
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard;
+    (void)guard.enter(h->device);
     free_all(h);
     delete h;
     return RSX_OK;
@@ -350,7 +369,7 @@ int rsx_get_field_params(const rsx_sim* h, double out[RSX_FIELD_PARAMS]) {
 
 int rsx_reset(rsx_sim* h, const double* ball, const double* blue, const double* yellow,
               const uint8_t* env_mask, void* stream) {
-    if (int rc = check(h)) return rc;
+    RSX_ENTER(h);
     if (!ball || (h->P.n_blue && !blue) || (h->P.n_yellow && !yellow)) return fail(RSX_ERR_ARG, "null placement array");
     hipStream_t s = (hipStream_t)stream;
     std::vector<float> soa;
@@ -361,7 +380,7 @@ int rsx_reset(rsx_sim* h, const double* ball, const double* blue, const double* 
 }
 
 int rsx_step(rsx_sim* h, const double* cmds, void* stream) {
-    if (int rc = check(h)) return rc;
+    RSX_ENTER(h);
     if (!cmds) return fail(RSX_ERR_ARG, "cmds is null");
     hipStream_t s = (hipStream_t)stream;
     const Params& P = h->P;
@@ -393,19 +412,19 @@ static int get_state_impl(rsx_sim* h, double* out, int rows, hipStream_t s) {
 }
 
 int rsx_get_state(rsx_sim* h, double* out, void* stream) {
-    if (int rc = check(h)) return rc;
+    RSX_ENTER(h);
     if (!out) return fail(RSX_ERR_ARG, "out is null");
     return get_state_impl(h, out, h->P.state_dim, (hipStream_t)stream);
 }
 
 int rsx_get_state_full(rsx_sim* h, double* out, void* stream) {
-    if (int rc = check(h)) return rc;
+    RSX_ENTER(h);
     if (!out) return fail(RSX_ERR_ARG, "out is null");
     return get_state_impl(h, out, h->P.state_dim + 1, (hipStream_t)stream);
 }
 
 int rsx_set_state(rsx_sim* h, const double* state, void* stream) {
-    if (int rc = check(h)) return rc;
+    RSX_ENTER(h);
     if (!state) return fail(RSX_ERR_ARG, "state is null");
     const size_t B = (size_t)h->P.num_envs;
     const int rows = h->P.state_dim + 1;
@@ -425,7 +444,7 @@ int rsx_dev_view_get(rsx_sim* h, rsx_dev_view* out) {
 }
 
 int rsx_step_dev(rsx_sim* h, void* stream) {
-    if (int rc = check(h)) return rc;
+    RSX_ENTER(h);
     h->host_state_valid = false;
     launch_sim(h, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
@@ -433,7 +452,7 @@ int rsx_step_dev(rsx_sim* h, void* stream) {
 }
 
 int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, int max_episode_steps) {
-    if (int rc = check(h)) return rc;
+    RSX_ENTER(h);
     if (h->P.task != RSX_TASK_NONE) return fail(RSX_ERR_STATE, "a task is already attached");
     Params P = h->P;
     if (derive_task(task, seed, env_id_base, max_episode_steps, h->M, P))
@@ -460,7 +479,6 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
     // episode ids start at 0xFFFFFFFF so that the first reset() opens episode 0
     HIP_TRY(hipMemset(h->d_aux + (size_t)ROW_EPISODE * B, 0xFF, B * sizeof(uint32_t)));
     h->P = P;
-    h->env_steps = 0;
     // VSS-v0 3v3: which tile layout steps the envs.  Both give identical results; the one-lane-
     // per-env kernel needs enough envs to fill the chip with its long waves.
     h->epl = false;
@@ -470,6 +488,8 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
         else if (lay && std::strcmp(lay, "lanes") == 0) h->epl = false;
         else h->epl = P.num_envs >= RSX_EPL_MIN_ENVS;
     }
+    h->task_ready = false;
+    HIP_TRY(hipDeviceSynchronize());   // null-stream memsets done before any caller stream steps
     return RSX_OK;
 }
 
@@ -488,15 +508,16 @@ int rsx_task_view_get(rsx_sim* h, rsx_task_view* out) {
 }
 
 int rsx_task_reset(rsx_sim* h, void* stream) {
-    if (int rc = check_task(h)) return rc;
+    RSX_ENTER_TASK(h);
     launch_task(h, nullptr, 1, MODE_RESET, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
+    h->task_ready = true;
     return RSX_OK;
 }
 
 int rsx_task_reset_to(rsx_sim* h, const double* ball, const double* blue, const double* yellow,
                       const uint8_t* env_mask, void* stream) {
-    if (int rc = check_task(h)) return rc;
+    RSX_ENTER_TASK(h);
     if (int rc = rsx_reset(h, ball, blue, yellow, env_mask, stream)) return rc;
     hipStream_t s = (hipStream_t)stream;
     const size_t B = (size_t)h->P.num_envs;
@@ -506,26 +527,27 @@ int rsx_task_reset_to(rsx_sim* h, const double* ball, const double* blue, const 
     launch_task(h, nullptr, 1, MODE_REFRESH, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(h->d_flags + B, 0, B, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipStreamSynchronize(s));   // the host mask / placement arrays may be reused by the caller
+    h->task_ready = true;
     return RSX_OK;
 }
 
 int rsx_task_step(rsx_sim* h, const float* actions_dev, void* stream) {
-    if (int rc = check_task(h)) return rc;
+    RSX_ENTER_TASK(h);
+    RSX_NEED_RESET(h);
     launch_task(h, actions_dev, 1, MODE_STEP, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
-    h->env_steps += h->P.num_envs;
     return RSX_OK;
 }
 
 int rsx_task_step_n(rsx_sim* h, int n, void* stream) {
-    if (int rc = check_task(h)) return rc;
+    RSX_ENTER_TASK(h);
+    RSX_NEED_RESET(h);
     if (n < 1) return fail(RSX_ERR_ARG, "n must be >= 1");
     static const bool use_graph = std::getenv("RSX_USE_GRAPH") != nullptr;
     if (!use_graph) {
         for (int i = 0; i < n; ++i) launch_task(h, nullptr, 1, MODE_STEP, (hipStream_t)stream);
         HIP_TRY(hipGetLastError());
-        h->env_steps += (long long)n * h->P.num_envs;
         return RSX_OK;
     }
     auto it = h->graphs.find(n);
@@ -540,26 +562,24 @@ int rsx_task_step_n(rsx_sim* h, int n, void* stream) {
         it = h->graphs.emplace(n, exec).first;
     }
     HIP_TRY(hipGraphLaunch(it->second, (hipStream_t)stream));
-    h->env_steps += (long long)n * h->P.num_envs;
     return RSX_OK;
 }
 
 int rsx_task_rollout(rsx_sim* h, int n, void* stream) {
-    if (int rc = check_task(h)) return rc;
+    RSX_ENTER_TASK(h);
+    RSX_NEED_RESET(h);
     if (n < 0) return fail(RSX_ERR_ARG, "n must be >= 0");  // 0 = load + store only (profiling)
     launch_task(h, nullptr, n, MODE_ROLLOUT, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
-    h->env_steps += (long long)n * h->P.num_envs;
     return RSX_OK;
 }
 
 int rsx_read_metrics(rsx_sim* h, int64_t out[RSX_METRICS], void* stream) {
-    if (int rc = check_task(h)) return rc;
+    RSX_ENTER_TASK(h);
     if (!out) return fail(RSX_ERR_ARG, "out is null");
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipMemcpyAsync(out, h->d_metrics, RSX_METRICS * sizeof(int64_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    out[0] = h->env_steps;
     return RSX_OK;
 }
 

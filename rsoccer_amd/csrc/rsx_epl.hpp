@@ -88,6 +88,9 @@ __global__ __launch_bounds__(64) void vss_epl_kernel(RSX_HOT_ARGS, const Params 
         for (int i = 0; i < ID; ++i) info[i] = auxe[(size_t)(ROW_INFO + i) * B];
         prev_pot = auxe[(size_t)ROW_PREV_POT * B]; ep_ret = auxe[(size_t)ROW_EP_RET * B];
     }
+    const bool counts_steps = blockIdx.x == 0 && lane == 0;   // metrics[0]: see task_step_kernel
+    unsigned long long steps_before = 0;
+    if (counts_steps) steps_before = bufs.metrics[0];
     const bool fed = MODE == MODE_STEP && bufs.actions != nullptr;
     float act0 = 0.0f, act1 = 0.0f;
     if (fed && live) { act0 = bufs.actions[(size_t)e * 2]; act1 = bufs.actions[(size_t)e * 2 + 1]; }
@@ -397,6 +400,7 @@ __global__ __launch_bounds__(64) void vss_epl_kernel(RSX_HOT_ARGS, const Params 
         auxe[(size_t)ROW_EPISODE * B] = __uint_as_float(episode);
         auxe[(size_t)ROW_PREV_POT * B] = prev_pot; auxe[(size_t)ROW_EP_RET * B] = ep_ret;
     }
+    if (counts_steps) bufs.metrics[0] = steps_before + (unsigned long long)P.num_envs * (unsigned long long)n_steps;
 }
 
 }  // namespace rsx

@@ -981,6 +981,11 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
         for (int i = 0; i < ID; ++i) info[i] = auxe[(size_t)(ROW_INFO + i) * B];
         prev_pot = auxe[(size_t)ROW_PREV_POT * B]; ep_ret = auxe[(size_t)ROW_EP_RET * B];
     }
+    // metrics[0] (env-steps) is counted on the device by ONE lane of the grid: launches of a handle
+    // are stream-ordered, so a plain read-modify-write is race free and costs no atomic
+    const bool counts_steps = (MODE == MODE_STEP || MODE == MODE_ROLLOUT) && blockIdx.x == 0 && lane == 0;
+    unsigned long long steps_before = 0;
+    if (counts_steps) steps_before = bufs.metrics[0];
     float reward = 0.0f; int term = 0, trunc = 0;
     bool success = false;  // goal scored / course completed / pass received (metrics[2])
     bool was_reset = false;
@@ -1351,6 +1356,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
         auxe[(size_t)(ROW_OU + 2 * b) * B] = ou0; auxe[(size_t)(ROW_OU + 2 * b + 1) * B] = ou1;
     }
     if (is_ball) { auxe[(size_t)ROW_PREV_POT * B] = prev_pot; auxe[(size_t)ROW_EP_RET * B] = ep_ret; }
+    if (counts_steps) bufs.metrics[0] = steps_before + (unsigned long long)P.num_envs * (unsigned long long)n_steps;
     RSX_STAMP(6);
 #ifdef RSX_TIMING
     __builtin_amdgcn_s_waitcnt(0x0F70);

@@ -126,11 +126,11 @@ if HAVE_GYMNASIUM:  # pragma: no cover
     register = _gym.register
     make = _gym.make
     TimeLimit = _gym.wrappers.TimeLimit
+    registry = _gym.registry   # the ids live in gymnasium's own registry
 else:
     Env = _Env
     spaces = _Spaces
     register = _register
     make = _make
     TimeLimit = _TimeLimit
-
-registry = _REGISTRY
+    registry = _REGISTRY

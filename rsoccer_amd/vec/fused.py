@@ -88,15 +88,17 @@ class VecFusedEnv:
         torch = self._torch
         ptr = None
         if actions is not None:
+            want = (self.num_envs, self.sim.act_dim)
+            if tuple(np.shape(actions)) != want:   # checked on the INPUT: copy_ below would broadcast
+                raise ValueError(f"actions must be [{want[0]}, {want[1]}], got {tuple(np.shape(actions))}")
             if isinstance(actions, torch.Tensor):
                 a = actions
                 if a.device != self.device or a.dtype != torch.float32 or not a.is_contiguous():
                     a = a.to(device=self.device, dtype=torch.float32).contiguous()
             else:
                 a = self._t["actions"]
-                a.copy_(torch.from_numpy(np.ascontiguousarray(actions, dtype=np.float32)), non_blocking=True)
-            if tuple(a.shape) != (self.num_envs, self.sim.act_dim):
-                raise ValueError(f"actions must be [{self.num_envs}, {self.sim.act_dim}], got {tuple(a.shape)}")
+                # pageable host memory: a blocking copy (non_blocking would read a temporary)
+                a.copy_(torch.from_numpy(np.ascontiguousarray(actions, dtype=np.float32)))
             self._keep = a  # keep the tensor alive until the launch has consumed it
             ptr = a.data_ptr()
         self.sim.task_step(ptr, self._stream())

@@ -19,7 +19,8 @@ from rsoccer_amd.Simulators.rsim import RSimVSS
 
 
 class VSSBaseEnv(gym.Env):
-    metadata = {"render.modes": ["human", "rgb_array"], "render_modes": ["human", "rgb_array"],
+    # "human" (the reference's pygame window, Render/) is outside the step engine's scope
+    metadata = {"render.modes": ["rgb_array"], "render_modes": ["rgb_array"],
                 "render_fps": 60, "render.fps": 60}
     NORM_BOUNDS = 1.2
     _SIM_ADAPTER = RSimVSS
@@ -29,6 +30,9 @@ class VSSBaseEnv(gym.Env):
     def __init__(self, field_type: int, n_robots_blue: int, n_robots_yellow: int, time_step: float,
                  render_mode=None, sim_backend=None):
         super().__init__()
+        if render_mode not in (None, "rgb_array"):
+            raise ValueError(f"render_mode={render_mode!r} is not supported (None or 'rgb_array'); the pygame "
+                             "window of the reference is outside the scope of the step engine")
         self.render_mode = render_mode
         self.time_step = time_step
         self.rsim = self._SIM_ADAPTER(field_type=field_type, n_robots_blue=n_robots_blue,
@@ -57,8 +61,6 @@ class VSSBaseEnv(gym.Env):
         self.last_frame, self.frame = self.frame, self.rsim.get_frame()
         observation = self._frame_to_observations()
         reward, done = self._calculate_reward_and_done()
-        if self.render_mode == "human":
-            self.render()
         return observation, reward, done, False, {}
 
     def reset(self, *, seed=None, options=None):
@@ -69,18 +71,13 @@ class VSSBaseEnv(gym.Env):
         self.rsim.reset(self._get_initial_positions_frame())
         self.frame = self.rsim.get_frame()
         obs = self._frame_to_observations()
-        if self.render_mode == "human":
-            self.render()
         return obs, {}
 
     def render(self):
         """``rgb_array``: the current frame as uint8 [H, W, 3] in the reference's window geometry
-        (numpy rasteriser, rsoccer_amd/Render/raster.py).  ``human`` needs pygame and a display,
-        which are outside the scope of the step engine."""
+        (numpy rasteriser, rsoccer_amd/Render/raster.py)."""
         if self.render_mode != "rgb_array":
-            raise NotImplementedError(
-                "render_mode='human' (pygame window) is outside the scope of the step engine; "
-                "use render_mode='rgb_array' or None")
+            raise NotImplementedError("render() needs render_mode='rgb_array'")
         if getattr(self, "_raster", None) is None:
             from rsoccer_amd import Render
             self._raster = Render.FieldRaster(getattr(Render, self._RENDER_VIEW))

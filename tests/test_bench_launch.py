@@ -1,0 +1,104 @@
+"""bench.py as the driver runs it: `python bench.py --gpus N` must start its own ranks.
+
+CPU: the launcher + the gloo plumbing (`--dry-run`, no GPU).  GPU: the real line at one rank, the
+RCCL path with one rank, and the multi-rank code path with two ranks — on RCCL when the box has
+two devices, otherwise on one shared device with the metrics all-reduced over gloo (test mode);
+in every case the all-reduced metrics must equal those of ONE handle holding the whole population
+(envs are keyed by global env id: one simulator per env, rsoccer_gym/vss/vss_gym_base.py:40-45).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env=None, timeout=900):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)   # the test itself may run under a launcher
+    e.update(env or {})
+    res = subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=timeout, env=e, cwd=ROOT)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    return res, (json.loads(lines[-1]) if lines else None)
+
+
+def test_gpus_n_self_launches_its_ranks_dry_run():
+    """plain `python bench.py --gpus 2` (no torchrun around it): two ranks come up, shard the env ids,
+    all-reduce, and rank 0 prints exactly one JSON line."""
+    res, line = _run(["--gpus", "2", "--steps", "7", "--warmup", "1", "--envs", "33", "--dry-run"])
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert sum(ln.startswith("{") for ln in res.stdout.splitlines()) == 1
+    assert line["n_gpus"] == 2 and line["dry_run"] is True
+    assert line["env_steps_counted"] == 2 * 33 * 7          # both shards were counted
+    assert line["env_id_bases_sum"] == 0 + 33               # rank r owns [r*B, (r+1)*B)
+
+
+def test_gpus_must_match_the_world_size():
+    res, _ = _run(["--gpus", "3", "--dry-run"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert res.returncode != 0 and "WORLD_SIZE" in (res.stdout + res.stderr)
+
+
+def _single_handle_metrics(total_envs, steps, warmup):
+    import torch
+    from rsoccer_amd import _lib as L
+    sim = L.Sim(L.KIND_VSS, 0, 3, 3, 25, total_envs, 0)
+    sim.task_attach(L.TASK_VSS_V0, seed=0, env_id_base=0, max_episode_steps=0)
+    sim.task_reset()
+    sim.task_step_n(warmup + steps)
+    torch.cuda.synchronize()
+    m = sim.read_metrics()
+    sim.close()
+    return m
+
+
+@pytest.mark.gpu
+def test_bench_line_single_gpu_has_every_leg():
+    res, line = _run(["--steps", "20", "--warmup", "5", "--no-cpu-baseline"])
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert line["n_gpus"] == 1 and line["steps"] == 20 and line["warmup"] == 5
+    assert line["env_steps_counted"] >= 4096 * 25          # counted on the device
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and r["achieved"] <= r["peak"]
+    assert line["steady"]["steps"] >= 2000 and line["steady"]["after_steps"] >= 200
+    envs = [p["envs"] for p in line["sweep"]]
+    assert envs == [65536, 1048576, 4194304]
+    for p in line["sweep"]:
+        assert "error" not in p, p
+        if "skipped" not in p:
+            assert 0 < p["step"]["roofline_frac"] < 1 and 0 < p["rollout"]["roofline_frac"] < 1
+    assert line["python_layer"]["vec_api_calls_per_s"] > 1000
+    assert line["python_layer"]["single_env_steps_per_s"] > 100
+
+
+@pytest.mark.gpu
+def test_bench_rccl_path_with_one_rank():
+    res, line = _run(["--steps", "150", "--warmup", "50", "--no-cpu-baseline", "--no-extra", "--no-rollout"],
+                     env={"RSX_BENCH_FORCE_DIST": "1"})
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert line["collective"]["backend"] == "rccl" and line["collective"]["ranks"] == 1
+    m = _single_handle_metrics(4096, 150, 50)
+    assert line["env_steps_counted"] == int(m[0]) == 4096 * 200 and line["episodes"] == int(m[1])
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_equal_one_handle():
+    """`python bench.py --gpus 2`: the code path of world > 1 (env_id_base per rank, in-loop all-reduce,
+    max over ranks).  Two devices -> RCCL; one device -> both ranks share it (gloo for the 64 bytes)."""
+    import torch
+    env = {} if torch.cuda.device_count() >= 2 else {"RSX_BENCH_SHARE_DEVICE": "1"}
+    B, K, W = 1024, 120, 30
+    res, line = _run(["--gpus", "2", "--envs", str(B), "--steps", str(K), "--warmup", str(W),
+                      "--no-cpu-baseline", "--no-extra", "--no-rollout"], env=env)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert line["n_gpus"] == 2 and line["collective"]["ranks"] == 2
+    assert len(line["collective"]["per_rank_ms_per_step"]) == 2
+    assert abs(line["value"] - 2 * B * K / (line["ms_per_step"] * 1e-3 * K)) < 1e-6 * line["value"]
+    m = _single_handle_metrics(2 * B, K, W)
+    assert line["env_steps_counted"] == int(m[0]) == 2 * B * (K + W)
+    assert line["episodes"] == int(m[1])

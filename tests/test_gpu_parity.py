@@ -540,8 +540,13 @@ def test_api_errors_are_reported_not_crashed():
     sim.task_attach(1, 0, 0, 0)
     with pytest.raises(L.RsxError, match="already attached"):
         sim.task_attach(1, 0, 0, 0)
+    for call in (lambda: sim.task_step(None), lambda: sim.task_step_n(3), lambda: sim.task_rollout(3)):
+        with pytest.raises(L.RsxError, match="must come before the first step"):
+            call()                            # no episode is open yet
+    sim.task_reset()
     with pytest.raises(L.RsxError):
         sim.task_rollout(-1)
+    sim.task_step(None)
     sim.close()
     for bad in ((2, 0, 3, 3), (0, 7, 3, 3), (0, 0, 0, 0), (0, 0, 20, 20)):
         with pytest.raises(L.RsxError, match="bad simulator configuration"):
@@ -552,6 +557,46 @@ def test_api_errors_are_reported_not_crashed():
     with pytest.raises(L.RsxError, match="does not match"):
         ssl.task_attach(3, 0, 0, 0)           # dribbling needs 1v4
     ssl.close()
+
+
+def test_api_calls_leave_the_current_device_alone():
+    """No C-ABI call may change the thread's current HIP device (= torch's current device), also not
+    the destructor run by the garbage collector.  With a single device this pins the common case;
+    with two, a handle on the other device is created, stepped and destroyed while device 0 is current."""
+    import gc
+    import torch
+    L = _lib()
+    ndev = torch.cuda.device_count()
+    torch.cuda.set_device(0)
+    other = 1 if ndev >= 2 else 0
+    sim = L.Sim(0, 0, 3, 3, 25, 64, device_id=other)
+    assert torch.cuda.current_device() == 0
+    sim.task_attach(1, 3, 0, 0)
+    sim.task_reset()
+    sim.task_step_n(5)
+    st = sim.get_state()
+    m = sim.read_metrics()
+    assert torch.cuda.current_device() == 0 and m[0] == 5 * 64 and np.all(np.isfinite(st))
+    x = torch.zeros(4, device="cuda")          # lands on torch's current device, not the handle's
+    assert x.device.index == 0
+    del sim
+    gc.collect()
+    assert torch.cuda.current_device() == 0
+
+
+def test_metrics_env_steps_are_counted_on_the_device():
+    """metrics[0] is part of the device vector (what the multi-GPU all-reduce sends), for single-step
+    launches, C-side step loops and one-launch rollouts alike."""
+    L = _lib()
+    sim = L.Sim(0, 0, 3, 3, 25, 100)
+    sim.task_attach(1, 1, 0, 0)
+    sim.task_reset()
+    sim.task_step(None); sim.task_step_n(4); sim.task_rollout(7)
+    import torch
+    torch.cuda.synchronize()
+    dev = sim.task_tensors()["metrics"].cpu().numpy()
+    assert dev[0] == 100 * 12 and np.array_equal(dev, sim.read_metrics())
+    sim.close()
 
 
 @pytest.mark.parametrize("ts_ms", [0, 3, 12, 50])

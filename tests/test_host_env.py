@@ -344,3 +344,7 @@ def test_rgb_array_render_has_the_reference_window_geometry(oracle_mod):
     with pytest.raises(NotImplementedError):
         env.render()
     env.close()
+    # 'human' is refused at construction (not at the first reset) and is not advertised
+    with pytest.raises(ValueError):
+        VSSEnv(render_mode="human", sim_backend=fake_robosim)
+    assert VSSEnv.metadata["render_modes"] == ["rgb_array"]
