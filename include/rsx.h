@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define RSX_ABI_VERSION 1
+#define RSX_ABI_VERSION 2
 
 /* kind: which robosim class the handle stands for (rsim.py:116 robosim.VSS, :169 robosim.SSL) */
 #define RSX_KIND_VSS 0
@@ -60,6 +60,9 @@ extern "C" {
 
 /* number of entries of get_field_params(), in the order of Entities/Field.py:5-21 */
 #define RSX_FIELD_PARAMS 17
+/* internal state rows that follow the get_state() rows: ball vertical velocity (m/s), ball spin
+ * about the vertical axis (rad/s) */
+#define RSX_STATE_EXTRA_ROWS 2
 /* metrics vector length (int64 each; see rsx_read_metrics) */
 #define RSX_METRICS 8
 
@@ -67,14 +70,15 @@ typedef struct rsx_sim rsx_sim; /* opaque */
 
 /* Device-side views, zero-copy.  SoA: row f of an [F][B] array is the contiguous run
  * base + f*num_envs (one float per env).  state rows 0..state_dim-1 are exactly the reference's
- * get_state() layout (Entities/Frame.py:20-47 VSS, :55-92 SSL) transposed; row state_dim holds
- * the ball's vertical velocity (internal, needed to checkpoint a chipped ball). */
+ * get_state() layout (Entities/Frame.py:20-47 VSS, :55-92 SSL) transposed; rows state_dim and
+ * state_dim + 1 hold the ball's vertical velocity and its spin (internal, needed to checkpoint
+ * a chipped / spinning ball). */
 typedef struct rsx_dev_view {
     int32_t num_envs;    /* B                                                                */
     int32_t n_robots;    /* N = n_blue + n_yellow                                            */
     int32_t state_dim;   /* 5 + 6N (VSS) | 5 + 11N (SSL)                                     */
     int32_t cmd_dim;     /* C: 2 (VSS) | 8 (SSL)  — per robot                                */
-    float*  state;       /* [state_dim + 1][B] f32 SoA                                       */
+    float*  state;       /* [state_dim + 2][B] f32 SoA                                       */
     float*  cmds;        /* [N*C][B] f32 SoA, row = robot*C + col; read by rsx_step_dev      */
 } rsx_dev_view;
 
@@ -134,8 +138,9 @@ int rsx_step(rsx_sim* h, const double* cmds, void* stream);
 /* get_state() — rsim.py:105,158; out [B][state_dim] host f64 */
 int rsx_get_state(rsx_sim* h, double* out, void* stream);
 
-/* full-state restore (checkpoint/resume, also used by parity tests): state [B][state_dim+1]
- * host f64 = get_state() layout + ball vertical velocity. rsx_get_state_full is its inverse. */
+/* full-state restore (checkpoint/resume, also used by parity tests): state
+ * [B][state_dim + RSX_STATE_EXTRA_ROWS] host f64 = get_state() layout + ball vertical velocity
+ * + ball spin. rsx_get_state_full is its inverse. */
 int rsx_set_state(rsx_sim* h, const double* state, void* stream);
 int rsx_get_state_full(rsx_sim* h, double* out, void* stream);
 

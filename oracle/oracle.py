@@ -36,6 +36,7 @@ def lib():
 
 
 _dp = C.POINTER(C.c_double)
+X_ROWS = 2   # internal state entries behind get_state(): ball vertical velocity, ball spin (RSXO_XROWS)
 
 
 def _d(a):
@@ -97,12 +98,12 @@ class OracleEnv:
         return out
 
     def get_state_full(self):
-        out = np.zeros(self.state_dim + 1)
+        out = np.zeros(self.state_dim + X_ROWS)
         self._f("rsxo_get_state_full")(self.h, _d(out))
         return out
 
     def set_state_full(self, s):
-        s = np.ascontiguousarray(s, dtype=np.float64).reshape(self.state_dim + 1)
+        s = np.ascontiguousarray(s, dtype=np.float64).reshape(self.state_dim + X_ROWS)
         self._f("rsxo_set_state_full")(self.h, _d(s))
 
     # ---- tasks ----

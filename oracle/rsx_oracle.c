@@ -52,11 +52,13 @@ typedef struct rsxo_cfg {
     double w_max, r_wheel, lever;
     double grav, e_ground, vz_min, robot_h;
     double dck, half_kw, ir_tol, drib_vmax;
+    double mu_rr, mu_rb, mu_wb, spin_dec;   /* Coulomb friction in contacts, spin deceleration (rad/s^2) */
     double wheel_ang[4];
     double pinv[3][4];
 } rsxo_cfg;
 
 #define RSXO_PI 3.14159265358979323846
+#define RSXO_XROWS 2 /* internal state entries behind get_state(): ball vz, ball spin */
 
 static int rsxo_cfg_init(rsxo_cfg* c, int kind, int field_type, int nb, int ny, int ts_ms) {
     memset(c, 0, sizeof(*c));
@@ -112,6 +114,7 @@ static int rsxo_cfg_init(rsxo_cfg* c, int kind, int field_type, int nb, int ny, 
     c->w_max = f[16] / 60.0 * 2.0 * RSXO_PI;
     c->grav = 9.81; c->e_ground = 0.5; c->vz_min = 0.2; c->robot_h = 0.15;
     c->dck = f[7]; c->half_kw = f[9] / 2; c->ir_tol = 0.025; c->drib_vmax = 1.0;
+    c->mu_rr = 0.2; c->mu_rb = 0.35; c->mu_wb = 0.3; c->spin_dec = 30.0;   /* build */
     for (int k = 0; k < 4; ++k) c->wheel_ang[k] = f[10 + k] * RSXO_PI / 180.0;
     if (kind == 1) {
         /* omni inverse kinematics: wheel surface speed_k = -sin(a_k) vx + cos(a_k) vy + R w.

@@ -7,7 +7,8 @@
  * State vector (wire format of robosim.get_state(), Entities/Frame.py:20-47 / :55-92):
  *   [0..4]  ball x, y, z, vx, vy         robot k at 5 + RS*k: x, y, theta(deg), vx, vy,
  *   omega(deg/s) [, infrared, v_wheel0..3 (rad/s)]   RS = 6 (VSS) | 11 (SSL)
- *   [state_dim] ball vertical velocity (internal).
+ *   [state_dim] ball vertical velocity, [state_dim + 1] ball spin about the vertical axis in
+ *   rad/s (both internal: not part of get_state(), carried by get/set_state_full).
  */
 
 #define RC(x) ((R)(x))
@@ -24,9 +25,11 @@ typedef struct SUF(rsxo_env) {
     R w_max, half_rw, rw_2b, inv_rw, r_wheel;
     R a_lin_h, a_lin_h2, a_lat_h, a_ang_h, mu_g_dt, g_h, e_ground, vz_min, robot_h;
     R dck_rb, half_kw, ir_tol, drib_gain, drib_vmax, drib_vmax2;
+    /* tangential friction / ball spin */
+    R dck, mu_rr, mu_rb, mu_wb, kt_rr, kt_rb_r, kt_rb_b, kw, spin_c, ope_wb, spin_dec_dt;
     R ws[4], wc[4], pinv[3][4];
     R deg2rad, rad2deg, h_deg;
-    R state[5 + 11 * MAXROB + 1];
+    R state[5 + 11 * MAXROB + RSXO_XROWS];
     /* ---- task ---- */
     int task, obs_dim, act_dim, info_dim, max_steps;
     uint32_t key[2], env_id, episode;
@@ -77,6 +80,19 @@ void* SUF(rsxo_create)(int kind, int field_type, int nb, int ny, int ts_ms) {
     e->dck_rb = RC(c->dck + c->r_ball); e->half_kw = RC(c->half_kw); e->ir_tol = RC(c->ir_tol);
     e->drib_gain = RC(c->h > 0 ? 0.5 / c->h : 0.0);
     e->drib_vmax = RC(c->drib_vmax); e->drib_vmax2 = RC(c->drib_vmax * c->drib_vmax);
+    /* Coulomb friction in contacts.  Tangential effective mass: robots are yaw-controlled by
+     * their motors (no torque from contacts), the ball is a solid sphere (I = 2/5 m r^2, so the
+     * contact point adds r^2 / I = 2.5 / m):  1/m_t = 1/m_r + 3.5/m_b (robot-ball), 2/m_r
+     * (robot-robot), 3.5/m_b (wall-ball). */
+    {
+        double mt_rb = 1.0 / (imr + 3.5 * imb);
+        e->dck = RC(c->dck);
+        e->mu_rr = RC(c->mu_rr); e->mu_rb = RC(c->mu_rb); e->mu_wb = RC(c->mu_wb);
+        e->kt_rr = RC(0.5); e->kt_rb_r = RC(mt_rb * imr); e->kt_rb_b = RC(mt_rb * imb);
+        e->kw = RC(2.0 / 7.0); e->spin_c = RC(2.5 / c->r_ball);
+        e->ope_wb = RC(1.0 + c->e_wall_ball);
+        e->spin_dec_dt = RC(c->spin_dec * (c->time_step_ms * 0.001));
+    }
     for (int k = 0; k < 4; ++k) { e->ws[k] = RC(sin(c->wheel_ang[k])); e->wc[k] = RC(cos(c->wheel_ang[k])); }
     for (int i = 0; i < 3; ++i) for (int k = 0; k < 4; ++k) e->pinv[i][k] = RC(c->pinv[i][k]);
     e->deg2rad = RC(RSXO_PI / 180.0); e->rad2deg = RC(180.0 / RSXO_PI);
@@ -115,52 +131,75 @@ void SUF(rsxo_get_state)(void* p, double* out) {
 }
 void SUF(rsxo_get_state_full)(void* p, double* out) {
     SUF(rsxo_env)* e = (SUF(rsxo_env)*)p;
-    for (int i = 0; i <= e->state_dim; ++i) out[i] = (double)e->state[i];
+    for (int i = 0; i < e->state_dim + RSXO_XROWS; ++i) out[i] = (double)e->state[i];
 }
 void SUF(rsxo_set_state_full)(void* p, const double* in) {
     SUF(rsxo_env)* e = (SUF(rsxo_env)*)p;
-    for (int i = 0; i <= e->state_dim; ++i) e->state[i] = RC(in[i]);
+    for (int i = 0; i < e->state_dim + RSXO_XROWS; ++i) e->state[i] = RC(in[i]);
 }
 
 /* ------------------------------------------------------------------------------------------
  * walls: clamp a circle of radius r into the playable region; e = restitution
  * ---------------------------------------------------------------------------------------- */
-static void SUF(walls)(const SUF(rsxo_env)* e, R r, R rest, R* px, R* py, R* pvx, R* pvy) {
+static int SUF(walls)(const SUF(rsxo_env)* e, R r, R rest, R* px, R* py, R* pvx, R* pvy) {
     R x = *px, y = *py, vx = *pvx, vy = *pvy;
     R ax = R_FABS(x), ay = R_FABS(y);
     R sx = x < RC(0) ? RC(-1) : RC(1), sy = y < RC(0) ? RC(-1) : RC(1);
+    int hit = 0; /* bit 0: vx was reflected, bit 1: vy was reflected */
     if (e->cfg.kind == 0) {
         if (ax > e->half_len) { /* centre inside a goal box */
             R yl = e->ghw - r;
-            if (ay > yl) { y = sy * yl; if (vy * sy > RC(0)) vy = -rest * vy; }
+            if (ay > yl) { y = sy * yl; if (vy * sy > RC(0)) { vy = -rest * vy; hit |= 2; } }
             R xl = (e->half_len + e->gd) - r;
-            if (ax > xl) { x = sx * xl; if (vx * sx > RC(0)) vx = -rest * vx; }
+            if (ax > xl) { x = sx * xl; if (vx * sx > RC(0)) { vx = -rest * vx; hit |= 1; } }
         } else {
             R yl = e->half_wid - r;
-            if (ay > yl) { y = sy * yl; if (vy * sy > RC(0)) vy = -rest * vy; }
+            if (ay > yl) { y = sy * yl; if (vy * sy > RC(0)) { vy = -rest * vy; hit |= 2; } }
             R xl = e->half_len - r;
-            if (ax > xl && ay > e->ghw - r) { x = sx * xl; if (vx * sx > RC(0)) vx = -rest * vx; }
+            if (ax > xl && ay > e->ghw - r) { x = sx * xl; if (vx * sx > RC(0)) { vx = -rest * vx; hit |= 1; } }
         }
     } else {
         R yl = (e->half_wid + e->margin) - r;
-        if (ay > yl) { y = sy * yl; if (vy * sy > RC(0)) vy = -rest * vy; ay = yl; }
+        if (ay > yl) { y = sy * yl; if (vy * sy > RC(0)) { vy = -rest * vy; hit |= 2; } ay = yl; }
         R xl = (e->half_len + e->margin) - r;
-        if (ax > xl) { x = sx * xl; if (vx * sx > RC(0)) vx = -rest * vx; ax = xl; }
+        if (ax > xl) { x = sx * xl; if (vx * sx > RC(0)) { vx = -rest * vx; hit |= 1; } ax = xl; }
         if (ax > e->half_len) {
             R back = e->half_len + e->gd;
             if (ay < e->ghw) {
                 if (ax < back) { /* inside the goal */
-                    if (ax > back - r) { x = sx * (back - r); if (vx * sx > RC(0)) vx = -rest * vx; }
-                    if (ay > e->ghw - r) { y = sy * (e->ghw - r); if (vy * sy > RC(0)) vy = -rest * vy; }
+                    if (ax > back - r) { x = sx * (back - r); if (vx * sx > RC(0)) { vx = -rest * vx; hit |= 1; } }
+                    if (ay > e->ghw - r) { y = sy * (e->ghw - r); if (vy * sy > RC(0)) { vy = -rest * vy; hit |= 2; } }
                 } else if (ax < back + r) { /* behind the back wall */
-                    x = sx * (back + r); if (vx * sx < RC(0)) vx = -rest * vx;
+                    x = sx * (back + r); if (vx * sx < RC(0)) { vx = -rest * vx; hit |= 1; }
                 }
             } else if (ay < e->ghw + r && ax < back) { /* outside, touching a side wall */
-                y = sy * (e->ghw + r); if (vy * sy < RC(0)) vy = -rest * vy;
+                y = sy * (e->ghw + r); if (vy * sy < RC(0)) { vy = -rest * vy; hit |= 2; }
             }
         }
     }
     *px = x; *py = y; *pvx = vx; *pvy = vy;
+    return hit;
+}
+
+/* A bounce of the BALL off a wall with Coulomb friction at the contact point: couples the
+ * velocity component along the wall with the spin about the vertical axis.  (vx0, vy0) is the
+ * velocity before walls(): the ball moved INTO the wall, so its sign names the wall's side.
+ * Wall along x (vy reflected) first, then wall along y. */
+static inline void SUF(ball_wall_spin)(const SUF(rsxo_env)* e, int hit, R vx0, R vy0, R* vx, R* vy, R* om) {
+    if (hit & 2) {
+        R sg = vy0 < RC(0) ? RC(-1) : RC(1);
+        R vc = *vx - (*om * e->r_ball) * sg;                 /* contact-point speed along the wall */
+        R lim = e->mu_wb * (e->ope_wb * R_FABS(vy0));
+        R d = SUF(clampr)(-(vc * e->kw), -lim, lim);
+        *vx = *vx + d; *om = *om - (sg * d) * e->spin_c;
+    }
+    if (hit & 1) {
+        R sg = vx0 < RC(0) ? RC(-1) : RC(1);
+        R vc = *vy + (*om * e->r_ball) * sg;
+        R lim = e->mu_wb * (e->ope_wb * R_FABS(vx0));
+        R d = SUF(clampr)(-(vc * e->kw), -lim, lim);
+        *vy = *vy + d; *om = *om + (sg * d) * e->spin_c;
+    }
 }
 
 /* heading after a small turn d (rad): rotate (c, s) by sin / cos of d (|d| < 0.5; odd / even
@@ -177,7 +216,7 @@ static inline void SUF(rotate_heading)(R d, R* c, R* s) {
 /* per-body working record */
 typedef struct SUF(body) {
     R x, y, vx, vy;        /* all */
-    R th, om, c, s;        /* robots: heading (DEGREES), rate (rad/s), cos/sin(heading) */
+    R th, om, c, s;        /* robots: heading (DEGREES), rate (rad/s), cos/sin(heading); ball: om = spin (rad/s) */
     R t0, t1, t2;          /* VSS: (v_target, om_target, -) | SSL: (vtx, vty, om_target) */
     R kick_x, kick_z; int drib, ir;
     R z, vz;               /* ball */
@@ -206,12 +245,128 @@ static inline int SUF(rb_geom)(const SUF(rsxo_env)* e, const SUF(body)* a, const
     return 0;
 }
 
+/* Response of body a to ONE touching partner p, from a's point of view (each side of a pair
+ * evaluates this with its own constants).  n = unit normal a -> p, pen = penetration depth,
+ * (dvx, dvy) = v_p - v_a, wsum = om_p * lever_p + om_a * lever_a (surface speeds at the contact
+ * point), w = a's share of the normal impulse, kt = a's share of the tangential one, mu = Coulomb
+ * coefficient, spin_c = spin gained per unit of tangential velocity change (ball only). */
+static inline void SUF(respond)(const SUF(rsxo_env)* e, R nx, R ny, R pen, R dvx, R dvy, R wsum,
+                                R ope, R w, R kt, R mu, R spin_c,
+                                R* avx, R* avy, R* apx, R* apy, R* aw) {
+    R vn = R_FMA(dvx, nx, dvy * ny);
+    if (vn < RC(0)) {
+        R q = ope * vn * w;                               /* <= 0: pushes a away from p */
+        *avx = R_FMA(q, nx, *avx); *avy = R_FMA(q, ny, *avy);
+        R vt = R_FMA(dvy, nx, -(dvx * ny)) - wsum;        /* along t = (-ny, nx) */
+        R lim = q * mu;
+        R ft = SUF(clampr)(vt * kt, lim, -lim);           /* sticking impulse, Coulomb-limited */
+        *avx = R_FMA(-ft, ny, *avx); *avy = R_FMA(ft, nx, *avy);
+        *aw = R_FMA(ft, spin_c, *aw);
+    }
+    R pc = e->beta * pen * w;
+    *apx = R_FMA(-pc, nx, *apx); *apy = R_FMA(-pc, ny, *apy);
+}
+
+typedef struct SUF(kick) { int ovr, okick; R ovx, ovy, ovz; } SUF(kick);
+
+/* One Jacobi sweep: every body sums the responses to its touching partners (index order) from
+ * the SAME snapshot, then all are applied.  Returns 1 when any pair touched.  first != 0:
+ * infrared sensors are refreshed and kicker / dribbler decisions recorded in K. */
+static int SUF(contacts)(SUF(rsxo_env)* e, SUF(body)* b, int first, SUF(kick)* K) {
+    const rsxo_cfg* c = &e->cfg;
+    const int N = c->n_robots, M = N + 1, ssl = c->kind == 1;
+    SUF(body)* ball = &b[N];
+    R dvx[MAXBOD], dvy[MAXBOD], dpx[MAXBOD], dpy[MAXBOD], dws = RC(0);
+    int any = 0;
+    for (int i = 0; i < M; ++i) {
+        R avx = RC(0), avy = RC(0), apx = RC(0), apy = RC(0), aw = RC(0);
+        for (int j = 0; j < M; ++j) {
+            if (j == i) continue;
+            if (i < N && j < N) { /* robot - robot */
+                R dx = b[j].x - b[i].x, dy = b[j].y - b[i].y;
+                R d2 = R_FMA(dx, dx, dy * dy);
+                if (d2 < e->rs_rr2 && d2 > RC(0)) {
+                    R d = R_SQRT(d2), inv = RC(1) / d;
+                    R wsum = R_FMA(b[j].om, e->r_robot, b[i].om * e->r_robot);
+                    SUF(respond)(e, dx * inv, dy * inv, e->rs_rr - d, b[j].vx - b[i].vx, b[j].vy - b[i].vy, wsum,
+                                 e->ope_rr, e->w_rr, e->kt_rr, e->mu_rr, RC(0), &avx, &avy, &apx, &apy, &aw);
+                    any = 1;
+                }
+            } else if (i < N) { /* robot i, ball j */
+                R nx, ny, pen; int mouth;
+                int touch = SUF(rb_geom)(e, &b[i], ball, &nx, &ny, &pen, &mouth);
+                if (touch) {
+                    R wsum = R_FMA(ball->om, e->r_ball, b[i].om * (mouth ? e->dck : e->r_robot));
+                    SUF(respond)(e, nx, ny, pen, ball->vx - b[i].vx, ball->vy - b[i].vy, wsum,
+                                 e->ope_rb, e->w_rb_r, e->kt_rb_r, e->mu_rb, RC(0), &avx, &avy, &apx, &apy, &aw);
+                    any = 1;
+                }
+                if (first) b[i].ir = mouth && pen > -e->ir_tol;
+            } else if (!ssl) { /* VSS ball i, robot j: circle - circle from the ball's point of view */
+                R dx = b[j].x - ball->x, dy = b[j].y - ball->y;
+                R d2 = R_FMA(dx, dx, dy * dy);
+                if (d2 < e->rs_rb2 && d2 > RC(0) && ball->z < e->robot_h) {
+                    R d = R_SQRT(d2), inv = RC(1) / d;
+                    R wsum = R_FMA(b[j].om, e->r_robot, ball->om * e->r_ball);
+                    SUF(respond)(e, dx * inv, dy * inv, e->rs_rb - d, b[j].vx - ball->vx, b[j].vy - ball->vy, wsum,
+                                 e->ope_rb, e->w_rb_b, e->kt_rb_b, e->mu_rb, e->spin_c, &avx, &avy, &apx, &apy, &aw);
+                    any = 1;
+                }
+            } else { /* SSL ball i, robot j: the ball's side of what robot j evaluated (robot frame) */
+                R nx, ny, pen; int mouth;
+                int touch = SUF(rb_geom)(e, &b[j], ball, &nx, &ny, &pen, &mouth);
+                if (touch) {
+                    R dx_ = ball->vx - b[j].vx, dy_ = ball->vy - b[j].vy;
+                    R vn = R_FMA(dx_, nx, dy_ * ny);
+                    if (vn < RC(0)) {
+                        R q = e->ope_rb * vn * e->w_rb_b;
+                        R wsum = R_FMA(ball->om, e->r_ball, b[j].om * (mouth ? e->dck : e->r_robot));
+                        R vt = R_FMA(dy_, nx, -(dx_ * ny)) - wsum;
+                        R lim = q * e->mu_rb;
+                        R ft = SUF(clampr)(vt * e->kt_rb_b, lim, -lim);
+                        avx = avx - R_FMA(-ft, ny, q * nx);
+                        avy = avy - R_FMA(ft, nx, q * ny);
+                        aw = aw + ft * e->spin_c;
+                    }
+                    R pc = e->beta * pen * e->w_rb_b;
+                    apx = apx + pc * nx; apy = apy + pc * ny;
+                    any = 1;
+                }
+                if (first && mouth && pen > -e->ir_tol) { /* infrared: kicker / dribbler act */
+                    if (b[j].kick_x > RC(0) || b[j].kick_z > RC(0)) {
+                        K->ovr = 1; K->okick = 1;
+                        K->ovx = b[j].vx + b[j].kick_x * b[j].c;
+                        K->ovy = b[j].vy + b[j].kick_x * b[j].s;
+                        K->ovz = b[j].kick_z;
+                    } else if (b[j].drib) {
+                        R hx = b[j].x + e->dck_rb * b[j].c, hy = b[j].y + e->dck_rb * b[j].s;
+                        R cvx = (hx - ball->x) * e->drib_gain, cvy = (hy - ball->y) * e->drib_gain;
+                        R m2 = cvx * cvx + cvy * cvy;
+                        if (m2 > e->drib_vmax2) { R sc = e->drib_vmax / R_SQRT(m2); cvx = cvx * sc; cvy = cvy * sc; }
+                        K->ovr = 1; K->okick = 0;
+                        K->ovx = (b[j].vx - b[j].om * e->dck_rb * b[j].s) + cvx;
+                        K->ovy = (b[j].vy + b[j].om * e->dck_rb * b[j].c) + cvy;
+                    }
+                }
+            }
+        }
+        dvx[i] = avx; dvy[i] = avy; dpx[i] = apx; dpy[i] = apy;
+        if (i == N) dws = aw;
+    }
+    for (int i = 0; i < M; ++i) {
+        b[i].vx = b[i].vx + dvx[i]; b[i].vy = b[i].vy + dvy[i];
+        b[i].x = b[i].x + dpx[i]; b[i].y = b[i].y + dpy[i];
+    }
+    ball->om = ball->om + dws;
+    return any;
+}
+
 /* ------------------------------------------------------------------------------------------
  * robosim.step(cmds) — rsim.py:102 (VSS [N][2]) / rsim.py:155 (SSL [N][8]); cmds already R
  * ---------------------------------------------------------------------------------------- */
 static void SUF(step_core)(SUF(rsxo_env)* e, const R* cmds) {
     const rsxo_cfg* c = &e->cfg;
-    const int N = c->n_robots, M = N + 1, RS = e->RS, ssl = c->kind == 1;
+    const int N = c->n_robots, RS = e->RS, ssl = c->kind == 1;
     SUF(body) b[MAXBOD];
     memset(b, 0, sizeof(b));
     R* s = e->state;
@@ -253,6 +408,7 @@ static void SUF(step_core)(SUF(rsxo_env)* e, const R* cmds) {
     SUF(body)* ball = &b[N];
     ball->x = s[0]; ball->y = s[1]; ball->z = s[2] - e->r_ball; ball->vx = s[3]; ball->vy = s[4];
     ball->vz = s[e->state_dim];
+    ball->om = s[e->state_dim + 1];
     /* rolling resistance: a constant deceleration, applied once for the whole step() while the
      * ball is on the ground (exact stop, never reverses) */
     if (c->n_sub && !(ball->z > RC(0) || ball->vz > RC(0))) {
@@ -263,6 +419,9 @@ static void SUF(step_core)(SUF(rsxo_env)* e, const R* cmds) {
             R k = ns / sp;
             ball->vx = ball->vx * k; ball->vy = ball->vy * k;
         }
+        /* spin about the vertical axis: constant pivoting-friction deceleration to an exact stop */
+        R aw = R_FABS(ball->om) - e->spin_dec_dt;
+        ball->om = aw > RC(0) ? (ball->om < RC(0) ? -aw : aw) : RC(0);
     }
 
     for (int sub = 0; sub < c->n_sub; ++sub) {
@@ -303,83 +462,27 @@ static void SUF(step_core)(SUF(rsxo_env)* e, const R* cmds) {
         ball->x = R_FMA(ball->vx, e->h, ball->x);
         ball->y = R_FMA(ball->vy, e->h, ball->y);
 
-        /* ---- B: contacts, Jacobi over the post-integration snapshot ---- */
-        R dvx[MAXBOD], dvy[MAXBOD], dpx[MAXBOD], dpy[MAXBOD];
-        int ovr = 0; R ovx = RC(0), ovy = RC(0), ovz = RC(0); int okick = 0;
-        for (int i = 0; i < M; ++i) {
-            R avx = RC(0), avy = RC(0), apx = RC(0), apy = RC(0);
-            for (int j = 0; j < M; ++j) {
-                if (j == i) continue;
-                if (i < N && j < N) { /* robot - robot */
-                    R dx = b[j].x - b[i].x, dy = b[j].y - b[i].y;
-                    R d2 = R_FMA(dx, dx, dy * dy);
-                    if (d2 < e->rs_rr2 && d2 > RC(0)) {
-                        R d = R_SQRT(d2), inv = RC(1) / d;
-                        R nx = dx * inv, ny = dy * inv, pen = e->rs_rr - d;
-                        R vn = R_FMA(b[j].vx - b[i].vx, nx, (b[j].vy - b[i].vy) * ny);
-                        if (vn < RC(0)) { R q = e->ope_rr * vn * e->w_rr; avx = R_FMA(q, nx, avx); avy = R_FMA(q, ny, avy); }
-                        R pc = e->beta * pen * e->w_rr;
-                        apx = R_FMA(-pc, nx, apx); apy = R_FMA(-pc, ny, apy);
-                    }
-                } else if (i < N) { /* robot i, ball j */
-                    R nx, ny, pen; int mouth;
-                    int touch = SUF(rb_geom)(e, &b[i], ball, &nx, &ny, &pen, &mouth);
-                    if (touch) {
-                        R vn = R_FMA(ball->vx - b[i].vx, nx, (ball->vy - b[i].vy) * ny);
-                        if (vn < RC(0)) { R q = e->ope_rb * vn * e->w_rb_r; avx = R_FMA(q, nx, avx); avy = R_FMA(q, ny, avy); }
-                        R pc = e->beta * pen * e->w_rb_r;
-                        apx = R_FMA(-pc, nx, apx); apy = R_FMA(-pc, ny, apy);
-                    }
-                    b[i].ir = mouth && pen > -e->ir_tol;
-                } else { /* ball i, robot j */
-                    R nx, ny, pen; int mouth;
-                    int touch = SUF(rb_geom)(e, &b[j], ball, &nx, &ny, &pen, &mouth);
-                    if (touch) {
-                        R vn = R_FMA(ball->vx - b[j].vx, nx, (ball->vy - b[j].vy) * ny);
-                        if (vn < RC(0)) {
-                            R q = e->ope_rb * vn * e->w_rb_b;
-                            if (ssl) { avx = avx - q * nx; avy = avy - q * ny; }       /* summed from the robots' records */
-                            else { avx = R_FMA(-q, nx, avx); avy = R_FMA(-q, ny, avy); } /* computed in place */
-                        }
-                        R pc = e->beta * pen * e->w_rb_b;
-                        if (ssl) { apx = apx + pc * nx; apy = apy + pc * ny; }
-                        else { apx = R_FMA(pc, nx, apx); apy = R_FMA(pc, ny, apy); }
-                    }
-                    if (mouth && pen > -e->ir_tol) { /* infrared: kicker / dribbler act */
-                        if (b[j].kick_x > RC(0) || b[j].kick_z > RC(0)) {
-                            ovr = 1; okick = 1;
-                            ovx = b[j].vx + b[j].kick_x * b[j].c;
-                            ovy = b[j].vy + b[j].kick_x * b[j].s;
-                            ovz = b[j].kick_z;
-                        } else if (b[j].drib) {
-                            R hx = b[j].x + e->dck_rb * b[j].c, hy = b[j].y + e->dck_rb * b[j].s;
-                            R cvx = (hx - ball->x) * e->drib_gain, cvy = (hy - ball->y) * e->drib_gain;
-                            R m2 = cvx * cvx + cvy * cvy;
-                            if (m2 > e->drib_vmax2) { R sc = e->drib_vmax / R_SQRT(m2); cvx = cvx * sc; cvy = cvy * sc; }
-                            ovr = 1; okick = 0;
-                            ovx = (b[j].vx - b[j].om * e->dck_rb * b[j].s) + cvx;
-                            ovy = (b[j].vy + b[j].om * e->dck_rb * b[j].c) + cvy;
-                        }
-                    }
-                }
-            }
-            dvx[i] = avx; dvy[i] = avy; dpx[i] = apx; dpy[i] = apy;
-        }
-        for (int i = 0; i < M; ++i) {
-            b[i].vx = b[i].vx + dvx[i]; b[i].vy = b[i].vy + dvy[i];
-            b[i].x = b[i].x + dpx[i]; b[i].y = b[i].y + dpy[i];
-        }
-        if (ovr) {
-            ball->vx = ovx; ball->vy = ovy;
-            if (okick && ovz > RC(0)) ball->vz = ovz;
+        /* ---- B: contacts — one Jacobi sweep over the post-integration snapshot, and a second
+         * one over the corrected snapshot when anything touched (crowded scenes); what kicker and
+         * dribbler decided in the first sweep is applied after the impulses ---- */
+        SUF(kick) K; memset(&K, 0, sizeof(K));
+        if (SUF(contacts)(e, b, 1, &K)) SUF(contacts)(e, b, 0, &K);
+        if (K.ovr) {
+            ball->vx = K.ovx; ball->vy = K.ovy; ball->om = RC(0);
+            if (K.okick && K.ovz > RC(0)) ball->vz = K.ovz;
         }
         /* ---- C: walls ---- */
         for (int k = 0; k < N; ++k) SUF(walls)(e, e->r_robot, e->e_wr, &b[k].x, &b[k].y, &b[k].vx, &b[k].vy);
-        SUF(walls)(e, e->r_ball, e->e_wb, &ball->x, &ball->y, &ball->vx, &ball->vy);
+        {
+            const R vx0 = ball->vx, vy0 = ball->vy;
+            int hit = SUF(walls)(e, e->r_ball, e->e_wb, &ball->x, &ball->y, &ball->vx, &ball->vy);
+            if (hit) SUF(ball_wall_spin)(e, hit, vx0, vy0, &ball->vx, &ball->vy, &ball->om);
+        }
     }
     /* ---- store ---- */
     s[0] = ball->x; s[1] = ball->y; s[2] = e->r_ball + ball->z; s[3] = ball->vx; s[4] = ball->vy;
     s[e->state_dim] = ball->vz;
+    s[e->state_dim + 1] = ball->om;
     for (int k = 0; k < N; ++k) {
         R* r = s + 5 + RS * k;
         const SUF(body)* o = &b[k];
@@ -776,7 +879,7 @@ void SUF(rsxo_task_step)(void* p, const float* action) {
         }
     }
     R cmds[MAXROB * 8];
-    R last[5 + 11 * MAXROB + 1];
+    R last[5 + 11 * MAXROB + RSXO_XROWS];
     memcpy(last, e->state, sizeof(last));
     if (e->task == 1) {
         R act[MAXROB * 2];
@@ -868,7 +971,7 @@ void SUF(rsxo_task_cmds_eval)(void* p, const double* act, double theta_deg, doub
 void SUF(rsxo_task_reward_eval)(void* p, const double* last, const double* cmds, int first_step,
                                 double* reward, int* done) {
     SUF(rsxo_env)* e = (SUF(rsxo_env)*)p;
-    R l[5 + 11 * MAXROB + 1], q[MAXROB * 8];
+    R l[5 + 11 * MAXROB + RSXO_XROWS], q[MAXROB * 8];
     int N = e->cfg.n_robots, C = e->cfg.kind == 0 ? 2 : 8;
     for (int i = 0; i < e->state_dim; ++i) l[i] = RC(last[i]);
     for (int i = 0; i < N * C; ++i) q[i] = RC(cmds[i]);

@@ -22,6 +22,7 @@ FIELD_KEYS = (
     "rbt_radius", "rbt_wheel_radius", "rbt_motor_max_rpm",
 )  # Entities/Field.py:5-21
 N_METRICS = 8
+X_ROWS = 2   # internal state rows behind get_state(): ball vertical velocity, ball spin (RSX_STATE_EXTRA_ROWS)
 METRIC_NAMES = ("env_steps", "episodes", "goals_for", "goals_against", "return_sum_q20",
                 "episode_len_sum", "truncated_episodes", "reserved")
 
@@ -91,7 +92,7 @@ def load():
     lib.rsx_task_step_n.argtypes = [vp, ip, vp]
     lib.rsx_task_rollout.argtypes = [vp, ip, vp]
     lib.rsx_read_metrics.argtypes = [vp, vp, vp]
-    if lib.rsx_abi_version() != 1:
+    if lib.rsx_abi_version() != 2:
         raise RsxError("librsx_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -199,12 +200,12 @@ class Sim:
         return out
 
     def get_state_full(self, stream=None):
-        out = np.empty((self.num_envs, self.state_dim + 1), dtype=np.float64)
+        out = np.empty((self.num_envs, self.state_dim + X_ROWS), dtype=np.float64)
         _chk(self._lib.rsx_get_state_full(self._h, _ptr(out), self._stream(stream)))
         return out
 
     def set_state(self, state, stream=None):
-        s = _f64(state, (self.num_envs, self.state_dim + 1))
+        s = _f64(state, (self.num_envs, self.state_dim + X_ROWS))
         _chk(self._lib.rsx_set_state(self._h, _ptr(s), self._stream(stream)))
 
     # ---- device-resident path ----
@@ -217,8 +218,8 @@ class Sim:
                                device=torch.device("cuda", self.device_id))
 
     def state_tensor(self):
-        """[state_dim+1, B] float32, zero-copy view of the SoA state."""
-        return self._tensor(self._view.state, (self.state_dim + 1, self.num_envs), "<f4")
+        """[state_dim+2, B] float32, zero-copy view of the SoA state."""
+        return self._tensor(self._view.state, (self.state_dim + X_ROWS, self.num_envs), "<f4")
 
     def cmds_tensor(self):
         """[N*C, B] float32, zero-copy view of the SoA command buffer read by step_dev()."""

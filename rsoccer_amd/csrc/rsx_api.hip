@@ -242,7 +242,7 @@ int upload_state(rsx_sim* h, const std::vector<float>& soa, hipStream_t s) {
     return RSX_OK;
 }
 int download_state(rsx_sim* h, std::vector<float>& soa, hipStream_t s) {
-    soa.resize((size_t)(h->P.state_dim + 1) * h->P.num_envs);
+    soa.resize((size_t)(h->P.state_dim + X_ROWS) * h->P.num_envs);
     HIP_TRY(hipMemcpyAsync(soa.data(), h->d_state, soa.size() * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return RSX_OK;
@@ -255,7 +255,7 @@ void apply_reset(const rsx_sim* h, std::vector<float>& soa, const double* ball, 
     const size_t B = (size_t)P.num_envs;
     for (size_t e = 0; e < B; ++e) {
         if (mask && !mask[e]) continue;
-        for (int f = 0; f <= P.state_dim; ++f) soa[(size_t)f * B + e] = 0.0f;
+        for (int f = 0; f < P.state_dim + X_ROWS; ++f) soa[(size_t)f * B + e] = 0.0f;
         const double* bl = ball + 4 * e;
         soa[0 * B + e] = (float)bl[0]; soa[1 * B + e] = (float)bl[1]; soa[2 * B + e] = (float)h->M.field[6];
         soa[3 * B + e] = (float)bl[2]; soa[4 * B + e] = (float)bl[3];
@@ -326,7 +326,7 @@ int rsx_create(rsx_sim** out, int kind, int field_type, int n_blue, int n_yellow
     DeviceGuard guard;
     if (guard.enter(device_id)) { free_all(h); delete h; return RSX_ERR_HIP; }
     const size_t B = (size_t)num_envs;
-    const size_t sbytes = (size_t)(h->P.state_dim + 1) * B * sizeof(float);
+    const size_t sbytes = (size_t)(h->P.state_dim + X_ROWS) * B * sizeof(float);
     const size_t cbytes = (size_t)h->P.n_robots * h->M.cmd_dim * B * sizeof(float);
     if ((e = hipMalloc((void**)&h->arena_sim, align_up(sbytes) + align_up(cbytes))) != hipSuccess) return bail(e, "hipMalloc(state+cmds)");
     h->d_state = (float*)h->arena_sim;
@@ -336,7 +336,7 @@ int rsx_create(rsx_sim** out, int kind, int field_type, int n_blue, int n_yellow
     if ((e = hipHostMalloc((void**)&h->pin_state, sbytes, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc(state)");
     if ((e = hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     // the adapter's dummy line-up, rsim.py:20-24
-    std::vector<float> soa((size_t)(h->P.state_dim + 1) * B, 0.0f);
+    std::vector<float> soa((size_t)(h->P.state_dim + X_ROWS) * B, 0.0f);
     for (size_t i = 0; i < B; ++i) {
         soa[2 * B + i] = (float)h->M.field[6];
         for (int k = 0; k < h->P.n_robots; ++k) {
@@ -374,7 +374,7 @@ int rsx_reset(rsx_sim* h, const double* ball, const double* blue, const double* 
     hipStream_t s = (hipStream_t)stream;
     std::vector<float> soa;
     if (env_mask) { if (int rc = download_state(h, soa, s)) return rc; }
-    else soa.assign((size_t)(h->P.state_dim + 1) * h->P.num_envs, 0.0f);
+    else soa.assign((size_t)(h->P.state_dim + X_ROWS) * h->P.num_envs, 0.0f);
     apply_reset(h, soa, ball, blue, yellow, env_mask);
     return upload_state(h, soa, s);
 }
@@ -392,7 +392,7 @@ int rsx_step(rsx_sim* h, const double* cmds, void* stream) {
     launch_sim(h, s);
     HIP_TRY(hipGetLastError());
     if (h->host_state_cache)
-        HIP_TRY(hipMemcpyAsync(h->pin_state, h->d_state, (size_t)(P.state_dim + 1) * B * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(h->pin_state, h->d_state, (size_t)(P.state_dim + X_ROWS) * B * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     h->host_state_valid = h->host_state_cache;
     return RSX_OK;
@@ -401,7 +401,7 @@ int rsx_step(rsx_sim* h, const double* cmds, void* stream) {
 static int get_state_impl(rsx_sim* h, double* out, int rows, hipStream_t s) {
     const size_t B = (size_t)h->P.num_envs;
     if (!h->host_state_valid) {
-        HIP_TRY(hipMemcpyAsync(h->pin_state, h->d_state, (size_t)(h->P.state_dim + 1) * B * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(h->pin_state, h->d_state, (size_t)(h->P.state_dim + X_ROWS) * B * sizeof(float), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         h->host_state_valid = h->host_state_cache;
     }
@@ -420,14 +420,14 @@ int rsx_get_state(rsx_sim* h, double* out, void* stream) {
 int rsx_get_state_full(rsx_sim* h, double* out, void* stream) {
     RSX_ENTER(h);
     if (!out) return fail(RSX_ERR_ARG, "out is null");
-    return get_state_impl(h, out, h->P.state_dim + 1, (hipStream_t)stream);
+    return get_state_impl(h, out, h->P.state_dim + X_ROWS, (hipStream_t)stream);
 }
 
 int rsx_set_state(rsx_sim* h, const double* state, void* stream) {
     RSX_ENTER(h);
     if (!state) return fail(RSX_ERR_ARG, "state is null");
     const size_t B = (size_t)h->P.num_envs;
-    const int rows = h->P.state_dim + 1;
+    const int rows = h->P.state_dim + X_ROWS;
     std::vector<float> soa((size_t)rows * B);
     for (size_t e = 0; e < B; ++e)
         for (int f = 0; f < rows; ++f) soa[(size_t)f * B + e] = (float)state[e * rows + f];

@@ -28,7 +28,7 @@ struct EplShared {
     // phase 1 (contacts of a sub-step, only when some lane touches something): snapshot + sums,
     // phase 2 (after the physics): observation rows; the two never live together
     union {
-        struct { float snap[4][EPL_NB][64]; float acc[4][EPL_NB][64]; } c;
+        struct { float snap[5][EPL_NB][64]; float acc[4][EPL_NB][64]; float accw[64]; } c;
         float stage[64 * EPL_ODP];
     } u;
     // (the reset placement keeps its poses in the resetting env's own observation row: that row
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64) void vss_epl_kernel(RSX_HOT_ARGS, const Params 
     float info[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     float prev_pot = 0.0f, ep_ret = 0.0f;
     int steps = 0; uint32_t episode = 0;
-    float raw[N][6], rawb[6] = {0, 0, 0, 0, 0, 0};
+    float raw[N][6], rawb[7] = {0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < N; ++k) {
 #pragma unroll
@@ -82,6 +82,7 @@ __global__ __launch_bounds__(64) void vss_epl_kernel(RSX_HOT_ARGS, const Params 
 #pragma unroll
         for (int f = 0; f < 5; ++f) rawb[f] = st[(size_t)f * B];
         rawb[5] = st[(size_t)P.state_dim * B];
+        rawb[6] = st[(size_t)(P.state_dim + 1) * B];
         steps = __float_as_int(auxe[(size_t)ROW_STEPS * B]);
         episode = __float_as_uint(auxe[(size_t)ROW_EPISODE * B]);
 #pragma unroll
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(64) void vss_epl_kernel(RSX_HOT_ARGS, const Params 
         sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
     }
     ball.x = rawb[0]; ball.y = rawb[1]; ball.vx = rawb[3]; ball.vy = rawb[4];
-    ball.z = rawb[2] - K::r_ball; ball.vz = rawb[5];
+    ball.z = rawb[2] - K::r_ball; ball.vz = rawb[5]; ball.om = rawb[6];
 
     float reward = 0.0f; int term = 0, trunc = 0;
 
@@ -151,6 +152,8 @@ __global__ __launch_bounds__(64) void vss_epl_kernel(RSX_HOT_ARGS, const Params 
                 float kk = ns / sp;
                 ball.vx = ball.vx * kk; ball.vy = ball.vy * kk;
             }
+            const float aw = fabsf(ball.om) - P.spin_dec_dt;   // spin decay, once per step()
+            ball.om = aw > 0.0f ? (ball.om < 0.0f ? -aw : aw) : 0.0f;
         }
         for (int sub = 0; sub < P.n_sub; ++sub) {
             // A: actuation + integration
@@ -185,11 +188,12 @@ __global__ __launch_bounds__(64) void vss_epl_kernel(RSX_HOT_ARGS, const Params 
 
             // B: contacts, Jacobi over the post-integration snapshot.  Every pair once; the exact
             // integer form of 0 < d2 < thr (see rsx_kernels.hpp) gives one bit per touching pair.
+            // A second sweep over the corrected snapshot runs in the envs where anything touched.
             const bool ball_low = ball.z < K::robot_h;
             constexpr uint32_t T_RR = __builtin_bit_cast(uint32_t, K::rs_rr2) - 1u;
             constexpr uint32_t T_RB = __builtin_bit_cast(uint32_t, K::rs_rb2) - 1u;
-            unsigned touching = 0;
-            {
+            auto find_touching = [&]() -> unsigned {
+                unsigned touching = 0;
                 int p = 0;
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
@@ -202,72 +206,95 @@ __global__ __launch_bounds__(64) void vss_epl_kernel(RSX_HOT_ARGS, const Params 
                         touching |= tch ? 1u << p : 0u;
                     }
                 }
-            }
-            float avx[EPL_NB], avy[EPL_NB], apx[EPL_NB], apy[EPL_NB];
-#pragma unroll
-            for (int k = 0; k < EPL_NB; ++k) { avx[k] = 0.0f; avy[k] = 0.0f; apx[k] = 0.0f; apy[k] = 0.0f; }
+                return touching;
+            };
+            unsigned touching = find_touching();
             if (__any(touching != 0)) {
                 // some env of the wave has a contact: bodies are addressed by index from here on,
                 // so the snapshot and the sums go through LDS (column = lane, conflict free)
-#pragma unroll
-                for (int k = 0; k < N; ++k) {
-                    sh.u.c.snap[0][k][lane] = r[k].x; sh.u.c.snap[1][k][lane] = r[k].y;
-                    sh.u.c.snap[2][k][lane] = r[k].vx; sh.u.c.snap[3][k][lane] = r[k].vy;
-                }
-                sh.u.c.snap[0][N][lane] = ball.x; sh.u.c.snap[1][N][lane] = ball.y;
-                sh.u.c.snap[2][N][lane] = ball.vx; sh.u.c.snap[3][N][lane] = ball.vy;
-#pragma unroll
-                for (int k = 0; k < EPL_NB; ++k) {
-                    sh.u.c.acc[0][k][lane] = 0.0f; sh.u.c.acc[1][k][lane] = 0.0f;
-                    sh.u.c.acc[2][k][lane] = 0.0f; sh.u.c.acc[3][k][lane] = 0.0f;
-                }
-                wave_sync();
-                unsigned todo = touching;
-                while (todo) {   // each lane walks ITS touching pairs, in pair order
-                    const int p = __builtin_ctz(todo);
-                    todo &= todo - 1;
-                    int i, j;
-                    epl_pair(p, i, j);
-                    const bool rb = j == N;
-                    Body bi = Body{}, bj = Body{};
-                    bi.x = sh.u.c.snap[0][i][lane]; bi.y = sh.u.c.snap[1][i][lane]; bi.vx = sh.u.c.snap[2][i][lane]; bi.vy = sh.u.c.snap[3][i][lane];
-                    bj.x = sh.u.c.snap[0][j][lane]; bj.y = sh.u.c.snap[1][j][lane]; bj.vx = sh.u.c.snap[2][j][lane]; bj.vy = sh.u.c.snap[3][j][lane];
-                    const float rs = rb ? K::rs_rb : K::rs_rr, ope = rb ? K::ope_rb : K::ope_rr;
-                    // body i sees j ...
-                    {
-                        const float dx = bj.x - bi.x, dy = bj.y - bi.y;
-                        const float d2 = fma_(dx, dx, dy * dy);
-                        float a0 = sh.u.c.acc[0][i][lane], a1 = sh.u.c.acc[1][i][lane], a2 = sh.u.c.acc[2][i][lane], a3 = sh.u.c.acc[3][i][lane];
-                        contact_response(bi, make_float4(bj.x, bj.y, bj.vx, bj.vy), d2, rs, ope, rb ? K::w_rb_r : K::w_rr, K::beta, a0, a1, a2, a3);
-                        sh.u.c.acc[0][i][lane] = a0; sh.u.c.acc[1][i][lane] = a1; sh.u.c.acc[2][i][lane] = a2; sh.u.c.acc[3][i][lane] = a3;
+                for (int sweep = 0; sweep < 2; ++sweep) {
+                    if (sweep == 1) {
+                        touching = touching ? find_touching() : 0u;   // only the envs of the first sweep
+                        if (!__any(touching != 0)) break;
                     }
-                    // ... and j sees i, from its own point of view (what its lane computes in the other layout)
-                    {
-                        const float dx = bi.x - bj.x, dy = bi.y - bj.y;
-                        const float d2 = fma_(dx, dx, dy * dy);
-                        float a0 = sh.u.c.acc[0][j][lane], a1 = sh.u.c.acc[1][j][lane], a2 = sh.u.c.acc[2][j][lane], a3 = sh.u.c.acc[3][j][lane];
-                        contact_response(bj, make_float4(bi.x, bi.y, bi.vx, bi.vy), d2, rs, ope, rb ? K::w_rb_b : K::w_rr, K::beta, a0, a1, a2, a3);
-                        sh.u.c.acc[0][j][lane] = a0; sh.u.c.acc[1][j][lane] = a1; sh.u.c.acc[2][j][lane] = a2; sh.u.c.acc[3][j][lane] = a3;
-                    }
-                }
-                wave_sync();
 #pragma unroll
-                for (int k = 0; k < EPL_NB; ++k) {
-                    avx[k] = sh.u.c.acc[0][k][lane]; avy[k] = sh.u.c.acc[1][k][lane];
-                    apx[k] = sh.u.c.acc[2][k][lane]; apy[k] = sh.u.c.acc[3][k][lane];
+                    for (int k = 0; k < N; ++k) {
+                        sh.u.c.snap[0][k][lane] = r[k].x; sh.u.c.snap[1][k][lane] = r[k].y;
+                        sh.u.c.snap[2][k][lane] = r[k].vx; sh.u.c.snap[3][k][lane] = r[k].vy;
+                        sh.u.c.snap[4][k][lane] = r[k].om;
+                    }
+                    sh.u.c.snap[0][N][lane] = ball.x; sh.u.c.snap[1][N][lane] = ball.y;
+                    sh.u.c.snap[2][N][lane] = ball.vx; sh.u.c.snap[3][N][lane] = ball.vy;
+                    sh.u.c.snap[4][N][lane] = ball.om;
+#pragma unroll
+                    for (int k = 0; k < EPL_NB; ++k) {
+                        sh.u.c.acc[0][k][lane] = 0.0f; sh.u.c.acc[1][k][lane] = 0.0f;
+                        sh.u.c.acc[2][k][lane] = 0.0f; sh.u.c.acc[3][k][lane] = 0.0f;
+                    }
+                    sh.u.c.accw[lane] = 0.0f;
+                    wave_sync();
+                    unsigned todo = touching;
+                    while (todo) {   // each lane walks ITS touching pairs, in pair order
+                        const int p = __builtin_ctz(todo);
+                        todo &= todo - 1;
+                        int i, j;
+                        epl_pair(p, i, j);
+                        const bool rb = j == N;
+                        Body bi = Body{}, bj = Body{};
+                        bi.x = sh.u.c.snap[0][i][lane]; bi.y = sh.u.c.snap[1][i][lane]; bi.vx = sh.u.c.snap[2][i][lane]; bi.vy = sh.u.c.snap[3][i][lane];
+                        bj.x = sh.u.c.snap[0][j][lane]; bj.y = sh.u.c.snap[1][j][lane]; bj.vx = sh.u.c.snap[2][j][lane]; bj.vy = sh.u.c.snap[3][j][lane];
+                        const float wi = sh.u.c.snap[4][i][lane], wj = sh.u.c.snap[4][j][lane];
+                        const float rs = rb ? K::rs_rb : K::rs_rr, ope = rb ? K::ope_rb : K::ope_rr;
+                        const float mu = rb ? K::mu_rb : K::mu_rr;
+                        const float lever_j = rb ? K::r_ball : K::r_robot;
+                        float unused = 0.0f;
+                        // body i (a robot) sees j ...
+                        {
+                            const float dx = bj.x - bi.x, dy = bj.y - bi.y;
+                            const float d2 = fma_(dx, dx, dy * dy);
+                            float a0 = sh.u.c.acc[0][i][lane], a1 = sh.u.c.acc[1][i][lane], a2 = sh.u.c.acc[2][i][lane], a3 = sh.u.c.acc[3][i][lane];
+                            contact_response(bi, make_float4(bj.x, bj.y, bj.vx, bj.vy), d2, rs, ope, rb ? K::w_rb_r : K::w_rr,
+                                             rb ? K::kt_rb_r : K::kt_rr, mu, 0.0f, fma_(wj, lever_j, wi * K::r_robot), K::beta,
+                                             a0, a1, a2, a3, unused);
+                            sh.u.c.acc[0][i][lane] = a0; sh.u.c.acc[1][i][lane] = a1; sh.u.c.acc[2][i][lane] = a2; sh.u.c.acc[3][i][lane] = a3;
+                        }
+                        // ... and j sees i, from its own point of view (what its lane computes in the other layout)
+                        {
+                            const float dx = bi.x - bj.x, dy = bi.y - bj.y;
+                            const float d2 = fma_(dx, dx, dy * dy);
+                            float a0 = sh.u.c.acc[0][j][lane], a1 = sh.u.c.acc[1][j][lane], a2 = sh.u.c.acc[2][j][lane], a3 = sh.u.c.acc[3][j][lane];
+                            float a4 = rb ? sh.u.c.accw[lane] : 0.0f;
+                            contact_response(bj, make_float4(bi.x, bi.y, bi.vx, bi.vy), d2, rs, ope, rb ? K::w_rb_b : K::w_rr,
+                                             rb ? K::kt_rb_b : K::kt_rr, mu, rb ? K::spin_c : 0.0f, fma_(wi, K::r_robot, wj * lever_j), K::beta,
+                                             a0, a1, a2, a3, a4);
+                            sh.u.c.acc[0][j][lane] = a0; sh.u.c.acc[1][j][lane] = a1; sh.u.c.acc[2][j][lane] = a2; sh.u.c.acc[3][j][lane] = a3;
+                            if (rb) sh.u.c.accw[lane] = a4;
+                        }
+                    }
+                    wave_sync();
+#pragma unroll
+                    for (int k = 0; k < N; ++k) {
+                        r[k].vx = r[k].vx + sh.u.c.acc[0][k][lane]; r[k].vy = r[k].vy + sh.u.c.acc[1][k][lane];
+                        r[k].x = r[k].x + sh.u.c.acc[2][k][lane]; r[k].y = r[k].y + sh.u.c.acc[3][k][lane];
+                    }
+                    ball.vx = ball.vx + sh.u.c.acc[0][N][lane]; ball.vy = ball.vy + sh.u.c.acc[1][N][lane];
+                    ball.x = ball.x + sh.u.c.acc[2][N][lane]; ball.y = ball.y + sh.u.c.acc[3][N][lane];
+                    ball.om = ball.om + sh.u.c.accw[lane];
+                    wave_sync();
                 }
-                wave_sync();
             }
+            // C: walls
 #pragma unroll
             for (int k = 0; k < N; ++k) {
-                r[k].vx = r[k].vx + avx[k]; r[k].vy = r[k].vy + avy[k];
-                r[k].x = r[k].x + apx[k]; r[k].y = r[k].y + apy[k];
-                // C: walls
-                walls<KIND>(P, K::r_robot, K::e_wr, r[k].x, r[k].y, r[k].vx, r[k].vy);
+                int hit;
+                walls<KIND>(P, K::r_robot, K::e_wr, r[k].x, r[k].y, r[k].vx, r[k].vy, hit);
             }
-            ball.vx = ball.vx + avx[N]; ball.vy = ball.vy + avy[N];
-            ball.x = ball.x + apx[N]; ball.y = ball.y + apy[N];
-            walls<KIND>(P, K::r_ball, K::e_wb, ball.x, ball.y, ball.vx, ball.vy);
+            {
+                const float vx0 = ball.vx, vy0 = ball.vy;
+                int hit = 0;
+                walls<KIND>(P, K::r_ball, K::e_wb, ball.x, ball.y, ball.vx, ball.vy, hit);
+                if (hit) ball_wall_spin<KIND>(hit, vx0, vy0, ball.vx, ball.vy, ball.om);
+            }
         }
 
         // ---- wire-format values, observation, reward ----
@@ -396,6 +423,7 @@ __global__ __launch_bounds__(64) void vss_epl_kernel(RSX_HOT_ARGS, const Params 
         }
         st[0] = ball.x; st[B] = ball.y; st[2 * B] = K::r_ball + ball.z; st[3 * B] = ball.vx; st[4 * B] = ball.vy;
         st[(size_t)P.state_dim * B] = ball.vz;
+        st[(size_t)(P.state_dim + 1) * B] = ball.om;
         auxe[(size_t)ROW_STEPS * B] = __int_as_float(steps);
         auxe[(size_t)ROW_EPISODE * B] = __uint_as_float(episode);
         auxe[(size_t)ROW_PREV_POT * B] = prev_pot; auxe[(size_t)ROW_EP_RET * B] = ep_ret;

@@ -52,7 +52,7 @@ constexpr int ROW_REWARD = 0, ROW_PREV_POT = 1, ROW_EP_RET = 2, ROW_STEPS = 3, R
 __host__ __device__ constexpr int aux_rows(int n_robots) { return ROW_OU + 2 * n_robots; }
 
 struct Buffers {
-    float* state;          // [state_dim+1][B]
+    float* state;          // [state_dim+X_ROWS][B]
     float* aux;            // [aux_rows][B]   reward, prev_pot, ep_ret, steps, episode, info, ou
     float* obs;            // [B][obs_dim]
     float* final_obs;      // [B][obs_dim]
@@ -80,6 +80,8 @@ struct Shared {
     float4 A[64];   // x, y, vx, vy of every body (slot = lane)
     float4 Bq[64];  // SSL robot -> ball record 0: dvx, dvy, dpx, dpy (ball side)
     float4 Cq[64];  // SSL robot -> ball record 1: flags, ovx, ovy, ovz
+    float Dq[64];   // SSL robot -> ball record 2: spin change of the ball
+    float W[64];    // robots: yaw rate, ball: spin (rad/s) — read on the contact path only
     float zb[64 / L];          // ball height per env
     float x0[64 / L][12];      // robot 0 -> reward lane exchange
     float stage[(64 / L) * 64];  // obs staging, [env][obs_dim], obs_dim <= 64
@@ -101,7 +103,7 @@ struct Shared {
 // clamp a circle (radius r, restitution rest) into the playable region
 template <int KIND>
 __device__ __forceinline__ void walls(const Params& P, const float r, const float rest, float& x,
-                                      float& y, float& vx, float& vy) {
+                                      float& y, float& vx, float& vy, int& hit /* bit 0: vx reflected, bit 1: vy */) {
     using K = KC<KIND>;
     float ax = fabsf(x), ay = fabsf(y);
     const float sx = signf(x), sy = signf(y);  // only read when |x| (|y|) exceeds a positive limit
@@ -117,6 +119,7 @@ __device__ __forceinline__ void walls(const Params& P, const float r, const floa
         const bool fy = hy & (vy * sy > 0.0f), fx = hx & (vx * sx > 0.0f);
         y = hy ? ny : y; vy = fy ? -rest * vy : vy;
         x = hx ? nx : x; vx = fx ? -rest * vx : vx;
+        hit = (fx ? 1 : 0) | (fy ? 2 : 0);
     } else {
         // predicated like the VSS clamp: conditional stores to x / y / vx / vy inside nested
         // branches get merged by the compiler into stores through a selected POINTER, which
@@ -128,6 +131,7 @@ __device__ __forceinline__ void walls(const Params& P, const float r, const floa
         const bool hx = ax > xl;
         const bool fx0 = hx & (vx * sx > 0.0f);
         x = hx ? sx * xl : x; vx = fx0 ? -rest * vx : vx; ax = hx ? xl : ax;
+        hit = (fx0 ? 1 : 0) | (fy0 ? 2 : 0);
         if (ax > P.half_len) {   // beyond a goal line: the goal's walls (rare)
             const float back = P.half_len + P.gd;
             const bool in_mouth = ay < P.ghw;
@@ -143,7 +147,31 @@ __device__ __forceinline__ void walls(const Params& P, const float r, const floa
             y = c2 ? sy * (P.ghw - r) : (c4 ? sy * (P.ghw + r) : y);
             vx = fx ? -rest * vx : vx;
             vy = fy ? -rest * vy : vy;
+            hit |= (fx ? 1 : 0) | (fy ? 2 : 0);
         }
+    }
+}
+
+// A bounce of the BALL off a wall with Coulomb friction at the contact point: couples the velocity
+// component along the wall with the spin about the vertical axis.  (vx0, vy0) = velocity before
+// walls(): the ball moved INTO the wall, so its sign names the wall's side.
+template <int KIND>
+__device__ __forceinline__ void ball_wall_spin(const int hit, const float vx0, const float vy0,
+                                               float& vx, float& vy, float& om) {
+    using K = KC<KIND>;
+    if (hit & 2) {
+        const float sg = vy0 < 0.0f ? -1.0f : 1.0f;
+        const float vc = vx - (om * K::r_ball) * sg;
+        const float lim = K::mu_wb * (K::ope_wb * fabsf(vy0));
+        const float d = clampf(-(vc * K::kw), -lim, lim);
+        vx = vx + d; om = om - (sg * d) * K::spin_c;
+    }
+    if (hit & 1) {
+        const float sg = vx0 < 0.0f ? -1.0f : 1.0f;
+        const float vc = vy + (om * K::r_ball) * sg;
+        const float lim = K::mu_wb * (K::ope_wb * fabsf(vx0));
+        const float d = clampf(-(vc * K::kw), -lim, lim);
+        vy = vy + d; om = om + (sg * d) * K::spin_c;
     }
 }
 
@@ -181,18 +209,224 @@ __device__ __forceinline__ void robot_targets(const Params& P, Body& o, const fl
     }
 }
 
-// contact response once a pair is known to overlap (d2 = squared centre distance)
-__device__ __forceinline__ void contact_response(const Body& o, const float4 oj, const float d2,
-                                                 const float rs, const float ope, const float w,
-                                                 const float beta, float& avx, float& avy,
-                                                 float& apx, float& apy) {
-    float dx = oj.x - o.x, dy = oj.y - o.y;
-    float d = sqrtf(d2), inv = 1.0f / d;
-    float nx = dx * inv, ny = dy * inv, pen = rs - d;
-    float vn = fma_(oj.z - o.vx, nx, (oj.w - o.vy) * ny);
-    if (vn < 0.0f) { float q = ope * vn * w; avx = fma_(q, nx, avx); avy = fma_(q, ny, avy); }
+// Response of a body to ONE touching partner, from the body's point of view (each side of a pair
+// evaluates this with its own constants).  n = unit normal body -> partner, pen = penetration,
+// (dvx, dvy) = v_partner - v_body, wsum = om_partner * lever_partner + om_body * lever_body (surface
+// speeds at the contact point), w / kt = the body's share of the normal / tangential impulse,
+// mu = Coulomb coefficient, spin_c = spin per unit of tangential velocity change (ball only).
+__device__ __forceinline__ void respond(const float nx, const float ny, const float pen, const float dvx,
+                                        const float dvy, const float wsum, const float ope, const float w,
+                                        const float kt, const float mu, const float spin_c, const float beta,
+                                        float& avx, float& avy, float& apx, float& apy, float& aw) {
+    float vn = fma_(dvx, nx, dvy * ny);
+    if (vn < 0.0f) {
+        float q = ope * vn * w;                           // <= 0: pushes the body away from the partner
+        avx = fma_(q, nx, avx); avy = fma_(q, ny, avy);
+        float vt = fma_(dvy, nx, -(dvx * ny)) - wsum;     // along t = (-ny, nx)
+        float lim = q * mu;
+        float ft = clampf(vt * kt, lim, -lim);            // sticking impulse, Coulomb-limited
+        avx = fma_(-ft, ny, avx); avy = fma_(ft, nx, avy);
+        aw = fma_(ft, spin_c, aw);
+    }
     float pc = beta * pen * w;
     apx = fma_(-pc, nx, apx); apy = fma_(-pc, ny, apy);
+}
+
+// circle - circle pair known to overlap (d2 = squared centre distance)
+__device__ __forceinline__ void contact_response(const Body& o, const float4 oj, const float d2,
+                                                 const float rs, const float ope, const float w,
+                                                 const float kt, const float mu, const float spin_c,
+                                                 const float wsum, const float beta, float& avx, float& avy,
+                                                 float& apx, float& apy, float& aw) {
+    float dx = oj.x - o.x, dy = oj.y - o.y;
+    float d = sqrtf(d2), inv = 1.0f / d;
+    respond(dx * inv, dy * inv, rs - d, oj.z - o.vx, oj.w - o.vy, wsum, ope, w, kt, mu, spin_c, beta,
+            avx, avy, apx, apy, aw);
+}
+
+// lanes of the env in slot g: body j sits at lane j * G + g
+template <int L>
+__device__ __forceinline__ unsigned long long env_lane_mask(const int g) {
+    constexpr int G = 64 / L;
+    unsigned long long m = 0;
+#pragma unroll
+    for (int j = 0; j < L; ++j) m |= 1ull << (j * G);
+    return m << g;
+}
+
+// VSS contact sweep with a run-time partner loop: exact integer overlap test into one bit per
+// partner, then the lane walks ITS partners in index order.  First sweep of the run-time-count
+// kernels and second sweep (rare) of all VSS kernels.  Returns whether anything touched.
+template <int KIND, int L>
+__device__ __forceinline__ bool vss_sweep_loop(const Body& o, const int N, const int g, const bool is_ball,
+                                               const bool ball_low, const Shared<L>& sh, float& avx,
+                                               float& avy, float& apx, float& apy, float& aw) {
+    using K = KC<KIND>;
+    constexpr int G = 64 / L;
+    constexpr uint32_t T_RR = __builtin_bit_cast(uint32_t, K::rs_rr2) - 1u;
+    constexpr uint32_t T_RB = __builtin_bit_cast(uint32_t, K::rs_rb2) - 1u;
+    unsigned todo = 0;
+#pragma unroll 4
+    for (int j = 0; j <= N; ++j) {
+        const float4 oj = sh.A[j * G + g];
+        const bool rb = is_ball || j == N;
+        const float dx = oj.x - o.x, dy = oj.y - o.y;
+        const uint32_t u = __float_as_uint(fma_(dx, dx, dy * dy)) - 1u;   // own slot: 0xFFFFFFFF
+        todo |= ((u < (rb ? T_RB : T_RR)) & (!rb | ball_low)) ? 1u << j : 0u;
+    }
+    const bool any = todo != 0;
+    const float lever = is_ball ? K::r_ball : K::r_robot;
+    while (todo) {
+        const int j = __builtin_ctz(todo);
+        todo &= todo - 1;
+        const float4 oj = sh.A[j * G + g];
+        const float wj = sh.W[j * G + g];
+        const float dx = oj.x - o.x, dy = oj.y - o.y;
+        const bool rb = is_ball || j == N;
+        contact_response(o, oj, fma_(dx, dx, dy * dy), rb ? K::rs_rb : K::rs_rr, rb ? K::ope_rb : K::ope_rr,
+                         is_ball ? K::w_rb_b : (j == N ? K::w_rb_r : K::w_rr),
+                         is_ball ? K::kt_rb_b : (j == N ? K::kt_rb_r : K::kt_rr), rb ? K::mu_rb : K::mu_rr,
+                         is_ball ? K::spin_c : 0.0f, fma_(wj, j == N ? K::r_ball : K::r_robot, o.om * lever),
+                         K::beta, avx, avy, apx, apy, aw);
+    }
+    return any;
+}
+
+// What the kicker / dribbler of some robot decided for the ball in the first sweep of a sub-step
+struct BallOverride { bool ovr, okick; float ovx, ovy, ovz; };
+
+// SSL contact sweep.  Robot lanes: robot-robot pairs (circles), then the robot's own robot-ball
+// geometry (kicker mouth or body circle) whose ball-side record goes to LDS; one ballot tells the
+// ball lane which robots wrote one.  FIRST: infrared is refreshed and kicker / dribbler act.
+// NRX > 0: robot count known at compile time (first sweep of the fixed-size kernels).
+template <int KIND, int L, int NRX, bool FIRST>
+__device__ __forceinline__ bool ssl_sweep(const Params& P, Body& o, const int N, const int g, const int lane,
+                                          const bool is_robot, const bool is_ball, const bool ball_low,
+                                          Shared<L>& sh, float& avx, float& avy, float& apx, float& apy,
+                                          float& aw, BallOverride& bo) {
+    using K = KC<KIND>;
+    constexpr int G = 64 / L;
+    constexpr uint32_t T_RR = __builtin_bit_cast(uint32_t, K::rs_rr2) - 1u;
+    int fl = 0;   // what this robot does to the ball in this sweep (0 = nothing)
+    bool touched = false;
+    if (is_robot) {
+        unsigned todo = 0;
+        if (NRX) {
+            float4 oth[NRX ? NRX : 1];  // all reads in flight together, one wait
+#pragma unroll
+            for (int j = 0; j < NRX; ++j) oth[j] = sh.A[j * G + g];
+            uint32_t u[NRX ? NRX : 1];   // exact integer form of 0 < d2 < rs_rr^2, see the VSS sweep
+#pragma unroll
+            for (int j = 0; j < NRX; ++j) {
+                float dx = oth[j].x - o.x, dy = oth[j].y - o.y;
+                u[j] = __float_as_uint(fma_(dx, dx, dy * dy)) - 1u;
+            }
+            uint32_t um = u[0];
+#pragma unroll
+            for (int j = 1; j < NRX; ++j) um = min(um, u[j]);
+            if (RSX_RARE_B(KIND, 2, um < T_RR)) {
+#pragma unroll
+                for (int j = 0; j < NRX; ++j) todo |= u[j] < T_RR ? 1u << j : 0u;
+            }
+        } else {
+#pragma unroll 4
+            for (int j = 0; j < N; ++j) {
+                const float4 oj = sh.A[j * G + g];
+                const float dx = oj.x - o.x, dy = oj.y - o.y;
+                todo |= (__float_as_uint(fma_(dx, dx, dy * dy)) - 1u) < T_RR ? 1u << j : 0u;
+            }
+        }
+        if (RSX_RARE_B(KIND, 2, todo != 0)) {   // per-lane partner walk, see the VSS sweep
+            touched = true;
+            while (todo) {
+                const int j = __builtin_ctz(todo);
+                todo &= todo - 1;
+                const float4 oj = sh.A[j * G + g];
+                const float wj = sh.W[j * G + g];
+                const float dx = oj.x - o.x, dy = oj.y - o.y;
+                contact_response(o, oj, fma_(dx, dx, dy * dy), K::rs_rr, K::ope_rr, K::w_rr, K::kt_rr, K::mu_rr, 0.0f,
+                                 fma_(wj, K::r_robot, o.om * K::r_robot), K::beta, avx, avy, apx, apy, aw);
+            }
+        }
+        // robot - ball: kicker mouth (flat face at dck) or body circle; n points robot -> ball
+        const float4 ob = sh.A[N * G + g];
+        float dx = ob.x - o.x, dy = ob.y - o.y;
+        float nx = 0.0f, ny = 0.0f, pen = -1.0f;
+        bool mouth = false, touch = false;
+        if (ball_low) {
+            float lx = fma_(dx, o.c, dy * o.s), ly = fma_(dy, o.c, -(dx * o.s));
+            if (fabsf(ly) < K::half_kw && lx > 0.0f) {
+                mouth = true; pen = K::dck_rb - lx; nx = o.c; ny = o.s; touch = pen > 0.0f;
+            } else {
+                float d2 = fma_(dx, dx, dy * dy);
+                if (d2 < K::rs_rb2 && d2 > 0.0f) {
+                    float d = sqrtf(d2), inv = 1.0f / d;
+                    nx = dx * inv; ny = dy * inv; pen = K::rs_rb - d; touch = true;
+                }
+            }
+        }
+        float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float dws = 0.0f;
+        if (touch) {
+            touched = true;
+            const float dvx = ob.z - o.vx, dvy = ob.w - o.vy;
+            float vn = fma_(dvx, nx, dvy * ny);
+            if (vn < 0.0f) {
+                const float omb = sh.W[N * G + g];
+                float q = K::ope_rb * vn * K::w_rb_r; avx = fma_(q, nx, avx); avy = fma_(q, ny, avy);
+                const float wsum = fma_(omb, K::r_ball, o.om * (mouth ? K::dck : K::r_robot));
+                const float vt = fma_(dvy, nx, -(dvx * ny)) - wsum;
+                const float lim = q * K::mu_rb;
+                const float ft = clampf(vt * K::kt_rb_r, lim, -lim);
+                avx = fma_(-ft, ny, avx); avy = fma_(ft, nx, avy);
+                // the ball's side of the same contact
+                float qb = K::ope_rb * vn * K::w_rb_b;
+                const float limb = qb * K::mu_rb;
+                const float ftb = clampf(vt * K::kt_rb_b, limb, -limb);
+                r0.x = fma_(-ftb, ny, qb * nx); r0.y = fma_(ftb, nx, qb * ny); dws = ftb * K::spin_c; fl |= 1;
+            }
+            float pc = K::beta * pen * K::w_rb_r;
+            apx = fma_(-pc, nx, apx); apy = fma_(-pc, ny, apy);
+            float pb = K::beta * pen * K::w_rb_b; r0.z = pb * nx; r0.w = pb * ny; fl |= 2;
+        }
+        if (FIRST) {
+            o.ir = mouth && pen > -K::ir_tol;
+            if (o.ir) {  // infrared: kicker / dribbler act on the ball
+                if (o.kick_x > 0.0f || o.kick_z > 0.0f) {
+                    fl |= 4 | 8;
+                    r1.y = o.vx + o.kick_x * o.c; r1.z = o.vy + o.kick_x * o.s; r1.w = o.kick_z;
+                } else if (o.drib) {
+                    float hx = o.x + K::dck_rb * o.c, hy = o.y + K::dck_rb * o.s;
+                    float cvx = (hx - ob.x) * P.drib_gain, cvy = (hy - ob.y) * P.drib_gain;
+                    float m2 = cvx * cvx + cvy * cvy;
+                    if (m2 > K::drib_vmax2) { float sc = K::drib_vmax / sqrtf(m2); cvx = cvx * sc; cvy = cvy * sc; }
+                    fl |= 4;
+                    r1.y = (o.vx - o.om * K::dck_rb * o.s) + cvx;
+                    r1.z = (o.vy + o.om * K::dck_rb * o.c) + cvy;
+                }
+            }
+        }
+        r1.x = __int_as_float(fl);
+        if (fl) { sh.Bq[lane] = r0; sh.Cq[lane] = r1; sh.Dq[lane] = dws; }
+    }
+    // which robots wrote a record: one ballot; the ball lane visits only those, in index order
+    // (usually none: no LDS read at all on the ball's side)
+    const unsigned long long wrote = __ballot(fl != 0);
+    wave_sync();
+    if (is_ball) {
+        unsigned long long todo = L <= 32 ? (env_lane_mask<L>(g) & wrote) : wrote;
+        while (todo) {
+            const int lj = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const float4 r1 = sh.Cq[lj];
+            const float4 r0 = sh.Bq[lj];
+            const int flj = __float_as_int(r1.x);
+            if (flj & 1) { avx = avx - r0.x; avy = avy - r0.y; aw = aw + sh.Dq[lj]; }
+            if (flj & 2) { apx = apx + r0.z; apy = apy + r0.w; }
+            if (FIRST && (flj & 4)) { bo.ovr = true; bo.okick = (flj & 8) != 0; bo.ovx = r1.y; bo.ovy = r1.z; bo.ovz = r1.w; }
+        }
+    }
+    return touched;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -212,7 +446,8 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
 
     // rolling resistance: a constant deceleration, applied once for the whole step() while the
     // ball is on the ground (exact stop, never reverses) — keeps the sqrt + divide chain out of
-    // the sub-step loop, where the ball lane's branch is serialised with the robots' work
+    // the sub-step loop, where the ball lane's branch is serialised with the robots' work.
+    // Same place: the spin about the vertical axis decays at a constant rate to an exact stop.
     if (is_ball && P.n_sub && !(o.z > 0.0f || o.vz > 0.0f)) {
         float sp2 = fma_(o.vx, o.vx, o.vy * o.vy);
         if (sp2 > 0.0f) {
@@ -221,6 +456,8 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
             float k = ns / sp;
             o.vx = o.vx * k; o.vy = o.vy * k;
         }
+        const float aw = fabsf(o.om) - P.spin_dec_dt;
+        o.om = aw > 0.0f ? (o.om < 0.0f ? -aw : aw) : 0.0f;
     }
 
     for (int sub = 0; sub < P.n_sub; ++sub) {
@@ -261,12 +498,16 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
             o.y = fma_(o.vy, P.h, o.y);
         }
 
-        // ---- B: contacts, Jacobi over the post-integration snapshot ----
+        // ---- B: contacts — one Jacobi sweep over the post-integration snapshot, and a second one
+        // over the corrected snapshot for the envs in which anything touched (crowded scenes) ----
         sh.A[lane] = make_float4(o.x, o.y, o.vx, o.vy);
+        sh.W[lane] = o.om;   // yaw rate / spin: read on the contact path only
         if (is_ball) sh.zb[g] = o.z;
         wave_sync();
         const bool ball_low = sh.zb[g] < K::robot_h;
-        float avx = 0.0f, avy = 0.0f, apx = 0.0f, apy = 0.0f;
+        float avx = 0.0f, avy = 0.0f, apx = 0.0f, apy = 0.0f, aw = 0.0f;
+        bool touched = false;
+        BallOverride bo{false, false, 0.0f, 0.0f, 0.0f};
 
         if (KIND == RSX_KIND_VSS) {
             // every pair is circle-circle; only the constants depend on the pair type
@@ -301,194 +542,85 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                         // response, rarely two) instead of one response block per distinct partner
                         // index present anywhere in the wave.  The wave that finishes last sets a
                         // single-step launch's duration, and it is always one with contacts.
+                        touched = true;
                         unsigned todo = 0;
 #pragma unroll
                         for (int j = 0; j <= NR; ++j) {
                             const bool rb = is_ball || j == NR;
                             todo |= ((u[j] < (rb ? T_RB : T_RR)) & (!rb | ball_low)) ? 1u << j : 0u;
                         }
+                        const float lever = is_ball ? K::r_ball : K::r_robot;
                         // software-pipelined: the next partner's slot is fetched while the current
                         // response is being computed
                         int jn = __builtin_ctz(todo);
                         todo &= todo - 1;
                         float4 nxt = sh.A[jn * G + g];
+                        float nxw = sh.W[jn * G + g];
                         for (;;) {
                             const int j = jn;
                             const float4 oj = nxt;
+                            const float wj = nxw;
                             const bool more = todo != 0;
                             if (more) {
                                 jn = __builtin_ctz(todo);
                                 todo &= todo - 1;
                                 nxt = sh.A[jn * G + g];
+                                nxw = sh.W[jn * G + g];
                             }
                             const float dx = oj.x - o.x, dy = oj.y - o.y;
                             const float d2 = fma_(dx, dx, dy * dy);   // the value the sweep above saw
                             const bool rb = is_ball || j == NR;
                             contact_response(o, oj, d2, rb ? K::rs_rb : K::rs_rr, rb ? K::ope_rb : K::ope_rr,
-                                             is_ball ? K::w_rb_b : (j == NR ? K::w_rb_r : K::w_rr), K::beta,
-                                             avx, avy, apx, apy);
+                                             is_ball ? K::w_rb_b : (j == NR ? K::w_rb_r : K::w_rr),
+                                             is_ball ? K::kt_rb_b : (j == NR ? K::kt_rb_r : K::kt_rr),
+                                             rb ? K::mu_rb : K::mu_rr, is_ball ? K::spin_c : 0.0f,
+                                             fma_(wj, j == NR ? K::r_ball : K::r_robot, o.om * lever), K::beta,
+                                             avx, avy, apx, apy, aw);
                             if (!more) break;
                         }
                     }
                 } else {
-                    // run-time robot count: same two phases (exact integer overlap test into a bit per
-                    // partner, then the per-lane partner walk), the loops just are not unrolled
-                    constexpr uint32_t T_RR = __builtin_bit_cast(uint32_t, K::rs_rr2) - 1u;
-                    constexpr uint32_t T_RB = __builtin_bit_cast(uint32_t, K::rs_rb2) - 1u;
-                    unsigned todo = 0;
-#pragma unroll 4
-                    for (int j = 0; j <= N; ++j) {
-                        const float4 oj = sh.A[j * G + g];
-                        const bool rb = is_ball || j == N;
-                        const float dx = oj.x - o.x, dy = oj.y - o.y;
-                        const uint32_t u = __float_as_uint(fma_(dx, dx, dy * dy)) - 1u;   // own slot: 0xFFFFFFFF
-                        todo |= ((u < (rb ? T_RB : T_RR)) & (!rb | ball_low)) ? 1u << j : 0u;
-                    }
-                    while (todo) {
-                        const int j = __builtin_ctz(todo);
-                        todo &= todo - 1;
-                        const float4 oj = sh.A[j * G + g];
-                        const float dx = oj.x - o.x, dy = oj.y - o.y;
-                        const bool rb = is_ball || j == N;
-                        contact_response(o, oj, fma_(dx, dx, dy * dy), rb ? K::rs_rb : K::rs_rr, rb ? K::ope_rb : K::ope_rr,
-                                         is_ball ? K::w_rb_b : (j == N ? K::w_rb_r : K::w_rr), K::beta,
-                                         avx, avy, apx, apy);
-                    }
+                    touched = vss_sweep_loop<KIND, L>(o, N, g, is_ball, ball_low, sh, avx, avy, apx, apy, aw);
                 }
             }
-            o.vx = o.vx + avx; o.vy = o.vy + avy;
-            o.x = o.x + apx; o.y = o.y + apy;
         } else {
-            bool ovr = false, okick = false;
-            float ovx = 0.0f, ovy = 0.0f, ovz = 0.0f;
-            int fl = 0;   // what this robot does to the ball in this sub-step (0 = nothing)
-            if (is_robot) {
-                if (NR) {
-                    float4 oth[NR ? NR : 1];  // all reads in flight together, one wait
-#pragma unroll
-                    for (int j = 0; j < NR; ++j) oth[j] = sh.A[j * G + g];
-                    // exact integer form of 0 < d2 < rs_rr^2, see the VSS sweep
-                    constexpr uint32_t T_RR = __builtin_bit_cast(uint32_t, K::rs_rr2) - 1u;
-                    uint32_t u[NR ? NR : 1];
-#pragma unroll
-                    for (int j = 0; j < NR; ++j) {
-                        float dx = oth[j].x - o.x, dy = oth[j].y - o.y;
-                        u[j] = __float_as_uint(fma_(dx, dx, dy * dy)) - 1u;
-                    }
-                    uint32_t um = u[0];
-#pragma unroll
-                    for (int j = 1; j < NR; ++j) um = min(um, u[j]);
-                    if (RSX_RARE_B(KIND, 2, um < T_RR)) {   // per-lane partner walk, see the VSS sweep
-                        unsigned todo = 0;
-#pragma unroll
-                        for (int j = 0; j < NR; ++j) todo |= u[j] < T_RR ? 1u << j : 0u;
-                        while (todo) {
-                            const int j = __builtin_ctz(todo);
-                            todo &= todo - 1;
-                            const float4 oj = sh.A[j * G + g];
-                            const float dx = oj.x - o.x, dy = oj.y - o.y;
-                            contact_response(o, oj, fma_(dx, dx, dy * dy), K::rs_rr, K::ope_rr, K::w_rr, K::beta, avx, avy, apx, apy);
-                        }
-                    }
-                } else {
-                    constexpr uint32_t T_RR = __builtin_bit_cast(uint32_t, K::rs_rr2) - 1u;
-                    unsigned todo = 0;
-#pragma unroll 4
-                    for (int j = 0; j < N; ++j) {
-                        const float4 oj = sh.A[j * G + g];
-                        const float dx = oj.x - o.x, dy = oj.y - o.y;
-                        todo |= (__float_as_uint(fma_(dx, dx, dy * dy)) - 1u) < T_RR ? 1u << j : 0u;
-                    }
-                    while (todo) {
-                        const int j = __builtin_ctz(todo);
-                        todo &= todo - 1;
-                        const float4 oj = sh.A[j * G + g];
-                        const float dx = oj.x - o.x, dy = oj.y - o.y;
-                        contact_response(o, oj, fma_(dx, dx, dy * dy), K::rs_rr, K::ope_rr, K::w_rr, K::beta, avx, avy, apx, apy);
-                    }
-                }
-                // robot - ball: kicker mouth (flat face at dck) or body circle; n points robot -> ball
-                const float4 ob = sh.A[N * G + g];
-                float dx = ob.x - o.x, dy = ob.y - o.y;
-                float nx = 0.0f, ny = 0.0f, pen = -1.0f;
-                bool mouth = false, touch = false;
-                if (ball_low) {
-                    float lx = fma_(dx, o.c, dy * o.s), ly = fma_(dy, o.c, -(dx * o.s));
-                    if (fabsf(ly) < K::half_kw && lx > 0.0f) {
-                        mouth = true; pen = K::dck_rb - lx; nx = o.c; ny = o.s; touch = pen > 0.0f;
-                    } else {
-                        float d2 = fma_(dx, dx, dy * dy);
-                        if (d2 < K::rs_rb2 && d2 > 0.0f) {
-                            float d = sqrtf(d2), inv = 1.0f / d;
-                            nx = dx * inv; ny = dy * inv; pen = K::rs_rb - d; touch = true;
-                        }
-                    }
-                }
-                float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (touch) {
-                    float vn = fma_(ob.z - o.vx, nx, (ob.w - o.vy) * ny);
-                    if (vn < 0.0f) {
-                        float q = K::ope_rb * vn * K::w_rb_r; avx = fma_(q, nx, avx); avy = fma_(q, ny, avy);
-                        float qb = K::ope_rb * vn * K::w_rb_b; r0.x = qb * nx; r0.y = qb * ny; fl |= 1;
-                    }
-                    float pc = K::beta * pen * K::w_rb_r;
-                    apx = fma_(-pc, nx, apx); apy = fma_(-pc, ny, apy);
-                    float pb = K::beta * pen * K::w_rb_b; r0.z = pb * nx; r0.w = pb * ny; fl |= 2;
-                }
-                o.ir = mouth && pen > -K::ir_tol;
-                if (o.ir) {  // infrared: kicker / dribbler act on the ball
-                    if (o.kick_x > 0.0f || o.kick_z > 0.0f) {
-                        fl |= 4 | 8;
-                        r1.y = o.vx + o.kick_x * o.c; r1.z = o.vy + o.kick_x * o.s; r1.w = o.kick_z;
-                    } else if (o.drib) {
-                        float hx = o.x + K::dck_rb * o.c, hy = o.y + K::dck_rb * o.s;
-                        float cvx = (hx - ob.x) * P.drib_gain, cvy = (hy - ob.y) * P.drib_gain;
-                        float m2 = cvx * cvx + cvy * cvy;
-                        if (m2 > K::drib_vmax2) { float sc = K::drib_vmax / sqrtf(m2); cvx = cvx * sc; cvy = cvy * sc; }
-                        fl |= 4;
-                        r1.y = (o.vx - o.om * K::dck_rb * o.s) + cvx;
-                        r1.z = (o.vy + o.om * K::dck_rb * o.c) + cvy;
-                    }
-                }
-                r1.x = __int_as_float(fl);
-                if (fl) { sh.Bq[lane] = r0; sh.Cq[lane] = r1; }
-            }
-            // which robots wrote a record: one ballot; the ball lane visits only those, in index
-            // order (usually none: no LDS read at all on the ball's side)
-            const unsigned long long wrote = __ballot(fl != 0);
+            touched = ssl_sweep<KIND, L, NR, true>(P, o, N, g, lane, is_robot, is_ball, ball_low, sh, avx, avy, apx, apy, aw, bo);
+        }
+        o.vx = o.vx + avx; o.vy = o.vy + avy;
+        o.x = o.x + apx; o.y = o.y + apy;
+        if (is_ball) o.om = o.om + aw;
+
+        // second sweep, for the envs in which something touched (one ballot; usually no lane)
+        const unsigned long long tmask = __ballot(touched);
+        if (RSX_RARE_B(KIND, 2, tmask != 0)) {
+            const bool again = (L == 64 ? tmask : (tmask & env_lane_mask<L>(g))) != 0;
+            wave_sync();   // every lane has read the first snapshot
+            if (again) { sh.A[lane] = make_float4(o.x, o.y, o.vx, o.vy); sh.W[lane] = o.om; }
             wave_sync();
-            if (is_ball) {
-                unsigned long long todo = 0;   // lanes j * G + g, j < N
-                if (L <= 32) {
-#pragma unroll
-                    for (int j = 0; j < L; ++j) todo |= 1ull << (j * G);
-                    todo = (todo << g) & wrote;
-                } else {
-                    todo = wrote;   // one env per wave
-                }
-                while (todo) {
-                    const int lj = __builtin_ctzll(todo);
-                    todo &= todo - 1;
-                    const float4 r1 = sh.Cq[lj];
-                    const float4 r0 = sh.Bq[lj];
-                    const int flj = __float_as_int(r1.x);
-                    if (flj & 1) { avx = avx - r0.x; avy = avy - r0.y; }
-                    if (flj & 2) { apx = apx + r0.z; apy = apy + r0.w; }
-                    if (flj & 4) { ovr = true; okick = (flj & 8) != 0; ovx = r1.y; ovy = r1.z; ovz = r1.w; }
-                }
+            avx = 0.0f; avy = 0.0f; apx = 0.0f; apy = 0.0f; aw = 0.0f;
+            if (KIND == RSX_KIND_VSS) {
+                if (again && (is_robot || is_ball)) vss_sweep_loop<KIND, L>(o, N, g, is_ball, ball_low, sh, avx, avy, apx, apy, aw);
+            } else {
+                BallOverride unused{false, false, 0.0f, 0.0f, 0.0f};
+                ssl_sweep<KIND, L, 0, false>(P, o, N, g, lane, is_robot && again, is_ball && again, ball_low, sh, avx, avy, apx, apy, aw, unused);
             }
             o.vx = o.vx + avx; o.vy = o.vy + avy;
             o.x = o.x + apx; o.y = o.y + apy;
-            if (ovr) {
-                o.vx = ovx; o.vy = ovy;
-                if (okick && ovz > 0.0f) o.vz = ovz;
-            }
+            if (is_ball) o.om = o.om + aw;
+        }
+        if (KIND == RSX_KIND_SSL && bo.ovr) {   // kicker / dribbler: decided in the first sweep, applied after the impulses
+            o.vx = bo.ovx; o.vy = bo.ovy; o.om = 0.0f;
+            if (bo.okick && bo.ovz > 0.0f) o.vz = bo.ovz;
         }
 
         // ---- C: walls ----
-        if (is_robot || is_ball)
-            walls<KIND>(P, is_ball ? K::r_ball : K::r_robot, is_ball ? K::e_wb : K::e_wr, o.x, o.y, o.vx, o.vy);
-        wave_sync();  // A / Bq / Cq are rewritten by the next sub-step
+        if (is_robot || is_ball) {
+            const float vx0 = o.vx, vy0 = o.vy;
+            int hit = 0;
+            walls<KIND>(P, is_ball ? K::r_ball : K::r_robot, is_ball ? K::e_wb : K::e_wr, o.x, o.y, o.vx, o.vy, hit);
+            if (RSX_RARE_B(KIND, 2, is_ball && hit)) ball_wall_spin<KIND>(hit, vx0, vy0, o.vx, o.vy, o.om);
+        }
+        wave_sync();  // A / W / Bq / Cq / Dq are rewritten by the next sub-step
 #ifdef RSX_TIMING
         if (threadIdx.x == 0 && sh.dbg) sh.dbg[(size_t)(8 + sub) * gridDim.x + blockIdx.x] = __builtin_readcyclecounter();
 #endif
@@ -502,7 +634,7 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
 // the row index differs: ball rows 0..4 + the vz row, robot rows 5+RS*b .. +5), so all loads of a
 // wave are in flight together; nothing is computed here (a use would park the wave on vmcnt
 // between the two roles' loads).
-struct RawBody { float v0, v1, v2, v3, v4, v5, ir, w[4]; };
+struct RawBody { float v0, v1, v2, v3, v4, v5, ir /* ball: spin */, w[4]; };
 
 template <int KIND>
 __device__ __forceinline__ RawBody load_raw(const Params& P, const float* __restrict__ st, int e,
@@ -517,11 +649,15 @@ __device__ __forceinline__ RawBody load_raw(const Params& P, const float* __rest
         r.v0 = p[0]; r.v1 = p[B]; r.v2 = p[2 * B]; r.v3 = p[3 * B]; r.v4 = p[4 * B];
         r.v5 = st[(size_t)row5 * B + e];
     }
-    if (KIND == RSX_KIND_SSL && is_robot) {
-        const float* p = st + (size_t)(5 + RS * b + 6) * B + e;
-        r.ir = p[0];
+    if (KIND == RSX_KIND_SSL) {   // robots: infrared flag; ball: spin row (same load instruction)
+        if (is_robot || is_ball) r.ir = st[(size_t)(is_ball ? P.state_dim + 1 : 5 + RS * b + 6) * B + e];
+        if (is_robot) {
+            const float* p = st + (size_t)(5 + RS * b + 7) * B + e;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r.w[i] = p[(1 + i) * B];
+            for (int i = 0; i < 4; ++i) r.w[i] = p[i * B];
+        }
+    } else if (is_ball) {
+        r.ir = st[(size_t)(P.state_dim + 1) * B + e];
     }
     return r;
 }
@@ -548,6 +684,7 @@ __device__ __forceinline__ void interpret_body(const RawBody& r, bool is_robot, 
     } else if (is_ball) {
         o.z = r.v2 - K::r_ball;
         o.vz = r.v5;
+        o.om = r.ir;   // spin about the vertical axis, rad/s
     }
 }
 
@@ -578,6 +715,7 @@ __device__ __forceinline__ void store_body(const Params& P, float* __restrict__ 
         p[0] = o.x; p[B] = o.y; p[2 * B] = is_ball ? K::r_ball + o.z : th_deg; p[3 * B] = o.vx; p[4 * B] = o.vy;
         st[(size_t)row5 * B + e] = is_ball ? o.vz : om_deg;
     }
+    if (is_ball) st[(size_t)(P.state_dim + 1) * B + e] = o.om;
     if (KIND == RSX_KIND_SSL && is_robot) {
         float* p = st + (size_t)(5 + RS * b + 6) * B + e;
         if (write_ir) p[0] = o.ir ? 1.0f : 0.0f;

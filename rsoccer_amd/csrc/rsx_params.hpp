@@ -22,6 +22,8 @@
 namespace rsx {
 
 constexpr int MAX_ROBOTS = 22;
+// internal state rows behind the get_state() rows: ball vertical velocity, ball spin (rad/s)
+constexpr int X_ROWS = 2;
 constexpr double PI_D = 3.14159265358979323846;
 
 // ---------------------------------------------------------------------------------------------
@@ -40,6 +42,7 @@ template <> struct ModelD<RSX_KIND_VSS> {
     static constexpr double m_robot = 0.18, m_ball = 0.046;          // [build]
     static constexpr double a_lin = 8.0, a_lat = 20.0, a_ang = 300.0, mu_g = 0.3;  // [build]
     static constexpr double e_rr = 0.1, e_rb = 0.3, e_wb = 0.6, e_wr = 0.1;        // [build]
+    static constexpr double mu_rr = 0.2, mu_rb = 0.35, mu_wb = 0.3, spin_dec = 30.0;  // [build] Coulomb friction in contacts, spin deceleration (rad/s^2)
     static constexpr double margin = 0.0;
     static constexpr int rs = 6, cmd_dim = 2;     // Entities/Frame.py:27, rsim.py:93
 };
@@ -55,6 +58,7 @@ template <> struct ModelD<RSX_KIND_SSL> {
     static constexpr double m_robot = 2.2, m_ball = 0.046;
     static constexpr double a_lin = 5.0, a_lat = 0.0, a_ang = 50.0, mu_g = 0.4;
     static constexpr double e_rr = 0.1, e_rb = 0.2, e_wb = 0.5, e_wr = 0.1;
+    static constexpr double mu_rr = 0.2, mu_rb = 0.35, mu_wb = 0.3, spin_dec = 30.0;
     static constexpr double margin = 0.3;
     static constexpr int rs = 11, cmd_dim = 8;    // Entities/Frame.py:62, rsim.py:130
 };
@@ -86,6 +90,15 @@ struct KC {
     static constexpr float half_kw = (float)(D::kick_w / 2), ir_tol = 0.025f;
     static constexpr float drib_vmax = 1.0f, drib_vmax2 = 1.0f;
     static constexpr float deg2rad = (float)(PI_D / 180.0), rad2deg = (float)(180.0 / PI_D);
+    // Coulomb friction in contacts.  Tangential effective mass: robots are yaw-controlled by their
+    // motors (no torque from contacts), the ball is a solid sphere (I = 2/5 m r^2: the contact point
+    // adds r^2 / I = 2.5 / m), so 1/m_t = 1/m_r + 3.5/m_b (robot-ball), 2/m_r (robot-robot),
+    // 3.5/m_b (wall-ball).  kt_* = m_t / m_body, spin_c = spin per unit of tangential velocity change.
+    static constexpr double mt_rb = 1.0 / (imr + 3.5 * imb);
+    static constexpr float mu_rr = (float)D::mu_rr, mu_rb = (float)D::mu_rb, mu_wb = (float)D::mu_wb;
+    static constexpr float kt_rr = 0.5f, kt_rb_r = (float)(mt_rb * imr), kt_rb_b = (float)(mt_rb * imb);
+    static constexpr float kw = (float)(2.0 / 7.0), spin_c = (float)(2.5 / D::r_ball);
+    static constexpr float ope_wb = (float)(1.0 + D::e_wb), dck = (float)D::dck;
 };
 
 // per-task literals
@@ -134,7 +147,7 @@ template <> struct TC<RSX_TASK_SSL_PASS_ENDURANCE> : TCSslBase {
 struct Params {
     int kind, n_blue, n_yellow, n_robots, n_sub, state_dim, num_envs;
     // sub-step and field dependent
-    float h, h_deg, a_lin_h, a_lin_h2, a_lat_h, a_ang_h, mu_g_dt, g_h, drib_gain;
+    float h, h_deg, a_lin_h, a_lin_h2, a_lat_h, a_ang_h, mu_g_dt, g_h, drib_gain, spin_dec_dt;
     float half_len, half_wid, ghw, gd;
     // omni-wheel kinematics (SSL; used once per step)
     float ws[4], wc[4], pinv[3][4];
@@ -183,6 +196,7 @@ inline int derive_model_k(int field_type, int ts_ms, Params& P, HostModel& M) {
     P.a_lin_h = (float)(D::a_lin * h); P.a_lin_h2 = (float)((D::a_lin * h) * (D::a_lin * h));
     P.a_lat_h = (float)(D::a_lat * h); P.a_ang_h = (float)(D::a_ang * h);
     P.mu_g_dt = (float)(D::mu_g * (ts_ms * 0.001)); P.g_h = (float)(GRAV_D * h);
+    P.spin_dec_dt = (float)(D::spin_dec * (ts_ms * 0.001));
     P.drib_gain = (float)(h > 0 ? 0.5 / h : 0.0);
     P.half_len = (float)(f[0] / 2); P.half_wid = (float)(f[1] / 2);
     P.ghw = (float)(f[4] / 2); P.gd = (float)f[5];

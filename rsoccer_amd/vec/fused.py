@@ -136,7 +136,7 @@ class VecFusedEnv:
 
     @property
     def state(self):
-        """[state_dim + 1, num_envs] float32 view of the SoA simulator state."""
+        """[state_dim + 2, num_envs] float32 view of the SoA simulator state."""
         return self.sim.state_tensor()
 
     def close(self):

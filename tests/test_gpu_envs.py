@@ -83,7 +83,7 @@ def test_fused_observation_matches_reference_arithmetic():
         B = len(states)
         sim = L.Sim(kind, ft, nb, ny, 25, B)
         sim.task_attach(task, 0, 0, 0)
-        sim.set_state(np.concatenate([states, np.zeros((B, 1))], 1))
+        sim.set_state(np.concatenate([states, np.zeros((B, 2))], 1))
         dummy = (np.zeros((B, 4)), np.zeros((B, nb, 3)), np.zeros((B, ny, 3)))
         sim.task_reset_to(*dummy, env_mask=np.zeros(B, dtype=np.uint8))   # nothing teleported: obs refresh only
         torch.cuda.synchronize()

@@ -135,7 +135,7 @@ def test_seeded_placement(vss_env, sd_env):
 def test_observations(vss_env, sd_env):
     for env, key in ((vss_env, "vss"), (sd_env, "sd")):
         for s, want in zip(G[f"{key}_obs_states"], G[f"{key}_obs"]):
-            env.rsim.simulator.o.set_state_full(np.append(s, 0.0))
+            env.rsim.simulator.o.set_state_full(np.append(s, [0.0, 0.0]))
             env.frame = env.rsim.get_frame()
             got = env._frame_to_observations()
             assert got.dtype == np.float32 and np.array_equal(got, want)
@@ -264,7 +264,7 @@ def test_other_ssl_tasks_replay_reference_exactly(tag, oracle_mod):
     assert np.allclose([env.max_pos, env.max_v, env.max_w], G[f"{tag}_norms"], rtol=1e-15)
     # observations of arbitrary states
     for i, (s, want) in enumerate(zip(G[f"{tag}_obs_states"], G[f"{tag}_obs"])):
-        env.rsim.simulator.o.set_state_full(np.append(s, 0.0))
+        env.rsim.simulator.o.set_state_full(np.append(s, [0.0, 0.0]))
         env.frame = env.rsim.get_frame()
         if hasattr(env, "checkpoints_count"):
             env.checkpoints_count = i % 7

@@ -38,7 +38,7 @@ def test_normalisers(oracle_mod, prec, otol, stol):
 def test_observations(oracle_mod, prec, otol, stol, task, key):
     e = _env(oracle_mod, task, prec)
     for s, want in zip(G[f"{key}_obs_states"], G[f"{key}_obs"]):
-        e.set_state_full(np.append(s, 0.0))
+        e.set_state_full(np.append(s, [0.0, 0.0]))
         got = e.obs_eval()
         assert got.shape == want.shape
         assert np.max(np.abs(got - want)) <= otol
@@ -88,11 +88,11 @@ def test_reward_done_info_over_episodes(oracle_mod, prec, otol, stol, task, pref
     seen_done = 0
     for i, ep in _episodes(prefix):
         e = _env(oracle_mod, task, prec)
-        e.set_state_full(np.append(ep["reset_state"], 0.0))
+        e.set_state_full(np.append(ep["reset_state"], [0.0, 0.0]))
         assert np.max(np.abs(e.obs_eval() - ep["obs0"])) <= otol
         last = ep["reset_state"]
         for t in range(len(ep["reward"])):
-            e.set_state_full(np.append(ep["states"][t], 0.0))
+            e.set_state_full(np.append(ep["states"][t], [0.0, 0.0]))
             assert np.max(np.abs(e.obs_eval() - ep["obs"][t])) <= otol, (i, t)
             r, d = e.reward_eval(last, ep["cmds"][t], t == 0)
             assert d == bool(ep["done"][t]), (i, t)
@@ -127,7 +127,7 @@ def test_physics_regression_against_recorded_oracle_runs(oracle_mod, task, prefi
     model against silent changes — a deliberate model change must regenerate the fixtures."""
     for i, ep in _episodes(prefix):
         e = oracle_mod.OracleEnv(*kind, 25, "f64")
-        e.set_state_full(np.append(ep["reset_state"], 0.0))
+        e.set_state_full(np.append(ep["reset_state"], [0.0, 0.0]))
         for t in range(len(ep["reward"]) - 1):  # the last state of scripted episodes is injected
             e.step(ep["cmds"][t])
             assert np.allclose(e.get_state(), ep["states"][t], rtol=0, atol=1e-12), (i, t)
@@ -199,7 +199,7 @@ def test_other_tasks_observations(oracle_mod, prec, otol, stol, tag):
     e = _other_env(oracle_mod, tag, prec)
     assert np.allclose(e.norms(), G[f"{tag}_norms"], rtol=1e-6)
     for i, (s, want) in enumerate(zip(G[f"{tag}_obs_states"], G[f"{tag}_obs"])):
-        e.set_state_full(np.append(s, 0.0))
+        e.set_state_full(np.append(s, [0.0, 0.0]))
         if tag == "drib":
             e.set_scalar(i % 7)
         got = e.obs_eval()
@@ -215,14 +215,14 @@ def test_other_tasks_episodes(oracle_mod, prec, otol, stol, tag):
     for ep in range(n_ep):
         e = _other_env(oracle_mod, tag, prec)
         R = {k: G[f"{tag}_ep{ep}_{k}"] for k in ("reset_state", "obs0", "actions", "cmds", "states", "obs", "reward", "done", "info")}
-        e.set_state_full(np.append(R["reset_state"], 0.0))
+        e.set_state_full(np.append(R["reset_state"], [0.0, 0.0]))
         e.set_scalar(0)
         assert np.max(np.abs(e.obs_eval() - R["obs0"])) <= otol
         last = R["reset_state"]
         for t in range(len(R["reward"])):
             cm = e.cmds_eval(R["actions"][t], last[7])
             assert np.allclose(cm, R["cmds"][t], rtol=0, atol=3e-6), (tag, ep, t, cm, R["cmds"][t])
-            e.set_state_full(np.append(R["states"][t], 0.0))
+            e.set_state_full(np.append(R["states"][t], [0.0, 0.0]))
             assert np.max(np.abs(e.obs_eval() - R["obs"][t])) <= otol, (tag, ep, t)
             r, d = e.reward_eval(last, R["cmds"][t], t == 0)
             assert d == bool(R["done"][t]), (tag, ep, t)

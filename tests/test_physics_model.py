@@ -314,3 +314,157 @@ def test_time_step_scales_motion(backend, oracle_mod):
         b.step(np.zeros((6, 2)))
     # rolling resistance is applied once per step(): the two discretisations agree to O(mu dt T)
     assert np.allclose(a.get_state(), b.get_state(), atol=1e-3)
+
+
+# ---- tangential friction, ball spin, second contact sweep ----
+def _full(s):
+    return s._sim.get_state_full()[0] if hasattr(s, "_sim") else s.o.get_state_full()
+
+
+def _set_full(s, v):
+    if hasattr(s, "_sim"):
+        s._sim.set_state(np.asarray(v, float)[None])
+    else:
+        s.o.set_state_full(np.asarray(v, float))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_turning_robot_drags_the_ball_sideways_and_spins_it(backend, oracle_mod):
+    """Coulomb friction at the contact point: a robot that hits the ball while turning drags it
+    along its surface and spins it; the mirrored command gives the mirrored result."""
+    out = {}
+    for name, (wl, wr) in {"ccw": (12.0, 40.0), "cw": (40.0, 12.0), "straight": (30.0, 30.0)}.items():
+        s = _vss(backend, [0.085, 0.0, 0, 0], [0.0, 0.0, 0.0])
+        for _ in range(8):
+            s.step(_cmd(6, 2, {0: [wl, wr]}))
+        f = _full(s)
+        out[name] = (f[1], f[4], f[-1])       # ball y, ball vy, ball spin
+        assert f[3] > 0.05                     # it was hit
+    y, vy, sp = out["ccw"]
+    assert y > 1e-4 and vy > 1e-3              # counter-clockwise robot: its front surface moves to +y
+    assert sp < -0.5                           # the ball spins the other way (gears)
+    ym, vym, spm = out["cw"]
+    assert abs(y + ym) < 1e-6 and abs(vy + vym) < 1e-5 and abs(sp + spm) < 1e-3
+    assert abs(out["straight"][0]) < 1e-7 and abs(out["straight"][2]) < 1e-6
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_ball_spin_couples_with_walls_and_decays(backend, oracle_mod):
+    f = _vss(backend, [0, 0, 0, 0], [-0.5, 0.3, 0.0]).get_field_params()
+    W = f["width"]
+    # oblique bounce off the +y touch line: friction takes tangential speed and turns it into spin
+    s = _vss(backend, [0.0, W / 2 - 0.06, 1.0, 1.0], [-0.5, -0.3, 0.0])
+    for _ in range(6):
+        s.step(_cmd(6, 2, {}))
+    st = _full(s)
+    assert st[4] < 0                                        # came back
+    assert 0.5 < st[3] < 0.9                                # lost tangential speed beyond rolling resistance (0.045 m/s)
+    assert st[-1] > 5.0                                     # and rolls along the wall: spin = counter-clockwise
+    ke_in = 1.0 ** 2 + 1.0 ** 2
+    assert st[3] ** 2 + st[4] ** 2 + 0.4 * (0.0215 * st[-1]) ** 2 < ke_in   # no energy from nowhere
+    # a spinning ball hitting the wall head-on is deflected along it
+    s = _vss(backend, [0.0, W / 2 - 0.06, 0.0, 1.0], [-0.5, -0.3, 0.0])
+    v = _full(s); v[-1] = 60.0; _set_full(s, v)
+    for _ in range(6):
+        s.step(_cmd(6, 2, {}))
+    st = _full(s)
+    assert st[4] < 0 and st[3] > 0.05 and st[-1] < 60.0
+    v = _full(s); v[-1] = -60.0; v[0:5] = [0.0, W / 2 - 0.06, 0.0215, 0.0, 1.0]; _set_full(s, v)
+    for _ in range(6):
+        s.step(_cmd(6, 2, {}))
+    assert _full(s)[3] < -0.05
+    # free spin decays at a constant rate to an exact stop
+    s = _vss(backend, [0, 0, 0, 0], [-0.5, 0.3, 0.0])
+    v = _full(s); v[-1] = 20.0; _set_full(s, v)
+    prev = 20.0
+    for t in range(40):
+        s.step(_cmd(6, 2, {}))
+        sp = _full(s)[-1]
+        assert 0.0 <= sp < prev or sp == prev == 0.0
+        prev = sp
+    assert prev == 0.0 and abs(_full(s)[0]) < 1e-9         # spin alone does not move the ball
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_oblique_hit_on_a_resting_robot_loses_tangential_speed(backend, oracle_mod):
+    """ball thrown past the edge of a parked SSL robot: the grazing contact reduces the speed
+    along the surface and leaves the ball spinning; the reflected normal speed obeys e_rb."""
+    s = _ssl(backend, [-0.5, 0.095, 2.0, 0.0], [0.0, 0.0, 180.0])   # kicker looks away: body-circle contact
+    for _ in range(14):
+        s.step(_cmd(1, 8, {}))
+    st = _full(s)
+    speed = math.hypot(st[3], st[4])
+    assert st[4] > 0.1                       # deflected to +y
+    assert speed < 1.7                       # 2.0 - rolling resistance (14 * 0.01) would be 1.86 without the contact
+    assert abs(st[-1]) > 1.0                 # spinning
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_crowded_pushing_keeps_penetration_small(backend, oracle_mod):
+    """22 SSL robots all driving at the field centre at 2 m/s (two Jacobi sweeps per sub-step when
+    anything touches): overlap of any pair stays below 5 mm (2.8 % of a diameter) after every step;
+    a ball squeezed against a wall by a VSS robot stays within 3 mm of touching."""
+    s = _make(backend, 1, 1, 11, 11)
+    rng = np.random.default_rng(0)
+    pts = [(0.19 * (i - 2.5) + rng.uniform(-.004, .004), 0.19 * (j - 2) + rng.uniform(-.004, .004))
+           for i in range(6) for j in range(4)][:22]
+    pose = np.array([[p[0], p[1], rng.uniform(-180, 180)] for p in pts])
+    s.reset(np.array([2.0, 2.0, 0, 0.0]), pose[:11], pose[11:])
+    worst = 0.0
+    for _ in range(60):
+        st = s.get_state()
+        cmds = np.zeros((22, 8))
+        for k in range(22):
+            x, y, th = st[5 + 11 * k], st[6 + 11 * k], math.radians(st[7 + 11 * k])
+            n = math.hypot(x, y) + 1e-9
+            gx, gy = -2.0 * x / n, -2.0 * y / n
+            cmds[k, 1] = gx * math.cos(th) + gy * math.sin(th)
+            cmds[k, 2] = -gx * math.sin(th) + gy * math.cos(th)
+        s.step(cmds)
+        st = s.get_state()
+        P = st[5:].reshape(22, 11)[:, :2]
+        D = np.hypot(*(P[:, None] - P[None]).transpose(2, 0, 1))
+        np.fill_diagonal(D, 9.0)
+        worst = max(worst, 0.18 - D.min())
+    assert 0.0 < worst < 0.005, worst
+    # VSS: robot pins the ball against the +x goal-line wall (outside the goal mouth)
+    f = _vss(backend, [0, 0, 0, 0], [-0.5, 0.3, 0.0]).get_field_params()
+    L = f["length"]
+    s = _vss(backend, [L / 2 - 0.03, 0.4, 0, 0], [L / 2 - 0.12, 0.4, 0.0])
+    for _ in range(40):
+        s.step(_cmd(6, 2, {0: [40.0, 40.0]}))
+        st = s.get_state()
+        assert math.hypot(st[0] - st[5], st[1] - st[6]) > 0.0375 + 0.0215 - 3e-3
+        assert st[0] <= L / 2 - 0.0215 + 1e-6
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_contacts_never_add_kinetic_energy(backend, oracle_mod):
+    """robots thrown at each other with the motors commanded to stop: every mechanism on the path
+    (restitution < 1, Coulomb friction, braking, positional de-penetration) is dissipative, so the
+    kinetic energy of the env never rises from one step to the next."""
+    s = _make(backend, 1, 1, 11, 11)
+    rng = np.random.default_rng(4)
+    pts = [(0.21 * (i - 2.5), 0.21 * (j - 2)) for i in range(6) for j in range(4)][:22]
+    pose = np.array([[p[0], p[1], rng.uniform(-180, 180)] for p in pts])
+    s.reset(np.array([0.0, 3.0, 0.5, -3.0]), pose[:11], pose[11:])
+    v = _full(s)
+    for k in range(22):
+        v[5 + 11 * k + 3: 5 + 11 * k + 5] = rng.uniform(-2.0, 2.0, 2)
+    _set_full(s, v)
+
+    def ke(st):
+        R = st[5:5 + 22 * 11].reshape(22, 11)
+        return 0.5 * 2.2 * (R[:, 3:5] ** 2).sum() + 0.5 * 0.046 * (st[3] ** 2 + st[4] ** 2 + 0.4 * (0.0215 * st[-1]) ** 2)
+    prev = ke(_full(s))
+    touched = False
+    for _ in range(50):
+        s.step(np.zeros((22, 8)))
+        st = _full(s)
+        P = st[5:5 + 22 * 11].reshape(22, 11)[:, :2]
+        D = np.hypot(*(P[:, None] - P[None]).transpose(2, 0, 1)); np.fill_diagonal(D, 9.0)
+        touched |= D.min() < 0.1805
+        cur = ke(st)
+        assert cur <= prev * (1 + 1e-6) + 1e-9, (cur, prev)
+        prev = cur
+    assert touched and prev < 0.02          # only the ball still rolls
