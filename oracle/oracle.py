@@ -202,11 +202,12 @@ class OracleEnv:
         return out
 
 
-def philox(ctr, key):
+def philox(ctr, key, rounds=10):
+    """Philox4x32 with the published 10 rounds (known-answer vectors) or the engine's 7."""
     c = (C.c_uint32 * 4)(*ctr)
     k = (C.c_uint32 * 2)(*key)
     o = (C.c_uint32 * 4)()
-    lib().rsxo_philox4x32_10(c, k, o)
+    lib().rsxo_philox4x32(c, k, int(rounds), o)
     return list(o)
 
 

@@ -53,6 +53,7 @@ typedef struct rsxo_cfg {
     double grav, e_ground, vz_min, robot_h;
     double dck, half_kw, ir_tol, drib_vmax;
     double mu_rr, mu_rb, mu_wb, spin_dec;   /* Coulomb friction in contacts, spin deceleration (rad/s^2) */
+    double pen2;                            /* overlap beyond which an env gets the second contact sweep */
     double wheel_ang[4];
     double pinv[3][4];
 } rsxo_cfg;
@@ -115,6 +116,8 @@ static int rsxo_cfg_init(rsxo_cfg* c, int kind, int field_type, int nb, int ny, 
     c->grav = 9.81; c->e_ground = 0.5; c->vz_min = 0.2; c->robot_h = 0.15;
     c->dck = f[7]; c->half_kw = f[9] / 2; c->ir_tol = 0.025; c->drib_vmax = 1.0;
     c->mu_rr = 0.2; c->mu_rb = 0.35; c->mu_wb = 0.3; c->spin_dec = 30.0;   /* build */
+    c->pen2 = 0.005;                                                       /* build */
+    if (getenv("RSXO_PEN2")) c->pen2 = atof(getenv("RSXO_PEN2"));          /* model experiments only */
     for (int k = 0; k < 4; ++k) c->wheel_ang[k] = f[10 + k] * RSXO_PI / 180.0;
     if (kind == 1) {
         /* omni inverse kinematics: wheel surface speed_k = -sin(a_k) vx + cos(a_k) vy + R w.
@@ -146,12 +149,12 @@ static int rsxo_cfg_init(rsxo_cfg* c, int kind, int field_type, int nb, int ny, 
 }
 
 /* ------------------------------------------------------------------------------------------
- * Philox4x32-10 (Salmon et al., SC'11) — counter-based RNG shared by placement, OU noise and
+ * Philox4x32 (Salmon et al., SC'11) — counter-based RNG shared by placement, OU noise and
  * random actions.  counter = (global env id, episode, tick, domain), key = (seed lo, seed hi).
  * ---------------------------------------------------------------------------------------- */
-void rsxo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+void rsxo_philox4x32(const uint32_t ctr[4], const uint32_t key[2], int rounds, uint32_t out[4]) {
     uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < rounds; ++r) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
         uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
@@ -160,9 +163,17 @@ void rsxo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t o
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
+/* the published 10-round form (Random123 known-answer vectors pin the round function) */
+void rsxo_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { rsxo_philox4x32(ctr, key, 10, out); }
+/* what the engine draws with: Philox4x32-7, the smallest round count of the family that passes
+ * BigCrush (Salmon et al., SC'11, table 2); 32-bit multiplies are quarter rate on CDNA */
+#define RSXO_PHILOX_ROUNDS 7
+void rsxo_philox4x32_7(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) { rsxo_philox4x32(ctr, key, RSXO_PHILOX_ROUNDS, out); }
 
+/* domains.  ACT: per-step block(s) of an env: block q in bits 8.. ; SSL tasks use block 0 for the
+ * agent's action; VSS-v0 gives robot k the words (2 (k & 1), 2 (k & 1) + 1) of block k >> 1
+ * (robot 0: random action, robots >= 1: the two uniforms of their Box-Muller OU draw) */
 #define RSXO_DOM_ACT   1u
-#define RSXO_DOM_OU    2u
 #define RSXO_DOM_PLACE 3u
 
 /* float-only elementary functions with a fixed operation order (mirrored instruction for

@@ -26,7 +26,7 @@ typedef struct SUF(rsxo_env) {
     R a_lin_h, a_lin_h2, a_lat_h, a_ang_h, mu_g_dt, g_h, e_ground, vz_min, robot_h;
     R dck_rb, half_kw, ir_tol, drib_gain, drib_vmax, drib_vmax2;
     /* tangential friction / ball spin */
-    R dck, mu_rr, mu_rb, mu_wb, kt_rr, kt_rb_r, kt_rb_b, kw, spin_c, ope_wb, spin_dec_dt;
+    R dck, mu_rr, mu_rb, mu_wb, kt_rr, kt_rb_r, kt_rb_b, kw, spin_c, ope_wb, spin_dec_dt, pen2;
     R ws[4], wc[4], pinv[3][4];
     R deg2rad, rad2deg, h_deg;
     R state[5 + 11 * MAXROB + RSXO_XROWS];
@@ -92,6 +92,7 @@ void* SUF(rsxo_create)(int kind, int field_type, int nb, int ny, int ts_ms) {
         e->kw = RC(2.0 / 7.0); e->spin_c = RC(2.5 / c->r_ball);
         e->ope_wb = RC(1.0 + c->e_wall_ball);
         e->spin_dec_dt = RC(c->spin_dec * (c->time_step_ms * 0.001));
+        e->pen2 = RC(c->pen2);
     }
     for (int k = 0; k < 4; ++k) { e->ws[k] = RC(sin(c->wheel_ang[k])); e->wc[k] = RC(cos(c->wheel_ang[k])); }
     for (int i = 0; i < 3; ++i) for (int k = 0; k < 4; ++k) e->pinv[i][k] = RC(c->pinv[i][k]);
@@ -270,16 +271,19 @@ static inline void SUF(respond)(const SUF(rsxo_env)* e, R nx, R ny, R pen, R dvx
 typedef struct SUF(kick) { int ovr, okick; R ovx, ovy, ovz; } SUF(kick);
 
 /* One Jacobi sweep: every body sums the responses to its touching partners (index order) from
- * the SAME snapshot, then all are applied.  Returns 1 when any pair touched.  first != 0:
- * infrared sensors are refreshed and kicker / dribbler decisions recorded in K. */
+ * the SAME snapshot, then all are applied.  Returns 1 when some pair overlapped by more than
+ * pen2 (a deep contact: an impact at speed or a jammed pile — resting contacts stay far below).
+ * first != 0: infrared sensors are refreshed and kicker / dribbler decisions recorded in K. */
 static int SUF(contacts)(SUF(rsxo_env)* e, SUF(body)* b, int first, SUF(kick)* K) {
     const rsxo_cfg* c = &e->cfg;
     const int N = c->n_robots, M = N + 1, ssl = c->kind == 1;
     SUF(body)* ball = &b[N];
     R dvx[MAXBOD], dvy[MAXBOD], dpx[MAXBOD], dpy[MAXBOD], dws = RC(0);
+    int got[MAXBOD];   /* body had at least one touching partner: only those are updated */
     int any = 0;
     for (int i = 0; i < M; ++i) {
         R avx = RC(0), avy = RC(0), apx = RC(0), apy = RC(0), aw = RC(0);
+        int touched = 0;
         for (int j = 0; j < M; ++j) {
             if (j == i) continue;
             if (i < N && j < N) { /* robot - robot */
@@ -290,7 +294,8 @@ static int SUF(contacts)(SUF(rsxo_env)* e, SUF(body)* b, int first, SUF(kick)* K
                     R wsum = R_FMA(b[j].om, e->r_robot, b[i].om * e->r_robot);
                     SUF(respond)(e, dx * inv, dy * inv, e->rs_rr - d, b[j].vx - b[i].vx, b[j].vy - b[i].vy, wsum,
                                  e->ope_rr, e->w_rr, e->kt_rr, e->mu_rr, RC(0), &avx, &avy, &apx, &apy, &aw);
-                    any = 1;
+                    if (e->rs_rr - d > e->pen2) any = 1;
+                    touched = 1;
                 }
             } else if (i < N) { /* robot i, ball j */
                 R nx, ny, pen; int mouth;
@@ -299,7 +304,8 @@ static int SUF(contacts)(SUF(rsxo_env)* e, SUF(body)* b, int first, SUF(kick)* K
                     R wsum = R_FMA(ball->om, e->r_ball, b[i].om * (mouth ? e->dck : e->r_robot));
                     SUF(respond)(e, nx, ny, pen, ball->vx - b[i].vx, ball->vy - b[i].vy, wsum,
                                  e->ope_rb, e->w_rb_r, e->kt_rb_r, e->mu_rb, RC(0), &avx, &avy, &apx, &apy, &aw);
-                    any = 1;
+                    if (pen > e->pen2) any = 1;
+                    touched = 1;
                 }
                 if (first) b[i].ir = mouth && pen > -e->ir_tol;
             } else if (!ssl) { /* VSS ball i, robot j: circle - circle from the ball's point of view */
@@ -310,7 +316,8 @@ static int SUF(contacts)(SUF(rsxo_env)* e, SUF(body)* b, int first, SUF(kick)* K
                     R wsum = R_FMA(b[j].om, e->r_robot, ball->om * e->r_ball);
                     SUF(respond)(e, dx * inv, dy * inv, e->rs_rb - d, b[j].vx - ball->vx, b[j].vy - ball->vy, wsum,
                                  e->ope_rb, e->w_rb_b, e->kt_rb_b, e->mu_rb, e->spin_c, &avx, &avy, &apx, &apy, &aw);
-                    any = 1;
+                    if (e->rs_rb - d > e->pen2) any = 1;
+                    touched = 1;
                 }
             } else { /* SSL ball i, robot j: the ball's side of what robot j evaluated (robot frame) */
                 R nx, ny, pen; int mouth;
@@ -330,7 +337,8 @@ static int SUF(contacts)(SUF(rsxo_env)* e, SUF(body)* b, int first, SUF(kick)* K
                     }
                     R pc = e->beta * pen * e->w_rb_b;
                     apx = apx + pc * nx; apy = apy + pc * ny;
-                    any = 1;
+                    if (pen > e->pen2) any = 1;
+                    touched = 1;
                 }
                 if (first && mouth && pen > -e->ir_tol) { /* infrared: kicker / dribbler act */
                     if (b[j].kick_x > RC(0) || b[j].kick_z > RC(0)) {
@@ -350,14 +358,15 @@ static int SUF(contacts)(SUF(rsxo_env)* e, SUF(body)* b, int first, SUF(kick)* K
                 }
             }
         }
-        dvx[i] = avx; dvy[i] = avy; dpx[i] = apx; dpy[i] = apy;
+        dvx[i] = avx; dvy[i] = avy; dpx[i] = apx; dpy[i] = apy; got[i] = touched;
         if (i == N) dws = aw;
     }
     for (int i = 0; i < M; ++i) {
+        if (!got[i]) continue;   /* bodies without a contact keep their bits */
         b[i].vx = b[i].vx + dvx[i]; b[i].vy = b[i].vy + dvy[i];
         b[i].x = b[i].x + dpx[i]; b[i].y = b[i].y + dpy[i];
     }
-    ball->om = ball->om + dws;
+    if (got[N]) ball->om = ball->om + dws;
     return any;
 }
 
@@ -463,8 +472,8 @@ static void SUF(step_core)(SUF(rsxo_env)* e, const R* cmds) {
         ball->y = R_FMA(ball->vy, e->h, ball->y);
 
         /* ---- B: contacts — one Jacobi sweep over the post-integration snapshot, and a second
-         * one over the corrected snapshot when anything touched (crowded scenes); what kicker and
-         * dribbler decided in the first sweep is applied after the impulses ---- */
+         * one over the corrected snapshot when some pair was deep (impacts at speed, jammed piles);
+         * what kicker and dribbler decided in the first sweep is applied after the impulses ---- */
         SUF(kick) K; memset(&K, 0, sizeof(K));
         if (SUF(contacts)(e, b, 1, &K)) SUF(contacts)(e, b, 0, &K);
         if (K.ovr) {
@@ -513,7 +522,7 @@ static inline R SUF(u01)(uint32_t x) { return RC(x >> 8) * RC(5.9604644775390625
 
 static void SUF(draw)(const SUF(rsxo_env)* e, uint32_t tick, uint32_t dom, uint32_t out[4]) {
     uint32_t ctr[4] = {e->env_id, e->episode, tick, dom};
-    rsxo_philox4x32_10(ctr, e->key, out);
+    rsxo_philox4x32_7(ctr, e->key, out);
 }
 
 int SUF(rsxo_task_attach)(void* p, int task, uint64_t seed, uint64_t env_id, int max_steps) {
@@ -869,9 +878,9 @@ void SUF(rsxo_task_step)(void* p, const float* action) {
     const int first_step = e->steps == 0;
     if (first_step) { memset(e->info, 0, sizeof(e->info)); e->ep_ret = RC(0); }
     R a[8];
+    SUF(draw)(e, t, RSXO_DOM_ACT, u);   /* block 0 of the step (VSS-v0: robot 1 owns its words 2, 3) */
     if (action) for (int i = 0; i < e->act_dim; ++i) a[i] = RC(action[i]);
     else {
-        SUF(draw)(e, t, RSXO_DOM_ACT, u);
         for (int i = 0; i < 4 && i < e->act_dim; ++i) a[i] = SUF(u01)(u[i]) * RC(2) - RC(1);
         if (e->act_dim > 4) { /* fifth component: the low bytes u01 leaves unused in words 0..2 of the same block */
             uint32_t w = (u[0] & 0xFFu) | ((u[1] & 0xFFu) << 8) | ((u[2] & 0xFFu) << 16);
@@ -884,10 +893,11 @@ void SUF(rsxo_task_step)(void* p, const float* action) {
     if (e->task == 1) {
         R act[MAXROB * 2];
         act[0] = a[0]; act[1] = a[1];
-        for (int k = 1; k < N; ++k) { /* Utils.py:14-21, Box-Muller on Philox */
-            SUF(draw)(e, t, RSXO_DOM_OU | ((uint32_t)k << 8), u);
-            R u1 = RC((u[0] >> 8) + 1u) * RC(5.9604644775390625e-08);
-            R ang = (SUF(u01)(u[1]) - RC(0.5)) * RC(6.283185307179586);
+        for (int k = 1; k < N; ++k) { /* Utils.py:14-21, Box-Muller on Philox: words of block k >> 1 */
+            if (k % 2 == 0) SUF(draw)(e, t, RSXO_DOM_ACT | ((uint32_t)(k >> 1) << 8), u);
+            const uint32_t w0 = u[2 * (k & 1)], w1 = u[2 * (k & 1) + 1];
+            R u1 = RC((w0 >> 8) + 1u) * RC(5.9604644775390625e-08);
+            R ang = (SUF(u01)(w1) - RC(0.5)) * RC(6.283185307179586);
             R rad = R_SQRT(RC(-2) * R_LOG(u1));
             R sn, cs;
             R_SINCOS(ang, &sn, &cs);

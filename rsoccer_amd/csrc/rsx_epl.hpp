@@ -120,16 +120,18 @@ __global__ __launch_bounds__(64) void vss_epl_kernel(RSX_HOT_ARGS, const Params 
         }
         // ---- actions -> commands (vss_gym.py:119-142,235-254) ----
         float q0[N], q1[N];
+        u32x4 blk = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             float a0, a1;
-            const u32x4 u = philox4x32_10(env_id, episode, t, k == 0 ? DOM_ACT : (DOM_OU | ((uint32_t)k << 8)), P.key0, P.key1);
+            if ((k & 1) == 0) blk = philox4x32(env_id, episode, t, DOM_ACT | ((uint32_t)(k >> 1) << 8), P.key0, P.key1);   // one block serves two robots
+            const uint32_t w0 = (k & 1) ? blk.z : blk.x, w1 = (k & 1) ? blk.w : blk.y;
             if (k == 0) {
                 if (fed) { a0 = act0; a1 = act1; }
-                else { a0 = u01(u.x) * 2.0f - 1.0f; a1 = u01(u.y) * 2.0f - 1.0f; }
+                else { a0 = u01(w0) * 2.0f - 1.0f; a1 = u01(w1) * 2.0f - 1.0f; }
             } else {  // Ornstein-Uhlenbeck noise, Utils/Utils.py:14-21 (Box-Muller on Philox)
-                float u1 = (float)((u.x >> 8) + 1u) * 5.9604644775390625e-08f;
-                float ang = (u01(u.y) - 0.5f) * 6.283185307179586f;
+                float u1 = (float)((w0 >> 8) + 1u) * 5.9604644775390625e-08f;
+                float ang = (u01(w1) - 0.5f) * 6.283185307179586f;
                 float rad = sqrtf(-2.0f * log_f32(u1));
                 float sn, cs;
                 sincos_f32(ang, sn, cs);
@@ -208,80 +210,84 @@ __global__ __launch_bounds__(64) void vss_epl_kernel(RSX_HOT_ARGS, const Params 
                 }
                 return touching;
             };
-            unsigned touching = find_touching();
-            if (__any(touching != 0)) {
+            // bits of `touching` that involve body k (pairs in lexicographic order, see epl_pair)
+            constexpr unsigned PM[EPL_NB] = {0x00003Fu, 0x0007C1u, 0x007842u, 0x038884u, 0x0C9108u, 0x152210u, 0x1A4420u};
+            bool deep = false;
+            for (int sweep = 0; sweep < 2; ++sweep) {   // the second sweep runs the same (cached) instructions
+                const unsigned touching = (sweep == 0 || deep) ? find_touching() : 0u;   // second: envs with a deep pair only
+                if (!__any(touching != 0)) break;
                 // some env of the wave has a contact: bodies are addressed by index from here on,
                 // so the snapshot and the sums go through LDS (column = lane, conflict free)
-                for (int sweep = 0; sweep < 2; ++sweep) {
-                    if (sweep == 1) {
-                        touching = touching ? find_touching() : 0u;   // only the envs of the first sweep
-                        if (!__any(touching != 0)) break;
-                    }
 #pragma unroll
-                    for (int k = 0; k < N; ++k) {
-                        sh.u.c.snap[0][k][lane] = r[k].x; sh.u.c.snap[1][k][lane] = r[k].y;
-                        sh.u.c.snap[2][k][lane] = r[k].vx; sh.u.c.snap[3][k][lane] = r[k].vy;
-                        sh.u.c.snap[4][k][lane] = r[k].om;
-                    }
-                    sh.u.c.snap[0][N][lane] = ball.x; sh.u.c.snap[1][N][lane] = ball.y;
-                    sh.u.c.snap[2][N][lane] = ball.vx; sh.u.c.snap[3][N][lane] = ball.vy;
-                    sh.u.c.snap[4][N][lane] = ball.om;
+                for (int k = 0; k < N; ++k) {
+                    sh.u.c.snap[0][k][lane] = r[k].x; sh.u.c.snap[1][k][lane] = r[k].y;
+                    sh.u.c.snap[2][k][lane] = r[k].vx; sh.u.c.snap[3][k][lane] = r[k].vy;
+                    sh.u.c.snap[4][k][lane] = r[k].om;
+                }
+                sh.u.c.snap[0][N][lane] = ball.x; sh.u.c.snap[1][N][lane] = ball.y;
+                sh.u.c.snap[2][N][lane] = ball.vx; sh.u.c.snap[3][N][lane] = ball.vy;
+                sh.u.c.snap[4][N][lane] = ball.om;
 #pragma unroll
-                    for (int k = 0; k < EPL_NB; ++k) {
-                        sh.u.c.acc[0][k][lane] = 0.0f; sh.u.c.acc[1][k][lane] = 0.0f;
-                        sh.u.c.acc[2][k][lane] = 0.0f; sh.u.c.acc[3][k][lane] = 0.0f;
+                for (int k = 0; k < EPL_NB; ++k) {
+                    sh.u.c.acc[0][k][lane] = 0.0f; sh.u.c.acc[1][k][lane] = 0.0f;
+                    sh.u.c.acc[2][k][lane] = 0.0f; sh.u.c.acc[3][k][lane] = 0.0f;
+                }
+                sh.u.c.accw[lane] = 0.0f;
+                wave_sync();
+                deep = false;
+                unsigned todo = touching;
+                while (todo) {   // each lane walks ITS touching pairs, in pair order
+                    const int p = __builtin_ctz(todo);
+                    todo &= todo - 1;
+                    int i, j;
+                    epl_pair(p, i, j);
+                    const bool rb = j == N;
+                    Body bi = Body{}, bj = Body{};
+                    bi.x = sh.u.c.snap[0][i][lane]; bi.y = sh.u.c.snap[1][i][lane]; bi.vx = sh.u.c.snap[2][i][lane]; bi.vy = sh.u.c.snap[3][i][lane];
+                    bj.x = sh.u.c.snap[0][j][lane]; bj.y = sh.u.c.snap[1][j][lane]; bj.vx = sh.u.c.snap[2][j][lane]; bj.vy = sh.u.c.snap[3][j][lane];
+                    const float wi = sh.u.c.snap[4][i][lane], wj = sh.u.c.snap[4][j][lane];
+                    const float rs = rb ? K::rs_rb : K::rs_rr, ope = rb ? K::ope_rb : K::ope_rr;
+                    const float mu = rb ? K::mu_rb : K::mu_rr;
+                    const float lever_j = rb ? K::r_ball : K::r_robot;
+                    float unused = 0.0f;
+                    // body i (a robot) sees j ...
+                    {
+                        const float dx = bj.x - bi.x, dy = bj.y - bi.y;
+                        const float d2 = fma_(dx, dx, dy * dy);
+                        float a0 = sh.u.c.acc[0][i][lane], a1 = sh.u.c.acc[1][i][lane], a2 = sh.u.c.acc[2][i][lane], a3 = sh.u.c.acc[3][i][lane];
+                        contact_response(bi, make_float4(bj.x, bj.y, bj.vx, bj.vy), d2, rs, ope, rb ? K::w_rb_r : K::w_rr,
+                                         rb ? K::kt_rb_r : K::kt_rr, mu, 0.0f, fma_(wj, lever_j, wi * K::r_robot), K::beta, K::pen2,
+                                         a0, a1, a2, a3, unused, deep);
+                        sh.u.c.acc[0][i][lane] = a0; sh.u.c.acc[1][i][lane] = a1; sh.u.c.acc[2][i][lane] = a2; sh.u.c.acc[3][i][lane] = a3;
                     }
-                    sh.u.c.accw[lane] = 0.0f;
-                    wave_sync();
-                    unsigned todo = touching;
-                    while (todo) {   // each lane walks ITS touching pairs, in pair order
-                        const int p = __builtin_ctz(todo);
-                        todo &= todo - 1;
-                        int i, j;
-                        epl_pair(p, i, j);
-                        const bool rb = j == N;
-                        Body bi = Body{}, bj = Body{};
-                        bi.x = sh.u.c.snap[0][i][lane]; bi.y = sh.u.c.snap[1][i][lane]; bi.vx = sh.u.c.snap[2][i][lane]; bi.vy = sh.u.c.snap[3][i][lane];
-                        bj.x = sh.u.c.snap[0][j][lane]; bj.y = sh.u.c.snap[1][j][lane]; bj.vx = sh.u.c.snap[2][j][lane]; bj.vy = sh.u.c.snap[3][j][lane];
-                        const float wi = sh.u.c.snap[4][i][lane], wj = sh.u.c.snap[4][j][lane];
-                        const float rs = rb ? K::rs_rb : K::rs_rr, ope = rb ? K::ope_rb : K::ope_rr;
-                        const float mu = rb ? K::mu_rb : K::mu_rr;
-                        const float lever_j = rb ? K::r_ball : K::r_robot;
-                        float unused = 0.0f;
-                        // body i (a robot) sees j ...
-                        {
-                            const float dx = bj.x - bi.x, dy = bj.y - bi.y;
-                            const float d2 = fma_(dx, dx, dy * dy);
-                            float a0 = sh.u.c.acc[0][i][lane], a1 = sh.u.c.acc[1][i][lane], a2 = sh.u.c.acc[2][i][lane], a3 = sh.u.c.acc[3][i][lane];
-                            contact_response(bi, make_float4(bj.x, bj.y, bj.vx, bj.vy), d2, rs, ope, rb ? K::w_rb_r : K::w_rr,
-                                             rb ? K::kt_rb_r : K::kt_rr, mu, 0.0f, fma_(wj, lever_j, wi * K::r_robot), K::beta,
-                                             a0, a1, a2, a3, unused);
-                            sh.u.c.acc[0][i][lane] = a0; sh.u.c.acc[1][i][lane] = a1; sh.u.c.acc[2][i][lane] = a2; sh.u.c.acc[3][i][lane] = a3;
-                        }
-                        // ... and j sees i, from its own point of view (what its lane computes in the other layout)
-                        {
-                            const float dx = bi.x - bj.x, dy = bi.y - bj.y;
-                            const float d2 = fma_(dx, dx, dy * dy);
-                            float a0 = sh.u.c.acc[0][j][lane], a1 = sh.u.c.acc[1][j][lane], a2 = sh.u.c.acc[2][j][lane], a3 = sh.u.c.acc[3][j][lane];
-                            float a4 = rb ? sh.u.c.accw[lane] : 0.0f;
-                            contact_response(bj, make_float4(bi.x, bi.y, bi.vx, bi.vy), d2, rs, ope, rb ? K::w_rb_b : K::w_rr,
-                                             rb ? K::kt_rb_b : K::kt_rr, mu, rb ? K::spin_c : 0.0f, fma_(wi, K::r_robot, wj * lever_j), K::beta,
-                                             a0, a1, a2, a3, a4);
-                            sh.u.c.acc[0][j][lane] = a0; sh.u.c.acc[1][j][lane] = a1; sh.u.c.acc[2][j][lane] = a2; sh.u.c.acc[3][j][lane] = a3;
-                            if (rb) sh.u.c.accw[lane] = a4;
-                        }
+                    // ... and j sees i, from its own point of view (what its lane computes in the other layout)
+                    {
+                        const float dx = bi.x - bj.x, dy = bi.y - bj.y;
+                        const float d2 = fma_(dx, dx, dy * dy);
+                        float a0 = sh.u.c.acc[0][j][lane], a1 = sh.u.c.acc[1][j][lane], a2 = sh.u.c.acc[2][j][lane], a3 = sh.u.c.acc[3][j][lane];
+                        float a4 = rb ? sh.u.c.accw[lane] : 0.0f;
+                        contact_response(bj, make_float4(bi.x, bi.y, bi.vx, bi.vy), d2, rs, ope, rb ? K::w_rb_b : K::w_rr,
+                                         rb ? K::kt_rb_b : K::kt_rr, mu, rb ? K::spin_c : 0.0f, fma_(wi, K::r_robot, wj * lever_j), K::beta, K::pen2,
+                                         a0, a1, a2, a3, a4, deep);
+                        sh.u.c.acc[0][j][lane] = a0; sh.u.c.acc[1][j][lane] = a1; sh.u.c.acc[2][j][lane] = a2; sh.u.c.acc[3][j][lane] = a3;
+                        if (rb) sh.u.c.accw[lane] = a4;
                     }
-                    wave_sync();
+                }
+                wave_sync();
+                // only a body that touched something is updated (the others keep their bits)
 #pragma unroll
-                    for (int k = 0; k < N; ++k) {
+                for (int k = 0; k < N; ++k) {
+                    if (touching & PM[k]) {
                         r[k].vx = r[k].vx + sh.u.c.acc[0][k][lane]; r[k].vy = r[k].vy + sh.u.c.acc[1][k][lane];
                         r[k].x = r[k].x + sh.u.c.acc[2][k][lane]; r[k].y = r[k].y + sh.u.c.acc[3][k][lane];
                     }
+                }
+                if (touching & PM[N]) {
                     ball.vx = ball.vx + sh.u.c.acc[0][N][lane]; ball.vy = ball.vy + sh.u.c.acc[1][N][lane];
                     ball.x = ball.x + sh.u.c.acc[2][N][lane]; ball.y = ball.y + sh.u.c.acc[3][N][lane];
                     ball.om = ball.om + sh.u.c.accw[lane];
-                    wave_sync();
                 }
+                wave_sync();
             }
             // C: walls
 #pragma unroll
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(64) void vss_epl_kernel(RSX_HOT_ARGS, const Params 
                 // placement: the reference's sequential rejection sampling (vss_gym.py:194-233)
                 uint32_t n = 0;
                 auto draw = [&]() -> float2 {
-                    const u32x4 u = philox4x32_10(env_id, episode, n++, DOM_PLACE, P.key0, P.key1);
+                    const u32x4 u = philox4x32(env_id, episode, n++, DOM_PLACE, P.key0, P.key1);
                     return make_float2(u01(u.x), u01(u.y));
                 };
                 float bx, by;

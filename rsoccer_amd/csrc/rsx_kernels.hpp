@@ -236,12 +236,14 @@ __device__ __forceinline__ void respond(const float nx, const float ny, const fl
 __device__ __forceinline__ void contact_response(const Body& o, const float4 oj, const float d2,
                                                  const float rs, const float ope, const float w,
                                                  const float kt, const float mu, const float spin_c,
-                                                 const float wsum, const float beta, float& avx, float& avy,
-                                                 float& apx, float& apy, float& aw) {
+                                                 const float wsum, const float beta, const float pen2,
+                                                 float& avx, float& avy, float& apx, float& apy, float& aw,
+                                                 bool& deep) {
     float dx = oj.x - o.x, dy = oj.y - o.y;
     float d = sqrtf(d2), inv = 1.0f / d;
     respond(dx * inv, dy * inv, rs - d, oj.z - o.vx, oj.w - o.vy, wsum, ope, w, kt, mu, spin_c, beta,
             avx, avy, apx, apy, aw);
+    deep |= rs - d > pen2;   // an impact at speed or a jammed pile: the env gets a second sweep
 }
 
 // lanes of the env in slot g: body j sits at lane j * G + g
@@ -256,11 +258,10 @@ __device__ __forceinline__ unsigned long long env_lane_mask(const int g) {
 
 // VSS contact sweep with a run-time partner loop: exact integer overlap test into one bit per
 // partner, then the lane walks ITS partners in index order.  First sweep of the run-time-count
-// kernels and second sweep (rare) of all VSS kernels.  Returns whether anything touched.
+// kernels and second sweep (rare) of all VSS kernels.  Returns whether some pair was deep.
 template <int KIND, int L>
-__device__ __forceinline__ bool vss_sweep_loop(const Body& o, const int N, const int g, const bool is_ball,
-                                               const bool ball_low, const Shared<L>& sh, float& avx,
-                                               float& avy, float& apx, float& apy, float& aw) {
+__device__ __forceinline__ bool vss_sweep_loop(Body& o, const int N, const int g, const bool is_ball,
+                                               const bool ball_low, const Shared<L>& sh) {
     using K = KC<KIND>;
     constexpr int G = 64 / L;
     constexpr uint32_t T_RR = __builtin_bit_cast(uint32_t, K::rs_rr2) - 1u;
@@ -274,7 +275,10 @@ __device__ __forceinline__ bool vss_sweep_loop(const Body& o, const int N, const
         const uint32_t u = __float_as_uint(fma_(dx, dx, dy * dy)) - 1u;   // own slot: 0xFFFFFFFF
         todo |= ((u < (rb ? T_RB : T_RR)) & (!rb | ball_low)) ? 1u << j : 0u;
     }
-    const bool any = todo != 0;
+    if (todo == 0) return false;
+    bool deep = false;
+    float avx = 0.0f, avy = 0.0f, apx = 0.0f, apy = 0.0f, aw = 0.0f;
+    const Body snap = o;   // every partner is evaluated against the snapshot
     const float lever = is_ball ? K::r_ball : K::r_robot;
     while (todo) {
         const int j = __builtin_ctz(todo);
@@ -283,13 +287,17 @@ __device__ __forceinline__ bool vss_sweep_loop(const Body& o, const int N, const
         const float wj = sh.W[j * G + g];
         const float dx = oj.x - o.x, dy = oj.y - o.y;
         const bool rb = is_ball || j == N;
-        contact_response(o, oj, fma_(dx, dx, dy * dy), rb ? K::rs_rb : K::rs_rr, rb ? K::ope_rb : K::ope_rr,
+        contact_response(snap, oj, fma_(dx, dx, dy * dy), rb ? K::rs_rb : K::rs_rr, rb ? K::ope_rb : K::ope_rr,
                          is_ball ? K::w_rb_b : (j == N ? K::w_rb_r : K::w_rr),
                          is_ball ? K::kt_rb_b : (j == N ? K::kt_rb_r : K::kt_rr), rb ? K::mu_rb : K::mu_rr,
-                         is_ball ? K::spin_c : 0.0f, fma_(wj, j == N ? K::r_ball : K::r_robot, o.om * lever),
-                         K::beta, avx, avy, apx, apy, aw);
+                         is_ball ? K::spin_c : 0.0f, fma_(wj, j == N ? K::r_ball : K::r_robot, snap.om * lever),
+                         K::beta, K::pen2, avx, avy, apx, apy, aw, deep);
     }
-    return any;
+    // only a body that touched something is updated (the others keep their bits)
+    o.vx = o.vx + avx; o.vy = o.vy + avy;
+    o.x = o.x + apx; o.y = o.y + apy;
+    if (is_ball) o.om = o.om + aw;
+    return deep;
 }
 
 // What the kicker / dribbler of some robot decided for the ball in the first sweep of a sub-step
@@ -298,17 +306,20 @@ struct BallOverride { bool ovr, okick; float ovx, ovy, ovz; };
 // SSL contact sweep.  Robot lanes: robot-robot pairs (circles), then the robot's own robot-ball
 // geometry (kicker mouth or body circle) whose ball-side record goes to LDS; one ballot tells the
 // ball lane which robots wrote one.  FIRST: infrared is refreshed and kicker / dribbler act.
-// NRX > 0: robot count known at compile time (first sweep of the fixed-size kernels).
-template <int KIND, int L, int NRX, bool FIRST>
+// NRX > 0: robot count known at compile time.  `first` is wave-uniform: both sweeps of a sub-step run
+// the SAME instructions (a second copy of this code would be cold in the instruction cache every
+// time it is needed, which costs more than the sweep itself).
+template <int KIND, int L, int NRX>
 __device__ __forceinline__ bool ssl_sweep(const Params& P, Body& o, const int N, const int g, const int lane,
                                           const bool is_robot, const bool is_ball, const bool ball_low,
-                                          Shared<L>& sh, float& avx, float& avy, float& apx, float& apy,
-                                          float& aw, BallOverride& bo) {
+                                          const bool first, Shared<L>& sh, BallOverride& bo) {
     using K = KC<KIND>;
     constexpr int G = 64 / L;
     constexpr uint32_t T_RR = __builtin_bit_cast(uint32_t, K::rs_rr2) - 1u;
     int fl = 0;   // what this robot does to the ball in this sweep (0 = nothing)
-    bool touched = false;
+    bool touched = false;   // deep contact seen by this lane
+    bool got = false;       // this body touched something: only then is it updated
+    float avx = 0.0f, avy = 0.0f, apx = 0.0f, apy = 0.0f, aw = 0.0f;
     if (is_robot) {
         unsigned todo = 0;
         if (NRX) {
@@ -337,7 +348,8 @@ __device__ __forceinline__ bool ssl_sweep(const Params& P, Body& o, const int N,
             }
         }
         if (RSX_RARE_B(KIND, 2, todo != 0)) {   // per-lane partner walk, see the VSS sweep
-            touched = true;
+            bool& deep = touched;
+            got = true;
             while (todo) {
                 const int j = __builtin_ctz(todo);
                 todo &= todo - 1;
@@ -345,7 +357,7 @@ __device__ __forceinline__ bool ssl_sweep(const Params& P, Body& o, const int N,
                 const float wj = sh.W[j * G + g];
                 const float dx = oj.x - o.x, dy = oj.y - o.y;
                 contact_response(o, oj, fma_(dx, dx, dy * dy), K::rs_rr, K::ope_rr, K::w_rr, K::kt_rr, K::mu_rr, 0.0f,
-                                 fma_(wj, K::r_robot, o.om * K::r_robot), K::beta, avx, avy, apx, apy, aw);
+                                 fma_(wj, K::r_robot, o.om * K::r_robot), K::beta, K::pen2, avx, avy, apx, apy, aw, deep);
             }
         }
         // robot - ball: kicker mouth (flat face at dck) or body circle; n points robot -> ball
@@ -368,7 +380,8 @@ __device__ __forceinline__ bool ssl_sweep(const Params& P, Body& o, const int N,
         float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         float dws = 0.0f;
         if (touch) {
-            touched = true;
+            touched |= pen > K::pen2;
+            got = true;
             const float dvx = ob.z - o.vx, dvy = ob.w - o.vy;
             float vn = fma_(dvx, nx, dvy * ny);
             if (vn < 0.0f) {
@@ -389,7 +402,7 @@ __device__ __forceinline__ bool ssl_sweep(const Params& P, Body& o, const int N,
             apx = fma_(-pc, nx, apx); apy = fma_(-pc, ny, apy);
             float pb = K::beta * pen * K::w_rb_b; r0.z = pb * nx; r0.w = pb * ny; fl |= 2;
         }
-        if (FIRST) {
+        if (first) {
             o.ir = mouth && pen > -K::ir_tol;
             if (o.ir) {  // infrared: kicker / dribbler act on the ball
                 if (o.kick_x > 0.0f || o.kick_z > 0.0f) {
@@ -422,9 +435,14 @@ __device__ __forceinline__ bool ssl_sweep(const Params& P, Body& o, const int N,
             const float4 r0 = sh.Bq[lj];
             const int flj = __float_as_int(r1.x);
             if (flj & 1) { avx = avx - r0.x; avy = avy - r0.y; aw = aw + sh.Dq[lj]; }
-            if (flj & 2) { apx = apx + r0.z; apy = apy + r0.w; }
-            if (FIRST && (flj & 4)) { bo.ovr = true; bo.okick = (flj & 8) != 0; bo.ovx = r1.y; bo.ovy = r1.z; bo.ovz = r1.w; }
+            if (flj & 2) { apx = apx + r0.z; apy = apy + r0.w; got = true; }
+            if (flj & 4) { bo.ovr = true; bo.okick = (flj & 8) != 0; bo.ovx = r1.y; bo.ovy = r1.z; bo.ovz = r1.w; }
         }
+    }
+    if (got) {   // only a body that touched something is updated (the others keep their bits)
+        o.vx = o.vx + avx; o.vy = o.vy + avy;
+        o.x = o.x + apx; o.y = o.y + apy;
+        if (is_ball) o.om = o.om + aw;
     }
     return touched;
 }
@@ -499,114 +517,108 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
         }
 
         // ---- B: contacts — one Jacobi sweep over the post-integration snapshot, and a second one
-        // over the corrected snapshot for the envs in which anything touched (crowded scenes) ----
-        sh.A[lane] = make_float4(o.x, o.y, o.vx, o.vy);
-        sh.W[lane] = o.om;   // yaw rate / spin: read on the contact path only
+        // over the corrected snapshot for the envs in which some pair overlapped by more than pen2
+        // (impacts at speed, jammed piles; resting contacts stay far below).  The second sweep is
+        // the same loop body again: the instructions are in the cache (a separate copy never is) ----
         if (is_ball) sh.zb[g] = o.z;
-        wave_sync();
-        const bool ball_low = sh.zb[g] < K::robot_h;
-        float avx = 0.0f, avy = 0.0f, apx = 0.0f, apy = 0.0f, aw = 0.0f;
-        bool touched = false;
+        bool active = is_robot || is_ball;   // lanes whose env takes part in the current sweep
         BallOverride bo{false, false, 0.0f, 0.0f, 0.0f};
+        bool ball_low = true;
+        for (int sweep = 0;; ++sweep) {
+            if (active) {
+                sh.A[lane] = make_float4(o.x, o.y, o.vx, o.vy);
+                sh.W[lane] = o.om;   // yaw rate / spin: read on the contact path only
+            }
+            wave_sync();
+            if (sweep == 0) ball_low = sh.zb[g] < K::robot_h;
+            bool deep = false;   // this lane saw a deep contact
 
-        if (KIND == RSX_KIND_VSS) {
-            // every pair is circle-circle; only the constants depend on the pair type
-            if (is_robot || is_ball) {
-                if (NR) {
-                    float4 oth[NR + 1];  // all reads in flight together, one wait
+            if (KIND == RSX_KIND_VSS) {
+                // every pair is circle-circle; only the constants depend on the pair type
+                if (active) {
+                    if (NR) {
+                        float4 oth[NR + 1];  // all reads in flight together, one wait
 #pragma unroll
-                    for (int j = 0; j <= NR; ++j) oth[j] = sh.A[j * G + g];
-                    // Overlap test of the whole sweep, exact and with ONE compare per partner class:
-                    // d2 is a sum of squares (>= +0), and non-negative floats order like their bit
-                    // patterns, so with u = bits(d2) - 1 (d2 == 0, the lane's own slot, wraps to
-                    // 0xFFFFFFFF)   0 < d2 < thr   <=>   u < bits(thr) - 1   (unsigned).
-                    // The minimum of u over the robot slots is compared once; contacts are rare, so
-                    // the common case is ~5 instructions per partner and one untaken branch.
-                    constexpr uint32_t T_RR = __builtin_bit_cast(uint32_t, K::rs_rr2) - 1u;
-                    constexpr uint32_t T_RB = __builtin_bit_cast(uint32_t, K::rs_rb2) - 1u;
-                    uint32_t u[NR + 1];
-#pragma unroll
-                    for (int j = 0; j <= NR; ++j) {
-                        float dx = oth[j].x - o.x, dy = oth[j].y - o.y;
-                        u[j] = __float_as_uint(fma_(dx, dx, dy * dy)) - 1u;
-                    }
-                    uint32_t um = u[0];
-#pragma unroll
-                    for (int j = 1; j < NR; ++j) um = min(um, u[j]);
-                    // robot lane: robot slots are robot-robot pairs, slot NR the ball; ball lane:
-                    // every robot slot is a robot-ball pair, slot NR itself (u = 0xFFFFFFFF)
-                    const bool any = ((um < (is_ball ? T_RB : T_RR)) & (!is_ball | ball_low)) | ((u[NR] < T_RB) & ball_low);
-                    if (RSX_RARE_B(KIND, 2, any)) {
-                        // Each lane walks ITS partners in body-index order; lanes with different
-                        // partners share an iteration, so a wave pays for the deepest lane (one
-                        // response, rarely two) instead of one response block per distinct partner
-                        // index present anywhere in the wave.  The wave that finishes last sets a
-                        // single-step launch's duration, and it is always one with contacts.
-                        touched = true;
-                        unsigned todo = 0;
+                        for (int j = 0; j <= NR; ++j) oth[j] = sh.A[j * G + g];
+                        // Overlap test of the whole sweep, exact and with ONE compare per partner class:
+                        // d2 is a sum of squares (>= +0), and non-negative floats order like their bit
+                        // patterns, so with u = bits(d2) - 1 (d2 == 0, the lane's own slot, wraps to
+                        // 0xFFFFFFFF)   0 < d2 < thr   <=>   u < bits(thr) - 1   (unsigned).
+                        // The minimum of u over the robot slots is compared once; contacts are rare, so
+                        // the common case is ~5 instructions per partner and one untaken branch.
+                        constexpr uint32_t T_RR = __builtin_bit_cast(uint32_t, K::rs_rr2) - 1u;
+                        constexpr uint32_t T_RB = __builtin_bit_cast(uint32_t, K::rs_rb2) - 1u;
+                        uint32_t u[NR + 1];
 #pragma unroll
                         for (int j = 0; j <= NR; ++j) {
-                            const bool rb = is_ball || j == NR;
-                            todo |= ((u[j] < (rb ? T_RB : T_RR)) & (!rb | ball_low)) ? 1u << j : 0u;
+                            float dx = oth[j].x - o.x, dy = oth[j].y - o.y;
+                            u[j] = __float_as_uint(fma_(dx, dx, dy * dy)) - 1u;
                         }
-                        const float lever = is_ball ? K::r_ball : K::r_robot;
-                        // software-pipelined: the next partner's slot is fetched while the current
-                        // response is being computed
-                        int jn = __builtin_ctz(todo);
-                        todo &= todo - 1;
-                        float4 nxt = sh.A[jn * G + g];
-                        float nxw = sh.W[jn * G + g];
-                        for (;;) {
-                            const int j = jn;
-                            const float4 oj = nxt;
-                            const float wj = nxw;
-                            const bool more = todo != 0;
-                            if (more) {
-                                jn = __builtin_ctz(todo);
-                                todo &= todo - 1;
-                                nxt = sh.A[jn * G + g];
-                                nxw = sh.W[jn * G + g];
+                        uint32_t um = u[0];
+#pragma unroll
+                        for (int j = 1; j < NR; ++j) um = min(um, u[j]);
+                        // robot lane: robot slots are robot-robot pairs, slot NR the ball; ball lane:
+                        // every robot slot is a robot-ball pair, slot NR itself (u = 0xFFFFFFFF)
+                        const bool any = ((um < (is_ball ? T_RB : T_RR)) & (!is_ball | ball_low)) | ((u[NR] < T_RB) & ball_low);
+                        if (RSX_RARE_B(KIND, 2, any)) {
+                            // Each lane walks ITS partners in body-index order; lanes with different
+                            // partners share an iteration, so a wave pays for the deepest lane (one
+                            // response, rarely two) instead of one response block per distinct partner
+                            // index present anywhere in the wave.  The wave that finishes last sets a
+                            // single-step launch's duration, and it is always one with contacts.
+                            unsigned todo = 0;
+#pragma unroll
+                            for (int j = 0; j <= NR; ++j) {
+                                const bool rb = is_ball || j == NR;
+                                todo |= ((u[j] < (rb ? T_RB : T_RR)) & (!rb | ball_low)) ? 1u << j : 0u;
                             }
-                            const float dx = oj.x - o.x, dy = oj.y - o.y;
-                            const float d2 = fma_(dx, dx, dy * dy);   // the value the sweep above saw
-                            const bool rb = is_ball || j == NR;
-                            contact_response(o, oj, d2, rb ? K::rs_rb : K::rs_rr, rb ? K::ope_rb : K::ope_rr,
-                                             is_ball ? K::w_rb_b : (j == NR ? K::w_rb_r : K::w_rr),
-                                             is_ball ? K::kt_rb_b : (j == NR ? K::kt_rb_r : K::kt_rr),
-                                             rb ? K::mu_rb : K::mu_rr, is_ball ? K::spin_c : 0.0f,
-                                             fma_(wj, j == NR ? K::r_ball : K::r_robot, o.om * lever), K::beta,
-                                             avx, avy, apx, apy, aw);
-                            if (!more) break;
+                            float avx = 0.0f, avy = 0.0f, apx = 0.0f, apy = 0.0f, aw = 0.0f;
+                            const float lever = is_ball ? K::r_ball : K::r_robot;
+                            // software-pipelined: the next partner's slot is fetched while the current
+                            // response is being computed
+                            int jn = __builtin_ctz(todo);
+                            todo &= todo - 1;
+                            float4 nxt = sh.A[jn * G + g];
+                            float nxw = sh.W[jn * G + g];
+                            for (;;) {
+                                const int j = jn;
+                                const float4 oj = nxt;
+                                const float wj = nxw;
+                                const bool more = todo != 0;
+                                if (more) {
+                                    jn = __builtin_ctz(todo);
+                                    todo &= todo - 1;
+                                    nxt = sh.A[jn * G + g];
+                                    nxw = sh.W[jn * G + g];
+                                }
+                                const float dx = oj.x - o.x, dy = oj.y - o.y;
+                                const float d2 = fma_(dx, dx, dy * dy);   // the value the sweep above saw
+                                const bool rb = is_ball || j == NR;
+                                contact_response(o, oj, d2, rb ? K::rs_rb : K::rs_rr, rb ? K::ope_rb : K::ope_rr,
+                                                 is_ball ? K::w_rb_b : (j == NR ? K::w_rb_r : K::w_rr),
+                                                 is_ball ? K::kt_rb_b : (j == NR ? K::kt_rb_r : K::kt_rr),
+                                                 rb ? K::mu_rb : K::mu_rr, is_ball ? K::spin_c : 0.0f,
+                                                 fma_(wj, j == NR ? K::r_ball : K::r_robot, o.om * lever), K::beta, K::pen2,
+                                                 avx, avy, apx, apy, aw, deep);
+                                if (!more) break;
+                            }
+                            // only a body that touched something is updated (the others keep their bits)
+                            o.vx = o.vx + avx; o.vy = o.vy + avy;
+                            o.x = o.x + apx; o.y = o.y + apy;
+                            if (is_ball) o.om = o.om + aw;
                         }
+                    } else {
+                        deep = vss_sweep_loop<KIND, L>(o, N, g, is_ball, ball_low, sh);
                     }
-                } else {
-                    touched = vss_sweep_loop<KIND, L>(o, N, g, is_ball, ball_low, sh, avx, avy, apx, apy, aw);
                 }
-            }
-        } else {
-            touched = ssl_sweep<KIND, L, NR, true>(P, o, N, g, lane, is_robot, is_ball, ball_low, sh, avx, avy, apx, apy, aw, bo);
-        }
-        o.vx = o.vx + avx; o.vy = o.vy + avy;
-        o.x = o.x + apx; o.y = o.y + apy;
-        if (is_ball) o.om = o.om + aw;
-
-        // second sweep, for the envs in which something touched (one ballot; usually no lane)
-        const unsigned long long tmask = __ballot(touched);
-        if (RSX_RARE_B(KIND, 2, tmask != 0)) {
-            const bool again = (L == 64 ? tmask : (tmask & env_lane_mask<L>(g))) != 0;
-            wave_sync();   // every lane has read the first snapshot
-            if (again) { sh.A[lane] = make_float4(o.x, o.y, o.vx, o.vy); sh.W[lane] = o.om; }
-            wave_sync();
-            avx = 0.0f; avy = 0.0f; apx = 0.0f; apy = 0.0f; aw = 0.0f;
-            if (KIND == RSX_KIND_VSS) {
-                if (again && (is_robot || is_ball)) vss_sweep_loop<KIND, L>(o, N, g, is_ball, ball_low, sh, avx, avy, apx, apy, aw);
             } else {
-                BallOverride unused{false, false, 0.0f, 0.0f, 0.0f};
-                ssl_sweep<KIND, L, 0, false>(P, o, N, g, lane, is_robot && again, is_ball && again, ball_low, sh, avx, avy, apx, apy, aw, unused);
+                deep = ssl_sweep<KIND, L, NR>(P, o, N, g, lane, is_robot && active, is_ball && active, ball_low, sweep == 0, sh, bo);
             }
-            o.vx = o.vx + avx; o.vy = o.vy + avy;
-            o.x = o.x + apx; o.y = o.y + apy;
-            if (is_ball) o.om = o.om + aw;
+            // second sweep for the envs in which some pair was deep: one ballot, usually no lane
+            const unsigned long long dmask = __ballot(deep);
+            if (sweep == 1 || !RSX_RARE_B(KIND, 2, dmask != 0)) break;
+            active = active && (L == 64 ? dmask : (dmask & env_lane_mask<L>(g))) != 0;
+            wave_sync();   // every lane has read the first snapshot before it is republished
         }
         if (KIND == RSX_KIND_SSL && bo.ovr) {   // kicker / dribbler: decided in the first sweep, applied after the impulses
             o.vx = bo.ovx; o.vy = bo.ovy; o.om = 0.0f;
@@ -865,7 +877,7 @@ __device__ __forceinline__ void place_predraw(const Params& P, uint32_t env_id, 
     constexpr int NPRE = predraw_count<TASK, L>();
 #pragma unroll
     for (int n = b; n < NPRE; n += L) {
-        const u32x4 u = philox4x32_10(env_id, episode, (uint32_t)n, DOM_PLACE, P.key0, P.key1);
+        const u32x4 u = philox4x32(env_id, episode, (uint32_t)n, DOM_PLACE, P.key0, P.key1);
         draws[n] = make_float2(u01(u.x), u01(u.y));
     }
 }
@@ -879,7 +891,7 @@ __device__ __forceinline__ void place_env(const Params& P, const int N, uint32_t
     auto draw = [&]() -> float2 {
         const uint32_t i = n++;
         if (i < (uint32_t)NPRE) return draws[i];
-        const u32x4 u = philox4x32_10(env_id, episode, i, DOM_PLACE, P.key0, P.key1);
+        const u32x4 u = philox4x32(env_id, episode, i, DOM_PLACE, P.key0, P.key1);
         return make_float2(u01(u.x), u01(u.y));
     };
     int first = 0;
@@ -972,7 +984,7 @@ __device__ __forceinline__ float4 place_env_parallel(const Params& P, const int 
     constexpr int NPRE = predraw_count<TASK, L>();
     auto getdraw = [&](uint32_t i) -> float2 {
         if (i < (uint32_t)NPRE) return draws[i];
-        const u32x4 u = philox4x32_10(env_id, episode, i, DOM_PLACE, P.key0, P.key1);
+        const u32x4 u = philox4x32(env_id, episode, i, DOM_PLACE, P.key0, P.key1);
         return make_float2(u01(u.x), u01(u.y));
     };
     uint32_t n = 0;
@@ -1186,14 +1198,16 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
             if (TASK == RSX_TASK_VSS_V0) {
                 if (is_robot) {
                     float a0, a1;
-                    // one Philox call per lane: the agent's random action or this robot's OU draw
-                    const u32x4 u = philox4x32_10(env_id, episode, t, b == 0 ? DOM_ACT : (DOM_OU | ((uint32_t)b << 8)), P.key0, P.key1);
+                    // one Philox call per lane: block b >> 1 of the step, this robot's pair of words
+                    // (robot 0: the agent's random action; the others: their OU draw)
+                    const u32x4 u = philox4x32(env_id, episode, t, DOM_ACT | ((uint32_t)(b >> 1) << 8), P.key0, P.key1);
+                    const uint32_t w0 = (b & 1) ? u.z : u.x, w1 = (b & 1) ? u.w : u.y;
                     if (b == 0) {
                         if (fed) { a0 = act[0]; a1 = act[1]; }
-                        else { a0 = u01(u.x) * 2.0f - 1.0f; a1 = u01(u.y) * 2.0f - 1.0f; }
+                        else { a0 = u01(w0) * 2.0f - 1.0f; a1 = u01(w1) * 2.0f - 1.0f; }
                     } else {  // Ornstein-Uhlenbeck noise, Utils/Utils.py:14-21 (Box-Muller on Philox)
-                        float u1 = (float)((u.x >> 8) + 1u) * 5.9604644775390625e-08f;
-                        float ang = (u01(u.y) - 0.5f) * 6.283185307179586f;
+                        float u1 = (float)((w0 >> 8) + 1u) * 5.9604644775390625e-08f;
+                        float ang = (u01(w1) - 0.5f) * 6.283185307179586f;
                         float rad = sqrtf(-2.0f * log_f32(u1));
                         float sn, cs;
                         sincos_f32(ang, sn, cs);
@@ -1211,7 +1225,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
 #pragma unroll
                         for (int i = 0; i < AD; ++i) a[i] = act[i];
                     } else {
-                        u32x4 u = philox4x32_10(env_id, episode, t, DOM_ACT, P.key0, P.key1);
+                        u32x4 u = philox4x32(env_id, episode, t, DOM_ACT, P.key0, P.key1);
                         a[0] = u01(u.x) * 2.0f - 1.0f; a[1] = u01(u.y) * 2.0f - 1.0f;
                         a[2] = u01(u.z) * 2.0f - 1.0f;
                         if (AD > 3) a[3] = u01(u.w) * 2.0f - 1.0f;

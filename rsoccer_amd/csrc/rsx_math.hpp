@@ -103,15 +103,20 @@ __device__ __forceinline__ float atan2_f32(float y, float x) {
     return y > 0.0f ? 1.5707963267948966f : (y < 0.0f ? -1.5707963267948966f : 0.0f);
 }
 
-// Philox4x32-10 (Salmon, Moraes, Dror, Shaw — SC'11).  counter = (global env id, episode,
+// Philox4x32 (Salmon, Moraes, Dror, Shaw — SC'11).  counter = (global env id, episode,
 // tick, domain), key = (seed lo, seed hi): a draw depends only on WHAT it is for, never on the
 // thread that computes it, so results are invariant to batch size, batch position and sharding.
 struct u32x4 { uint32_t x, y, z, w; };
 
-__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                               uint32_t k0, uint32_t k1) {
+// Rounds: 7, the smallest count of the family that passes BigCrush (SC'11, table 2) — 32-bit integer
+// multiplies are quarter rate on CDNA, and at scale the draws were ~25 % of the step's VALU time
+// with the 10-round default.  The round function is pinned by the published 10-round vectors.
+constexpr int PHILOX_ROUNDS = 7;
+
+__device__ __forceinline__ u32x4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                            uint32_t k0, uint32_t k1) {
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < PHILOX_ROUNDS; ++r) {
         uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
         uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
         uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
@@ -121,7 +126,11 @@ __device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_
     return u32x4{c0, c1, c2, c3};
 }
 
-constexpr uint32_t DOM_ACT = 1u, DOM_OU = 2u, DOM_PLACE = 3u;
+// domains.  ACT: per-step block(s) of an env, block q in bits 8..: SSL tasks take the agent's action
+// from block 0; VSS-v0 gives robot k the words (2 (k & 1), 2 (k & 1) + 1) of block k >> 1 (robot 0:
+// random action, robots >= 1: the two uniforms of their Box-Muller OU draw) — one block serves two
+// robots, which the one-lane-per-env kernel turns into half the Philox work.
+constexpr uint32_t DOM_ACT = 1u, DOM_PLACE = 3u;
 
 // 24-bit uniform in [0, 1)
 __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }
