@@ -925,7 +925,9 @@ void SUF(rsxo_task_step)(void* p, const float* action) {
         else if (e->task == 2 || e->task == 4) e->metrics[2] += e->info[0] > RC(0);  /* goal */
         else if (e->task == 3) e->metrics[2] += e->info[0] >= RC(7);                  /* course completed */
         else e->metrics[2] += e->terminated && e->state[5 + 11 + 6] != RC(0);         /* pass received */
-        e->metrics[4] += (int64_t)llrint((double)(e->ep_ret * RC(1048576.0)));
+        /* VSS-v0: the return is taken from the cumulative reward terms (no running sum is kept) */
+        R ret = e->task == 1 ? ((e->info[1] + e->info[2]) + e->info[3]) + RC(10) * e->info[0] : e->ep_ret;
+        e->metrics[4] += (int64_t)llrint((double)(ret * RC(1048576.0)));
         e->metrics[5] += e->steps;
         e->metrics[6] += e->truncated && !e->terminated;
         e->episode += 1;

@@ -44,7 +44,7 @@ __device__ __forceinline__ void epl_pair(int p, int& i, int& j) {
 }
 
 template <int MODE>
-__global__ __launch_bounds__(64) void vss_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void vss_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
     constexpr int KIND = RSX_KIND_VSS, TASK = RSX_TASK_VSS_V0, N = EPL_NR;
     using K = KC<KIND>;
     using T = TC<TASK>;
@@ -62,13 +62,19 @@ __global__ __launch_bounds__(64) void vss_epl_kernel(RSX_HOT_ARGS, const Params 
     float* const st = bufs.state + e;
     float* const auxe = bufs.aux + e;
 
+    // Register budget: four waves per SIMD need <= 128 VGPRs, so in single-step launches nothing is
+    // kept in registers longer than it is needed: the OU state goes back to memory as soon as the
+    // commands exist, the cumulative info terms are fetched after the physics, the state rows are
+    // stored robot by robot while the observation is assembled.  Multi-step launches (MODE_ROLLOUT)
+    // keep all of it in registers across steps instead.
+    constexpr bool STEP = MODE == MODE_STEP;
     // ---- load: every row access of the wave is 256 contiguous bytes ----
     Body r[N];
     Body ball = Body{};
-    float od[N], wd[N];
     float ou[N][2];
-    float info[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    float prev_pot = 0.0f, ep_ret = 0.0f;
+    float wdeg[N];                        // multi-step launches: the wire-format yaw rate (deg/s) of the last step
+    float info[6] = {0, 0, 0, 0, 0, 0};   // rows 0, 4, 5 (goal counters) are zero except on a terminal step
+    float prev_pot = 0.0f;
     int steps = 0; uint32_t episode = 0;
     float raw[N][6], rawb[7] = {0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -85,9 +91,11 @@ __global__ __launch_bounds__(64) void vss_epl_kernel(RSX_HOT_ARGS, const Params 
         rawb[6] = st[(size_t)(P.state_dim + 1) * B];
         steps = __float_as_int(auxe[(size_t)ROW_STEPS * B]);
         episode = __float_as_uint(auxe[(size_t)ROW_EPISODE * B]);
+        if (!STEP) {
 #pragma unroll
-        for (int i = 0; i < ID; ++i) info[i] = auxe[(size_t)(ROW_INFO + i) * B];
-        prev_pot = auxe[(size_t)ROW_PREV_POT * B]; ep_ret = auxe[(size_t)ROW_EP_RET * B];
+            for (int i = 1; i <= 3; ++i) info[i] = auxe[(size_t)(ROW_INFO + i) * B];
+            prev_pot = auxe[(size_t)ROW_PREV_POT * B];
+        }
     }
     const bool counts_steps = blockIdx.x == 0 && lane == 0;   // metrics[0]: see task_step_kernel
     unsigned long long steps_before = 0;
@@ -100,24 +108,23 @@ __global__ __launch_bounds__(64) void vss_epl_kernel(RSX_HOT_ARGS, const Params 
     for (int k = 0; k < N; ++k) {   // interpret_body, robot
         r[k] = Body{};
         r[k].x = raw[k][0]; r[k].y = raw[k][1]; r[k].vx = raw[k][3]; r[k].vy = raw[k][4];
-        od[k] = raw[k][2]; wd[k] = raw[k][5];
-        r[k].th = od[k];
-        r[k].om = wd[k] * K::deg2rad;
+        r[k].th = raw[k][2];
+        wdeg[k] = raw[k][5];
+        r[k].om = raw[k][5] * K::deg2rad;
         sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
+        if (STEP) __builtin_amdgcn_sched_barrier(0);
     }
     ball.x = rawb[0]; ball.y = rawb[1]; ball.vx = rawb[3]; ball.vy = rawb[4];
     ball.z = rawb[2] - K::r_ball; ball.vz = rawb[5]; ball.om = rawb[6];
+    // the three internal ball rows (height, vertical speed, spin) rarely change in VSS: they are
+    // written back only when they did
+    const float z_in = rawb[2], vz_in = rawb[5], spin_in = rawb[6];
 
     float reward = 0.0f; int term = 0, trunc = 0;
 
     for (int it = 0; it < n_steps; ++it) {
         const bool first_step = steps == 0;
         const uint32_t t = (uint32_t)steps;
-        if (first_step) {
-#pragma unroll
-            for (int i = 0; i < 10; ++i) info[i] = 0.0f;
-            ep_ret = 0.0f;
-        }
         // ---- actions -> commands (vss_gym.py:119-142,235-254) ----
         float q0[N], q1[N];
         u32x4 blk = u32x4{0u, 0u, 0u, 0u};
@@ -143,7 +150,10 @@ __global__ __launch_bounds__(64) void vss_epl_kernel(RSX_HOT_ARGS, const Params 
             q0[k] = vss_wheel(a0); q1[k] = vss_wheel(a1);
             const float qq[2] = {q0[k], q1[k]};
             robot_targets<KIND>(P, r[k], qq);
+            if (STEP && k >= 1 && live) { auxe[(size_t)(ROW_OU + 2 * k) * B] = ou[k][0]; auxe[(size_t)(ROW_OU + 2 * k + 1) * B] = ou[k][1]; }
+            if (STEP) __builtin_amdgcn_sched_barrier(0);   // one robot after the other: interleaving them for ILP costs a wave of occupancy
         }
+        const float en0 = q0[0], en1 = q1[0];   // the agent's wheel commands: energy term of the reward
 
         // ---- physics: n_sub sub-steps, the whole env in registers ----
         if (P.n_sub && !(ball.z > 0.0f || ball.vz > 0.0f)) {   // rolling resistance, once per step()
@@ -274,18 +284,26 @@ __global__ __launch_bounds__(64) void vss_epl_kernel(RSX_HOT_ARGS, const Params 
                     }
                 }
                 wave_sync();
-                // only a body that touched something is updated (the others keep their bits)
+                // Positions and velocities come back from the snapshot (their registers were free during
+                // the walk: that is a wave of occupancy); only a body that touched something is updated,
+                // the others keep their bits
 #pragma unroll
                 for (int k = 0; k < N; ++k) {
-                    if (touching & PM[k]) {
-                        r[k].vx = r[k].vx + sh.u.c.acc[0][k][lane]; r[k].vy = r[k].vy + sh.u.c.acc[1][k][lane];
-                        r[k].x = r[k].x + sh.u.c.acc[2][k][lane]; r[k].y = r[k].y + sh.u.c.acc[3][k][lane];
-                    }
+                    const bool got = (touching & PM[k]) != 0;
+                    const float sx = sh.u.c.snap[0][k][lane], sy = sh.u.c.snap[1][k][lane];
+                    const float svx = sh.u.c.snap[2][k][lane], svy = sh.u.c.snap[3][k][lane];
+                    const float a0 = sh.u.c.acc[0][k][lane], a1 = sh.u.c.acc[1][k][lane];
+                    const float a2 = sh.u.c.acc[2][k][lane], a3 = sh.u.c.acc[3][k][lane];
+                    r[k].vx = got ? svx + a0 : svx; r[k].vy = got ? svy + a1 : svy;
+                    r[k].x = got ? sx + a2 : sx; r[k].y = got ? sy + a3 : sy;
                 }
-                if (touching & PM[N]) {
-                    ball.vx = ball.vx + sh.u.c.acc[0][N][lane]; ball.vy = ball.vy + sh.u.c.acc[1][N][lane];
-                    ball.x = ball.x + sh.u.c.acc[2][N][lane]; ball.y = ball.y + sh.u.c.acc[3][N][lane];
-                    ball.om = ball.om + sh.u.c.accw[lane];
+                {
+                    const bool got = (touching & PM[N]) != 0;
+                    const float sx = sh.u.c.snap[0][N][lane], sy = sh.u.c.snap[1][N][lane];
+                    const float svx = sh.u.c.snap[2][N][lane], svy = sh.u.c.snap[3][N][lane], sw = sh.u.c.snap[4][N][lane];
+                    ball.vx = got ? svx + sh.u.c.acc[0][N][lane] : svx; ball.vy = got ? svy + sh.u.c.acc[1][N][lane] : svy;
+                    ball.x = got ? sx + sh.u.c.acc[2][N][lane] : sx; ball.y = got ? sy + sh.u.c.acc[3][N][lane] : sy;
+                    ball.om = got ? sw + sh.u.c.accw[lane] : sw;
                 }
                 wave_sync();
             }
@@ -304,16 +322,29 @@ __global__ __launch_bounds__(64) void vss_epl_kernel(RSX_HOT_ARGS, const Params 
         }
 
         // ---- wire-format values, observation, reward ----
+        if (STEP && live) {   // cumulative shaping terms of the episode: fetched now, used after the observation
+#pragma unroll
+            for (int i = 1; i <= 3; ++i) info[i] = auxe[(size_t)(ROW_INFO + i) * B];
+            prev_pot = auxe[(size_t)ROW_PREV_POT * B];
+        }
         float* const row = sh.u.stage + lane * EPL_ODP;
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-            od[k] = r[k].th; wd[k] = r[k].om * K::rad2deg;
-            r[k].om = wd[k] * K::deg2rad;
+            const float wd = r[k].om * K::rad2deg;
+            wdeg[k] = wd;
+            r[k].om = wd * K::deg2rad;
             sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
-            write_obs<KIND, TASK>(P, row, k, true, false, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, wd[k], 0, prev_pot);
+            write_obs<KIND, TASK>(P, row, k, true, false, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, wd, 0, prev_pot);
+            if (STEP && live) {   // wire format, robot by robot (an env that resets below writes its rows again)
+                float* p = st + (size_t)(5 + 6 * k) * B;
+                p[0] = r[k].x; p[B] = r[k].y; p[2 * B] = r[k].th; p[3 * B] = r[k].vx; p[4 * B] = r[k].vy; p[5 * B] = wd;
+            }
+            if (STEP) __builtin_amdgcn_sched_barrier(0);
         }
         ball.z = (K::r_ball + ball.z) - K::r_ball;
         write_obs<KIND, TASK>(P, row, N, false, true, ball.x, ball.y, ball.vx, ball.vy, 0.0f, 0.0f, 0.0f, 0, prev_pot);
+        if (first_step) { info[1] = 0.0f; info[2] = 0.0f; info[3] = 0.0f; }
+        info[0] = 0.0f; info[4] = 0.0f; info[5] = 0.0f;
         {   // vss_gym.py:144-192,256-311
             reward = 0.0f; term = 0;
             const float bx = ball.x, by = ball.y;
@@ -331,19 +362,21 @@ __global__ __launch_bounds__(64) void vss_epl_kernel(RSX_HOT_ARGS, const Params 
                 float nrm = sqrtf(rbx * rbx + rby * rby);
                 float mv = (rbx / nrm) * r[0].vx + (rby / nrm) * r[0].vy;
                 float move = clampf(mv * 2.5f, -5.0f, 5.0f);
-                float energy = -(fabsf(q0[0]) + fabsf(q1[0]));
+                float energy = -(fabsf(en0) + fabsf(en1));
                 float t_move = 0.2f * move, t_grad = 0.8f * grad, t_en = 2e-4f * energy;
                 reward = (t_move + t_grad) + t_en;
                 info[1] += t_move; info[2] += t_grad; info[3] += t_en;
             }
-            ep_ret = ep_ret + reward;
         }
         steps += 1;
         trunc = steps >= P.max_steps;
         const bool ended = live && (term | trunc);
         if (live) {
 #pragma unroll
-            for (int i = 0; i < ID; ++i) auxe[(size_t)(ROW_INFO + i) * B] = info[i];
+            for (int i = 1; i <= 3; ++i) auxe[(size_t)(ROW_INFO + i) * B] = info[i];
+            if (term || first_step) {   // goal counters: non-zero on a terminal step only, cleared on the next first step
+                auxe[(size_t)(ROW_INFO + 0) * B] = info[0]; auxe[(size_t)(ROW_INFO + 4) * B] = info[4]; auxe[(size_t)(ROW_INFO + 5) * B] = info[5];
+            }
             auxe[(size_t)ROW_REWARD * B] = reward;
             bufs.flags[e] = (uint8_t)term; bufs.flags[B + e] = (uint8_t)trunc;
         }
@@ -356,7 +389,7 @@ __global__ __launch_bounds__(64) void vss_epl_kernel(RSX_HOT_ARGS, const Params 
                 atomicAdd(&bufs.metrics[1], 1ull);
                 if (info[4] > 0.0f) atomicAdd(&bufs.metrics[2], 1ull);
                 if (info[5] > 0.0f) atomicAdd(&bufs.metrics[3], 1ull);
-                atomicAdd(&bufs.metrics[4], (unsigned long long)__float2ll_rn(ep_ret * 1048576.0f));
+                atomicAdd(&bufs.metrics[4], (unsigned long long)__float2ll_rn(vss_episode_return(info) * 1048576.0f));
                 atomicAdd(&bufs.metrics[5], (unsigned long long)steps);
                 if (trunc && !term) atomicAdd(&bufs.metrics[6], 1ull);
                 // placement: the reference's sequential rejection sampling (vss_gym.py:194-233)
@@ -394,10 +427,15 @@ __global__ __launch_bounds__(64) void vss_epl_kernel(RSX_HOT_ARGS, const Params 
                     ou[k][0] = 0.0f; ou[k][1] = 0.0f;
                     r[k] = Body{};
                     r[k].x = nx[k]; r[k].y = ny[k];
-                    od[k] = nth[k]; wd[k] = 0.0f;
-                    r[k].th = od[k];
+                    r[k].th = nth[k];
+                    wdeg[k] = 0.0f;
                     sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
-                    write_obs<KIND, TASK>(P, row, k, true, false, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, wd[k], 0, 0.0f);
+                    write_obs<KIND, TASK>(P, row, k, true, false, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, 0.0f, 0, 0.0f);
+                    if (STEP) {   // this env's rows were written before the reset was known
+                        float* p = st + (size_t)(5 + 6 * k) * B;
+                        p[0] = r[k].x; p[B] = r[k].y; p[2 * B] = r[k].th; p[3 * B] = 0.0f; p[4 * B] = 0.0f; p[5 * B] = 0.0f;
+                        if (k >= 1) { auxe[(size_t)(ROW_OU + 2 * k) * B] = 0.0f; auxe[(size_t)(ROW_OU + 2 * k + 1) * B] = 0.0f; }
+                    }
                 }
                 ball = Body{};
                 ball.x = bx; ball.y = by;
@@ -421,18 +459,22 @@ __global__ __launch_bounds__(64) void vss_epl_kernel(RSX_HOT_ARGS, const Params 
 
     // ---- store (wire format) ----
     if (live) {
+        if (!STEP) {
 #pragma unroll
-        for (int k = 0; k < N; ++k) {
-            float* p = st + (size_t)(5 + 6 * k) * B;
-            p[0] = r[k].x; p[B] = r[k].y; p[2 * B] = od[k]; p[3 * B] = r[k].vx; p[4 * B] = r[k].vy; p[5 * B] = wd[k];
-            if (k >= 1) { auxe[(size_t)(ROW_OU + 2 * k) * B] = ou[k][0]; auxe[(size_t)(ROW_OU + 2 * k + 1) * B] = ou[k][1]; }
+            for (int k = 0; k < N; ++k) {
+                float* p = st + (size_t)(5 + 6 * k) * B;
+                p[0] = r[k].x; p[B] = r[k].y; p[2 * B] = r[k].th; p[3 * B] = r[k].vx; p[4 * B] = r[k].vy; p[5 * B] = wdeg[k];
+                if (k >= 1) { auxe[(size_t)(ROW_OU + 2 * k) * B] = ou[k][0]; auxe[(size_t)(ROW_OU + 2 * k + 1) * B] = ou[k][1]; }
+            }
         }
-        st[0] = ball.x; st[B] = ball.y; st[2 * B] = K::r_ball + ball.z; st[3 * B] = ball.vx; st[4 * B] = ball.vy;
-        st[(size_t)P.state_dim * B] = ball.vz;
-        st[(size_t)(P.state_dim + 1) * B] = ball.om;
+        st[0] = ball.x; st[B] = ball.y; st[3 * B] = ball.vx; st[4 * B] = ball.vy;
+        const float z_out = K::r_ball + ball.z;
+        if (z_out != z_in) st[2 * B] = z_out;
+        if (ball.vz != vz_in) st[(size_t)P.state_dim * B] = ball.vz;
+        if (ball.om != spin_in) st[(size_t)(P.state_dim + 1) * B] = ball.om;
         auxe[(size_t)ROW_STEPS * B] = __int_as_float(steps);
         auxe[(size_t)ROW_EPISODE * B] = __uint_as_float(episode);
-        auxe[(size_t)ROW_PREV_POT * B] = prev_pot; auxe[(size_t)ROW_EP_RET * B] = ep_ret;
+        auxe[(size_t)ROW_PREV_POT * B] = prev_pot;
     }
     if (counts_steps) bufs.metrics[0] = steps_before + (unsigned long long)P.num_envs * (unsigned long long)n_steps;
 }

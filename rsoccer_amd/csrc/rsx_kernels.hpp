@@ -845,6 +845,12 @@ __device__ __forceinline__ void write_obs(const Params& P, float* __restrict__ r
     }
 }
 
+// Return of a finished VSS-v0 episode, from its cumulative reward terms (vss_gym.py:151-158,186-190):
+// shaping sums + 10 per goal for, -10 per goal against.  (No running sum of rewards is kept.)
+__device__ __forceinline__ float vss_episode_return(const float* info) {
+    return ((info[1] + info[2]) + info[3]) + 10.0f * info[0];
+}
+
 // vss_gym.py:235-254
 __device__ __forceinline__ float vss_wheel(float a) {
     using T = TC<RSX_TASK_VSS_V0>;
@@ -1129,7 +1135,8 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
     if (is_ball) {
 #pragma unroll
         for (int i = 0; i < ID; ++i) info[i] = auxe[(size_t)(ROW_INFO + i) * B];
-        prev_pot = auxe[(size_t)ROW_PREV_POT * B]; ep_ret = auxe[(size_t)ROW_EP_RET * B];
+        prev_pot = auxe[(size_t)ROW_PREV_POT * B];
+        if (TASK != RSX_TASK_VSS_V0) ep_ret = auxe[(size_t)ROW_EP_RET * B];   // VSS-v0: derived from the info terms
     }
     // metrics[0] (env-steps) is counted on the device by ONE lane of the grid: launches of a handle
     // are stream-ordered, so a plain read-modify-write is race free and costs no atomic
@@ -1417,7 +1424,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
                     atomicAdd(&bufs.metrics[1], 1ull);
                     if (info[4] > 0.0f) atomicAdd(&bufs.metrics[2], 1ull);
                     if (info[5] > 0.0f) atomicAdd(&bufs.metrics[3], 1ull);
-                    atomicAdd(&bufs.metrics[4], (unsigned long long)__float2ll_rn(ep_ret * 1048576.0f));
+                    atomicAdd(&bufs.metrics[4], (unsigned long long)__float2ll_rn(vss_episode_return(info) * 1048576.0f));
                     atomicAdd(&bufs.metrics[5], (unsigned long long)steps);
                     if (trunc && !term) atomicAdd(&bufs.metrics[6], 1ull);
                 }
@@ -1507,7 +1514,10 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
     if (TASK == RSX_TASK_VSS_V0 && is_robot && b >= 1) {
         auxe[(size_t)(ROW_OU + 2 * b) * B] = ou0; auxe[(size_t)(ROW_OU + 2 * b + 1) * B] = ou1;
     }
-    if (is_ball) { auxe[(size_t)ROW_PREV_POT * B] = prev_pot; auxe[(size_t)ROW_EP_RET * B] = ep_ret; }
+    if (is_ball) {
+        auxe[(size_t)ROW_PREV_POT * B] = prev_pot;
+        if (TASK != RSX_TASK_VSS_V0) auxe[(size_t)ROW_EP_RET * B] = ep_ret;
+    }
     if (counts_steps) bufs.metrics[0] = steps_before + (unsigned long long)P.num_envs * (unsigned long long)n_steps;
     RSX_STAMP(6);
 #ifdef RSX_TIMING
