@@ -182,6 +182,13 @@ int rsx_task_step_n(rsx_sim* h, int n, void* stream);
  * steps; obs / reward / done buffers hold the values of the last step). */
 int rsx_task_rollout(rsx_sim* h, int n, void* stream);
 
+/* Debugging aid: number of non-finite floats in the state rows and, with a task attached, in the
+ * observations, rewards and info rows.  Synchronises `stream`.  With RSX_DEBUG_FINITE=1 in the
+ * environment every stepping call (rsx_step_dev, rsx_task_step, rsx_task_step_n, rsx_task_rollout)
+ * runs this scan afterwards and returns RSX_ERR_STATE when it finds one (the reference has no such
+ * guard: e.g. rsoccer_gym/vss/env_vss/vss_gym.py:298 divides by a distance that can be zero). */
+int rsx_check_finite(rsx_sim* h, int64_t* n_bad, void* stream);
+
 /* metrics, int64[RSX_METRICS], accumulated on device since attach (payload of the multi-GPU
  * all-reduce): 0 env_steps, 1 episodes, 2 goals_for (blue), 3 goals_against (yellow),
  * 4 sum of episode returns in 2^-20 fixed point, 5 sum of episode lengths,

@@ -683,7 +683,8 @@ static void SUF(task_reward)(SUF(rsxo_env)* e, const R* last, const R* cmds, int
             const R* r0 = s + 5;
             R rbx = bx - r0[0], rby = by - r0[1];
             R nrm = R_SQRT(rbx * rbx + rby * rby);
-            R mv = (rbx / nrm) * r0[3] + (rby / nrm) * r0[4];
+            /* vss_gym.py:298 divides unguarded; a robot exactly on the ball gets no move term here */
+            R mv = nrm > RC(0) ? (rbx / nrm) * r0[3] + (rby / nrm) * r0[4] : RC(0);
             R move = SUF(clampr)(mv * RC(2.5), RC(-5), RC(5));
             R energy = -(R_FABS(cmds[0]) + R_FABS(cmds[1]));
             R t_move = RC(0.2) * move, t_grad = RC(0.8) * grad, t_en = RC(2e-4) * energy;
@@ -736,7 +737,7 @@ static void SUF(task_reward)(SUF(rsxo_env)* e, const R* last, const R* cmds, int
         if (done) {
             R rdx = rc[0] - sh[0], rdy = rc[1] - sh[1];
             R dist_robs = R_SQRT(rdx * rdx + rdy * rdy);
-            e->info[0] = (dist_robs - dist) / dist_robs;
+            e->info[0] = dist_robs > RC(0) ? (dist_robs - dist) / dist_robs : RC(0);
         }
     } else { /* static_defenders.py:150-212,256-322; contested_possession.py:139-201 */
         const R* r0 = s + 5;

@@ -32,7 +32,7 @@ SYMBOLS = (
     "rsx_get_field_params", "rsx_reset", "rsx_step", "rsx_get_state", "rsx_set_state",
     "rsx_get_state_full", "rsx_dev_view_get", "rsx_step_dev", "rsx_task_attach",
     "rsx_task_view_get", "rsx_task_reset", "rsx_task_reset_to", "rsx_task_step",
-    "rsx_task_step_n", "rsx_task_rollout", "rsx_read_metrics",
+    "rsx_task_step_n", "rsx_task_rollout", "rsx_read_metrics", "rsx_check_finite",
 )
 
 
@@ -92,6 +92,7 @@ def load():
     lib.rsx_task_step_n.argtypes = [vp, ip, vp]
     lib.rsx_task_rollout.argtypes = [vp, ip, vp]
     lib.rsx_read_metrics.argtypes = [vp, vp, vp]
+    lib.rsx_check_finite.argtypes = [vp, C.POINTER(C.c_int64), vp]
     if lib.rsx_abi_version() != 2:
         raise RsxError("librsx_hip.so ABI version mismatch")
     _lib = lib
@@ -273,6 +274,12 @@ class Sim:
 
     def task_rollout(self, n, stream=None):
         _chk(self._lib.rsx_task_rollout(self._h, int(n), self._stream(stream)))
+
+    def check_finite(self, stream=None):
+        """Number of non-finite floats in state / obs / reward / info (debugging aid; synchronises)."""
+        n = C.c_int64(0)
+        _chk(self._lib.rsx_check_finite(self._h, C.byref(n), self._stream(stream)))
+        return int(n.value)
 
     def read_metrics(self, stream=None):
         out = np.zeros(N_METRICS, dtype=np.int64)

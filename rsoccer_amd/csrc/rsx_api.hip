@@ -7,6 +7,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <string>
@@ -57,6 +58,7 @@ struct rsx_sim {
     float *d_aux = nullptr, *d_obs = nullptr, *d_final_obs = nullptr, *d_actions = nullptr;
     uint8_t* d_flags = nullptr;
     unsigned long long* d_metrics = nullptr;
+    unsigned long long* d_check = nullptr;   // rsx_check_finite counter
     hipStream_t cap_stream = nullptr;
     std::map<int, hipGraphExec_t> graphs;
     std::vector<float> h_f32;
@@ -92,6 +94,14 @@ dim3 grid_for(const rsx_sim* h) {
 #ifdef RSX_TIMING
 unsigned long long* g_dbg = nullptr;  // development builds: s_memtime stamps
 #endif
+
+// debugging aid (rsx_check_finite / RSX_DEBUG_FINITE=1): counts the non-finite floats of a buffer
+__global__ void count_nonfinite_kernel(const float* __restrict__ p, size_t n, unsigned long long* out) {
+    unsigned long long bad = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        bad += !__builtin_isfinite(p[i]);
+    if (bad) atomicAdd(out, bad);
+}
 
 Buffers buffers_of(const rsx_sim* h, const float* actions) {
     Buffers b;
@@ -277,6 +287,8 @@ void free_all(rsx_sim* h) {
     if (h->pin_cmds) (void)hipHostFree(h->pin_cmds);
     if (h->pin_state) (void)hipHostFree(h->pin_state);
     h->pin_cmds = h->pin_state = nullptr;
+    if (h->d_check) (void)hipFree(h->d_check);
+    h->d_check = nullptr;
     if (h->arena_sim) (void)hipFree(h->arena_sim);
     if (h->arena_task) (void)hipFree(h->arena_task);
     h->arena_sim = h->arena_task = nullptr;
@@ -285,6 +297,39 @@ void free_all(rsx_sim* h) {
 size_t align_up(size_t n) { return (n + 255) & ~(size_t)255; }
 
 }  // namespace
+
+// state rows, and with a task attached observations, rewards and the cumulative info rows
+static int check_finite_impl(rsx_sim* h, int64_t* n_bad, hipStream_t s) {
+    if (!h->d_check) HIP_TRY(hipMalloc((void**)&h->d_check, sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(h->d_check, 0, sizeof(unsigned long long), s));
+    const size_t B = (size_t)h->P.num_envs;
+    auto scan = [&](const float* p, size_t n) {
+        const unsigned blocks = (unsigned)std::min<size_t>(2048, (n + 255) / 256);
+        hipLaunchKernelGGL(count_nonfinite_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, p, n, h->d_check);
+    };
+    scan(h->d_state, (size_t)(h->P.state_dim + X_ROWS) * B);
+    if (h->P.task != RSX_TASK_NONE) {
+        scan(h->d_obs, B * (size_t)h->P.obs_dim);
+        scan(h->d_aux + (size_t)ROW_REWARD * B, B);
+        scan(h->d_aux + (size_t)ROW_INFO * B, B * (size_t)h->M.info_dim);
+    }
+    HIP_TRY(hipGetLastError());
+    unsigned long long bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, h->d_check, sizeof(bad), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *n_bad = (int64_t)bad;
+    return RSX_OK;
+}
+
+// RSX_DEBUG_FINITE=1: every stepping call is followed by the scan (synchronous: a debugging mode)
+static int debug_finite(rsx_sim* h, hipStream_t s, const char* where) {
+    static const bool on = std::getenv("RSX_DEBUG_FINITE") != nullptr && std::getenv("RSX_DEBUG_FINITE")[0] == '1';
+    if (!on) return RSX_OK;
+    int64_t bad = 0;
+    if (int rc = check_finite_impl(h, &bad, s)) return rc;
+    if (bad) return fail(RSX_ERR_STATE, std::string("RSX_DEBUG_FINITE: ") + std::to_string(bad) + " non-finite value(s) after " + where);
+    return RSX_OK;
+}
 
 extern "C" {
 
@@ -448,7 +493,7 @@ int rsx_step_dev(rsx_sim* h, void* stream) {
     h->host_state_valid = false;
     launch_sim(h, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
-    return RSX_OK;
+    return debug_finite(h, (hipStream_t)stream, "rsx_step_dev");
 }
 
 int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, int max_episode_steps) {
@@ -537,7 +582,7 @@ int rsx_task_step(rsx_sim* h, const float* actions_dev, void* stream) {
     RSX_NEED_RESET(h);
     launch_task(h, actions_dev, 1, MODE_STEP, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
-    return RSX_OK;
+    return debug_finite(h, (hipStream_t)stream, "rsx_task_step");
 }
 
 int rsx_task_step_n(rsx_sim* h, int n, void* stream) {
@@ -548,7 +593,7 @@ int rsx_task_step_n(rsx_sim* h, int n, void* stream) {
     if (!use_graph) {
         for (int i = 0; i < n; ++i) launch_task(h, nullptr, 1, MODE_STEP, (hipStream_t)stream);
         HIP_TRY(hipGetLastError());
-        return RSX_OK;
+        return debug_finite(h, (hipStream_t)stream, "rsx_task_step_n");
     }
     auto it = h->graphs.find(n);
     if (it == h->graphs.end()) {
@@ -571,7 +616,13 @@ int rsx_task_rollout(rsx_sim* h, int n, void* stream) {
     if (n < 0) return fail(RSX_ERR_ARG, "n must be >= 0");  // 0 = load + store only (profiling)
     launch_task(h, nullptr, n, MODE_ROLLOUT, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
-    return RSX_OK;
+    return debug_finite(h, (hipStream_t)stream, "rsx_task_rollout");
+}
+
+int rsx_check_finite(rsx_sim* h, int64_t* n_bad, void* stream) {
+    RSX_ENTER(h);
+    if (!n_bad) return fail(RSX_ERR_ARG, "n_bad is null");
+    return check_finite_impl(h, n_bad, (hipStream_t)stream);
 }
 
 int rsx_read_metrics(rsx_sim* h, int64_t out[RSX_METRICS], void* stream) {

@@ -360,7 +360,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 prev_pot = pot;
                 float rbx = bx - r[0].x, rby = by - r[0].y;
                 float nrm = sqrtf(rbx * rbx + rby * rby);
-                float mv = (rbx / nrm) * r[0].vx + (rby / nrm) * r[0].vy;
+                float mv = nrm > 0.0f ? (rbx / nrm) * r[0].vx + (rby / nrm) * r[0].vy : 0.0f;   // unguarded in vss_gym.py:298
                 float move = clampf(mv * 2.5f, -5.0f, 5.0f);
                 float energy = -(fabsf(en0) + fabsf(en1));
                 float t_move = 0.2f * move, t_grad = 0.8f * grad, t_en = 2e-4f * energy;

@@ -1318,7 +1318,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
                         prev_pot = pot;
                         float rbx = bx - xr[0], rby = by - xr[1];
                         float nrm = sqrtf(rbx * rbx + rby * rby);
-                        float mv = (rbx / nrm) * xr[2] + (rby / nrm) * xr[3];
+                        float mv = nrm > 0.0f ? (rbx / nrm) * xr[2] + (rby / nrm) * xr[3] : 0.0f;   // unguarded in vss_gym.py:298
                         float move = clampf(mv * 2.5f, -5.0f, 5.0f);
                         float energy = -(fabsf(xr[4]) + fabsf(xr[5]));
                         float t_move = 0.2f * move, t_grad = 0.8f * grad, t_en = 2e-4f * energy;
@@ -1369,7 +1369,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
                     if (term) {
                         float rdx = rcx - shx, rdy = rcy - shy;
                         float dist_robs = sqrtf(rdx * rdx + rdy * rdy);
-                        info[0] = (dist_robs - dist) / dist_robs;
+                        info[0] = dist_robs > 0.0f ? (dist_robs - dist) / dist_robs : 0.0f;
                     }
                     success = term && rc_ir;
                 } else {  // static_defenders.py:150-212,256-322; contested_possession.py:139-201

@@ -640,6 +640,32 @@ def test_api_calls_leave_the_current_device_alone():
     assert torch.cuda.current_device() == 0
 
 
+def test_finite_check_and_debug_mode():
+    """rsx_check_finite counts non-finite floats; RSX_DEBUG_FINITE=1 turns every stepping call into a
+    checked one (RSX_ERR_STATE).  A NaN is planted through set_state."""
+    import subprocess, sys
+    L = _lib()
+    sim = L.Sim(0, 0, 3, 3, 25, 16)
+    sim.task_attach(1, 0, 0, 0)
+    sim.task_reset()
+    sim.task_step_n(20)
+    assert sim.check_finite() == 0
+    st = sim.get_state_full()
+    st[3, 5] = np.nan; st[7, 0] = np.inf
+    sim.set_state(st)
+    assert sim.check_finite() == 2
+    sim.close()
+    code = ("import numpy as np\nfrom rsoccer_amd import _lib as L\n"
+            "s = L.Sim(0, 0, 3, 3, 25, 16); s.task_attach(1, 0, 0, 0); s.task_reset(); s.task_step_n(5)\n"
+            "st = s.get_state_full(); st[3, 5] = np.nan; s.set_state(st)\n"
+            "try:\n    s.task_step(None)\n    print('NOT CAUGHT')\n"
+            "except L.RsxError as e:\n    print('CAUGHT', e)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root,
+                         env=dict(os.environ, RSX_DEBUG_FINITE="1", PYTHONPATH=root), timeout=300)
+    assert "CAUGHT" in res.stdout and "RSX_DEBUG_FINITE" in res.stdout and "NOT CAUGHT" not in res.stdout, res.stdout + res.stderr
+
+
 def test_metrics_env_steps_are_counted_on_the_device():
     """metrics[0] is part of the device vector (what the multi-GPU all-reduce sends), for single-step
     launches, C-side step loops and one-launch rollouts alike."""
