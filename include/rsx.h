@@ -149,6 +149,17 @@ int rsx_dev_view_get(rsx_sim* h, rsx_dev_view* out);
 /* advance all envs by time_step_ms using the commands currently in view.cmds */
 int rsx_step_dev(rsx_sim* h, void* stream);
 
+/* The same step, double-buffered: the new state is written to the handle's second state buffer,
+ * which then becomes the current one — the buffer that was current holds the PREVIOUS frame
+ * (the reference's `last_frame`, vss_gym_base.py:80) without a copy.  rsx_state_buffers returns both
+ * pointers (layout of rsx_dev_view.state); after every flip they trade places. */
+int rsx_step_dev_flip(rsx_sim* h, void* stream);
+int rsx_state_buffers(rsx_sim* h, float** current, float** other);
+/* reset(ball, blue, yellow) of rsim.py:38 from DEVICE arrays (f32, same shapes as rsx_reset),
+ * env_mask_dev [B] u8 device or NULL: stream-ordered, no host copy, no synchronisation. */
+int rsx_reset_dev(rsx_sim* h, const float* ball_dev, const float* blue_dev, const float* yellow_dev,
+                  const uint8_t* env_mask_dev, void* stream);
+
 /* ---- fused task epilogues -------------------------------------------------------------- */
 
 /* Attach a task to a handle whose kind / robot counts match it (VSS_V0: VSS, n_blue >= 1;

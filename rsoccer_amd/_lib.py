@@ -30,7 +30,8 @@ METRIC_NAMES = ("env_steps", "episodes", "goals_for", "goals_against", "return_s
 SYMBOLS = (
     "rsx_abi_version", "rsx_last_error", "rsx_device_count", "rsx_create", "rsx_destroy",
     "rsx_get_field_params", "rsx_reset", "rsx_step", "rsx_get_state", "rsx_set_state",
-    "rsx_get_state_full", "rsx_dev_view_get", "rsx_step_dev", "rsx_task_attach",
+    "rsx_get_state_full", "rsx_dev_view_get", "rsx_step_dev", "rsx_step_dev_flip", "rsx_state_buffers",
+    "rsx_reset_dev", "rsx_task_attach",
     "rsx_task_view_get", "rsx_task_reset", "rsx_task_reset_to", "rsx_task_step",
     "rsx_task_step_n", "rsx_task_rollout", "rsx_read_metrics", "rsx_check_finite",
 )
@@ -84,6 +85,9 @@ def load():
     lib.rsx_get_state_full.argtypes = [vp, vp, vp]
     lib.rsx_dev_view_get.argtypes = [vp, C.POINTER(DevView)]
     lib.rsx_step_dev.argtypes = [vp, vp]
+    lib.rsx_step_dev_flip.argtypes = [vp, vp]
+    lib.rsx_state_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    lib.rsx_reset_dev.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.rsx_task_attach.argtypes = [vp, ip, C.c_uint64, C.c_uint64, ip]
     lib.rsx_task_view_get.argtypes = [vp, C.POINTER(TaskView)]
     lib.rsx_task_reset.argtypes = [vp, vp]
@@ -212,6 +216,42 @@ class Sim:
     # ---- device-resident path ----
     def step_dev(self, stream=None):
         _chk(self._lib.rsx_step_dev(self._h, self._stream(stream)))
+
+    def step_dev_flip(self, stream=None):
+        """Double-buffered step_dev(): the two tensors of state_buffers() trade roles."""
+        _chk(self._lib.rsx_step_dev_flip(self._h, self._stream(stream)))
+
+    def state_buffers(self):
+        """(current, other): two [state_dim+2, B] float32 views; after each step_dev_flip() the one
+        that was current holds the previous frame."""
+        cur, oth = C.c_void_p(), C.c_void_p()
+        _chk(self._lib.rsx_state_buffers(self._h, C.byref(cur), C.byref(oth)))
+        shape = (self.state_dim + X_ROWS, self.num_envs)
+        return self._tensor(cur.value, shape, "<f4"), self._tensor(oth.value, shape, "<f4")
+
+    def reset_dev(self, ball, blue, yellow, env_mask=None, stream=None):
+        """reset() from device tensors: ball [B,4], blue [B,nb,3], yellow [B,ny,3] float32 CUDA,
+        env_mask [B] uint8/bool CUDA or None.  Stream-ordered, no host copy."""
+        import torch
+        def prep(t, shape):
+            if t is None:
+                return None
+            t = t.to(dtype=torch.float32).contiguous()
+            if tuple(t.shape) != shape:
+                raise ValueError(f"expected {shape}, got {tuple(t.shape)}")
+            return t
+        B = self.num_envs
+        ball = prep(ball, (B, 4))
+        blue = prep(blue, (B, self.n_blue, 3)) if self.n_blue else None
+        yellow = prep(yellow, (B, self.n_yellow, 3)) if self.n_yellow else None
+        m = None
+        if env_mask is not None:
+            m = env_mask.to(dtype=torch.uint8).contiguous()
+            if tuple(m.shape) != (B,):
+                raise ValueError(f"env_mask must be [{B}]")
+        ptr = lambda t: None if t is None else t.data_ptr()
+        self._keep_reset = (ball, blue, yellow, m)   # alive until the launch has consumed them
+        _chk(self._lib.rsx_reset_dev(self._h, ptr(ball), ptr(blue), ptr(yellow), ptr(m), self._stream(stream)))
 
     def _tensor(self, ptr, shape, typestr):
         import torch

@@ -54,6 +54,7 @@ struct rsx_sim {
     char* arena_sim = nullptr;   // state | cmds
     char* arena_task = nullptr;  // aux | obs | final_obs | flags | actions | metrics
     float* d_state = nullptr;
+    float* d_state_alt = nullptr;   // second state buffer of rsx_step_dev_flip (allocated on first use)
     float* d_cmds = nullptr;
     float *d_aux = nullptr, *d_obs = nullptr, *d_final_obs = nullptr, *d_actions = nullptr;
     uint8_t* d_flags = nullptr;
@@ -127,13 +128,13 @@ void pick_variant(rsx_sim* h) {
 }
 
 // hot arguments first (preloaded into SGPRs, see RSX_HOT_ARGS), then the by-value structs
-#define RSX_LAUNCH_SIM(kernel, P, b) hipLaunchKernelGGL((kernel), grid, dim3(64), 0, s, (b).state, (b).aux, (b).cmds, (b).flags, \
+#define RSX_LAUNCH_SIM(kernel, P, b) hipLaunchKernelGGL((kernel), grid, dim3(64), 0, s, (b).state, state_out, (b).cmds, (b).flags, \
                                                         (P).num_envs, (P).state_dim, (int)(grid.x >> 3), 1, (P), (b))
 #define RSX_LAUNCH(kernel, P, b, n) hipLaunchKernelGGL((kernel), grid, dim3(64), 0, s, (b).state, (b).aux, (b).actions, (b).flags, \
                                                        (P).num_envs, (P).state_dim, (int)(grid.x >> 3), (n), (P), (b))
 
 template <int KIND>
-void launch_sim_k(const rsx_sim* h, hipStream_t s) {
+void launch_sim_k(const rsx_sim* h, float* state_out, hipStream_t s) {
     const dim3 grid = grid_for(h);
     const Buffers b = buffers_of(h, nullptr);
     if (KIND == RSX_KIND_VSS && h->NR == 6) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 8, (KIND == RSX_KIND_VSS ? 6 : 0)>), h->P, b); return; }
@@ -149,9 +150,27 @@ void launch_sim_k(const rsx_sim* h, hipStream_t s) {
     }
 }
 
-void launch_sim(const rsx_sim* h, hipStream_t s) {
-    if (h->P.kind == RSX_KIND_VSS) launch_sim_k<RSX_KIND_VSS>(h, s);
-    else launch_sim_k<RSX_KIND_SSL>(h, s);
+// state_out: where the new state is written (nullptr = in place)
+void launch_sim(const rsx_sim* h, hipStream_t s, float* state_out = nullptr) {
+    if (!state_out) state_out = h->d_state;
+    if (h->P.kind == RSX_KIND_VSS) launch_sim_k<RSX_KIND_VSS>(h, state_out, s);
+    else launch_sim_k<RSX_KIND_SSL>(h, state_out, s);
+}
+
+// teleport of rsim.py:52-75 from device arrays: one thread per env, rows are coalesced across threads
+__global__ void reset_dev_kernel(float* __restrict__ st, const float* __restrict__ ball, const float* __restrict__ blue,
+                                 const float* __restrict__ yellow, const uint8_t* __restrict__ mask, int B, int rows,
+                                 int rs, int nb, int ny, float r_ball) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B || (mask && !mask[e])) return;
+    for (int f = 0; f < rows; ++f) st[(size_t)f * B + e] = 0.0f;
+    st[0 * (size_t)B + e] = ball[4 * (size_t)e + 0]; st[1 * (size_t)B + e] = ball[4 * (size_t)e + 1]; st[2 * (size_t)B + e] = r_ball;
+    st[3 * (size_t)B + e] = ball[4 * (size_t)e + 2]; st[4 * (size_t)B + e] = ball[4 * (size_t)e + 3];
+    for (int k = 0; k < nb + ny; ++k) {
+        const float* src = k < nb ? blue + ((size_t)e * nb + k) * 3 : yellow + ((size_t)e * ny + (k - nb)) * 3;
+        const size_t r = (size_t)(5 + rs * k);
+        st[(r + 0) * B + e] = src[0]; st[(r + 1) * B + e] = src[1]; st[(r + 2) * B + e] = src[2];
+    }
 }
 
 template <int KIND, int TASK, int NRS, int MODE>
@@ -287,6 +306,8 @@ void free_all(rsx_sim* h) {
     if (h->pin_cmds) (void)hipHostFree(h->pin_cmds);
     if (h->pin_state) (void)hipHostFree(h->pin_state);
     h->pin_cmds = h->pin_state = nullptr;
+    if (h->d_state_alt) (void)hipFree(h->d_state_alt);
+    h->d_state_alt = nullptr;
     if (h->d_check) (void)hipFree(h->d_check);
     h->d_check = nullptr;
     if (h->arena_sim) (void)hipFree(h->arena_sim);
@@ -494,6 +515,46 @@ int rsx_step_dev(rsx_sim* h, void* stream) {
     launch_sim(h, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return debug_finite(h, (hipStream_t)stream, "rsx_step_dev");
+}
+
+static int ensure_alt(rsx_sim* h) {
+    if (h->d_state_alt) return RSX_OK;
+    const size_t sbytes = (size_t)(h->P.state_dim + X_ROWS) * h->P.num_envs * sizeof(float);
+    HIP_TRY(hipMalloc((void**)&h->d_state_alt, sbytes));
+    HIP_TRY(hipMemset(h->d_state_alt, 0, sbytes));
+    HIP_TRY(hipDeviceSynchronize());
+    return RSX_OK;
+}
+
+int rsx_state_buffers(rsx_sim* h, float** current, float** other) {
+    RSX_ENTER(h);
+    if (!current || !other) return fail(RSX_ERR_ARG, "null argument");
+    if (int rc = ensure_alt(h)) return rc;
+    *current = h->d_state; *other = h->d_state_alt;
+    h->host_state_cache = false; h->host_state_valid = false;
+    return RSX_OK;
+}
+
+int rsx_step_dev_flip(rsx_sim* h, void* stream) {
+    RSX_ENTER(h);
+    if (int rc = ensure_alt(h)) return rc;
+    h->host_state_valid = false;
+    launch_sim(h, (hipStream_t)stream, h->d_state_alt);
+    HIP_TRY(hipGetLastError());
+    std::swap(h->d_state, h->d_state_alt);
+    return debug_finite(h, (hipStream_t)stream, "rsx_step_dev_flip");
+}
+
+int rsx_reset_dev(rsx_sim* h, const float* ball_dev, const float* blue_dev, const float* yellow_dev,
+                  const uint8_t* env_mask_dev, void* stream) {
+    RSX_ENTER(h);
+    if (!ball_dev || (h->P.n_blue && !blue_dev) || (h->P.n_yellow && !yellow_dev)) return fail(RSX_ERR_ARG, "null placement array");
+    h->host_state_valid = false;
+    const int B = h->P.num_envs;
+    hipLaunchKernelGGL(reset_dev_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->d_state, ball_dev, blue_dev,
+                       yellow_dev, env_mask_dev, B, h->P.state_dim + X_ROWS, h->M.rs, h->P.n_blue, h->P.n_yellow, (float)h->M.field[6]);
+    HIP_TRY(hipGetLastError());
+    return RSX_OK;
 }
 
 int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, int max_episode_steps) {

@@ -758,7 +758,8 @@ template <int KIND, int L, int NR>
 __global__ __launch_bounds__(64) void sim_step_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
     Params P = P_; P.num_envs = hp_num_envs; P.state_dim = hp_state_dim;
     Buffers bufs = bufs_; bufs.state = hp_state; bufs.cmds = hp_in;   // hp_in: the command buffer
-    (void)hp_aux; (void)hp_flags; (void)hp_n_steps;
+    float* const state_out = hp_aux;   // this kernel's second pointer slot: where the new state goes (== hp_state: in place)
+    (void)hp_flags; (void)hp_n_steps;
     using K = KC<KIND>;
     constexpr int G = 64 / L;
     constexpr int CD = ModelD<KIND>::cmd_dim;
@@ -789,7 +790,7 @@ __global__ __launch_bounds__(64) void sim_step_kernel(RSX_HOT_ARGS, const Params
         od = o.th; wd = o.om * K::rad2deg;
         if (KIND == RSX_KIND_SSL) wheel_speeds<KIND>(P, o, w);
     }
-    store_body<KIND>(P, bufs.state, e, b, is_robot, is_ball, o, od, wd, w, P.n_sub != 0);
+    store_body<KIND>(P, state_out, e, b, is_robot, is_ball, o, od, wd, w, P.n_sub != 0 || state_out != hp_state);
 }
 
 // =============================================================================================

@@ -45,24 +45,26 @@ class VecFrame:
         self.ball = _Rows(state, 0, ("x", "y", "z", "v_x", "v_y"))
         self.robots_blue = {i: _Rows(state, 5 + w * i, block) for i in range(n_blue)}
         self.robots_yellow = {i: _Rows(state, 5 + w * (n_blue + i), block) for i in range(n_yellow)}
+        self._shape = (n_blue, n_yellow, kind)
 
     def clone(self):
-        f = object.__new__(VecFrame)
-        st = self.state.clone()
-        f.state = st
-        f.ball = _Rows(st, 0, ("x", "y", "z", "v_x", "v_y"))
-        rb = lambda rows: {i: _Rows(st, min(r._index.values()), tuple(r._index)) for i, r in rows.items()}
-        f.robots_blue, f.robots_yellow = rb(self.robots_blue), rb(self.robots_yellow)
-        return f
+        return VecFrame(self.state.clone(), *self._shape)
 
 
 class _VecBaseEnv:
+    """``num_envs`` envs behind the four hooks of the reference's base classes, with the episode
+    bookkeeping of ``gymnasium.vector`` done ON THE DEVICE: ``step()`` sets ``truncated`` from the
+    registry's TimeLimit (``max_episode_steps``), re-places the envs whose episode ended inside the
+    same call (``info["final_obs"]`` keeps their terminal observation) and never copies anything
+    between host and device — provided ``_get_initial_positions`` returns device tensors.  The
+    previous frame (``self.last_frame``, what reward hooks difference against) is the simulator's
+    second state buffer (``rsx_step_dev_flip``), not a clone."""
     KIND = None
     NORM_BOUNDS = 1.2
     _LEVER_ARM = 0.04
 
     def __init__(self, field_type, n_robots_blue, n_robots_yellow, time_step, num_envs, device=0,
-                 keep_last_frame=True):
+                 keep_last_frame=True, max_episode_steps=None, auto_reset=True):
         import torch
         self._torch = torch
         self.num_envs = int(num_envs)
@@ -70,6 +72,8 @@ class _VecBaseEnv:
         self.time_step = time_step
         self.n_robots_blue, self.n_robots_yellow = n_robots_blue, n_robots_yellow
         self.field_type = field_type
+        self.max_episode_steps = max_episode_steps
+        self.auto_reset = auto_reset
         self.sim = _lib.Sim(self.KIND, field_type, n_robots_blue, n_robots_yellow, int(time_step * 1000),
                             self.num_envs, int(device))
         self.field = Field(**self.sim.get_field_params())
@@ -77,34 +81,65 @@ class _VecBaseEnv:
         self.max_v = (self.field.rbt_motor_max_rpm / 60) * 2 * np.pi * self.field.rbt_wheel_radius
         self.max_w = float(np.rad2deg(self.max_v / self._LEVER_ARM))
         n = n_robots_blue + n_robots_yellow
-        self.frame = VecFrame(self.sim.state_tensor(), n_robots_blue, n_robots_yellow, self.KIND)
-        self.commands = self.sim.cmds_tensor().view(n, self.sim.cmd_dim, self.num_envs)
         self.keep_last_frame = keep_last_frame
+        if keep_last_frame:   # two state buffers that trade places every step
+            cur, oth = self.sim.state_buffers()
+            self.frame = VecFrame(cur, n_robots_blue, n_robots_yellow, self.KIND)
+            self._other = VecFrame(oth, n_robots_blue, n_robots_yellow, self.KIND)
+        else:
+            self.frame = VecFrame(self.sim.state_tensor(), n_robots_blue, n_robots_yellow, self.KIND)
+            self._other = None
+        self.commands = self.sim.cmds_tensor().view(n, self.sim.cmd_dim, self.num_envs)
         self.last_frame = None
         self.steps = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+        self._zeros = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
 
     def _stream(self):
         return self._torch.cuda.current_stream(self.device).cuda_stream
 
+    def _place(self, env_mask):
+        """teleport the envs selected by env_mask ([B] bool device tensor, host array or None = all)"""
+        torch = self._torch
+        ball, blue, yellow = self._get_initial_positions()
+        if isinstance(ball, torch.Tensor):     # device placement: stream-ordered, no host copy, no sync
+            m = None if env_mask is None else torch.as_tensor(env_mask, device=self.device)
+            self.sim.reset_dev(ball, blue, yellow, m, self._stream())
+        else:                                  # host arrays (robosim.reset format): PCIe + synchronisation
+            m = env_mask.cpu().numpy() if isinstance(env_mask, torch.Tensor) else env_mask
+            self.sim.reset(ball, blue, yellow, m, self._stream())
+
     def step(self, action):
+        torch = self._torch
         self.steps += 1
         self.commands.zero_()
         self._get_commands(action)          # fills self.commands
         if self.keep_last_frame:
-            self.last_frame = self.frame.clone()
-        self.sim.step_dev(self._stream())
+            self.sim.step_dev_flip(self._stream())
+            self.frame, self._other = self._other, self.frame
+            self.last_frame = self._other
+        else:
+            self.sim.step_dev(self._stream())
         obs = self._frame_to_observations()
         reward, done = self._calculate_reward_and_done()
-        return obs, reward, done, self._torch.zeros_like(done), {}
+        done = done.to(torch.bool)
+        truncated = self.steps >= self.max_episode_steps if self.max_episode_steps else self._zeros
+        info = {}
+        if self.auto_reset:
+            ended = done | truncated
+            info["final_obs"] = obs
+            self._place(ended)
+            self.steps.masked_fill_(ended, 0)
+            # the placement wrote the CURRENT buffer; reset envs get their first observation
+            obs = torch.where(ended[:, None], self._frame_to_observations(), obs)
+        return obs, reward, done, truncated, info
 
     def reset(self, env_mask=None):
-        """(Re)place the envs selected by ``env_mask`` (host bool array, default all)."""
-        ball, blue, yellow = self._get_initial_positions()
-        self.sim.reset(ball, blue, yellow, env_mask, self._stream())
+        """(Re)place the envs selected by ``env_mask`` (bool device tensor or host array, default all)."""
+        self._place(env_mask)
         if env_mask is None:
             self.steps.zero_()
         else:
-            self.steps[self._torch.as_tensor(np.asarray(env_mask, dtype=bool), device=self.device)] = 0
+            self.steps.masked_fill_(self._torch.as_tensor(env_mask, device=self.device).to(self._torch.bool), 0)
         self.last_frame = None
         return self._frame_to_observations(), {}
 
@@ -125,7 +160,8 @@ class _VecBaseEnv:
         raise NotImplementedError
 
     def _get_initial_positions(self):
-        """returns host arrays ball [B,4], blue [B,nb,3], yellow [B,ny,3]"""
+        """returns ball [B,4], blue [B,nb,3], yellow [B,ny,3] — float32 device tensors (no host
+        traffic) or host arrays (the robosim.reset format)"""
         raise NotImplementedError
 
     # ---- normalisation helpers (vss_gym_base.py:213-220) ----

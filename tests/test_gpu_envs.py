@@ -169,7 +169,7 @@ def test_batched_hooks_env_matches_fused_kernel():
 
     class Task(VecVSSBaseEnv):
         def __init__(self, n):
-            super().__init__(0, 3, 3, 0.025, n)
+            super().__init__(0, 3, 3, 0.025, n, auto_reset=False)
             self.rng = np.random.default_rng(0)
 
         def _get_commands(self, action):
@@ -221,6 +221,122 @@ def test_batched_hooks_env_matches_fused_kernel():
     assert float(env.frame.robots_blue[0].v_x.mean()) > 0.1      # the agent robot did move
     assert float(env.frame.robots_yellow[1].v_x.abs().max()) == 0.0
     env.close()
+
+
+def _hook_task(n, device_placement, **kw):
+    import torch
+    from rsoccer_amd.vec import VecVSSBaseEnv
+
+    class Task(VecVSSBaseEnv):
+        """VSS-v0-shaped task written with the batched hooks"""
+
+        def __init__(self):
+            super().__init__(0, 3, 3, 0.025, n, **kw)
+            g = torch.Generator(device="cuda"); g.manual_seed(3)
+            self.gen = g
+
+        def _get_commands(self, action):
+            v = torch.clamp(action * self.max_v, -self.max_v, self.max_v) / self.field.rbt_wheel_radius
+            self.commands[0, 0].copy_(v[:, 0]); self.commands[0, 1].copy_(v[:, 1])
+
+        def _frame_to_observations(self):
+            f = self.frame
+            cols = [self.norm_pos(f.ball.x), self.norm_pos(f.ball.y)]
+            for i in range(3):
+                cols += [self.norm_pos(f.robots_blue[i].x), self.norm_pos(f.robots_blue[i].y)]
+            return torch.stack(cols, 1)
+
+        def _calculate_reward_and_done(self):
+            return self.frame.ball.x - self.last_frame.ball.x, self.frame.robots_blue[0].x > -0.45
+
+        def _get_initial_positions(self):
+            B = self.num_envs
+            ball = torch.zeros(B, 4, device="cuda"); ball[:, :2] = torch.rand(B, 2, device="cuda", generator=self.gen) * 0.4 - 0.2
+            blue = torch.zeros(B, 3, 3, device="cuda"); yellow = torch.zeros(B, 3, 3, device="cuda")
+            for k in range(3):
+                blue[:, k, 0] = -0.5; blue[:, k, 1] = 0.3 * (k - 1)
+                yellow[:, k, 0] = 0.5; yellow[:, k, 1] = 0.3 * (k - 1); yellow[:, k, 2] = 180.0
+            if device_placement:
+                return ball, blue, yellow
+            return ball.cpu().numpy().astype(np.float64), blue.cpu().numpy().astype(np.float64), yellow.cpu().numpy().astype(np.float64)
+    return Task()
+
+
+def test_batched_hooks_timelimit_and_auto_reset_stay_on_the_device():
+    """_VecBaseEnv: TimeLimit (`truncated` is really set), same-step auto-reset from DEVICE placements,
+    last_frame from the second state buffer — and no host<->device copy or synchronisation in step()
+    (torch's sync-debug mode turns any into an error; the engine calls are launches only)."""
+    import torch
+    env = _hook_task(256, True, max_episode_steps=7)
+    obs, _ = env.reset()
+    act = torch.zeros(256, 2, device="cuda"); act[:128] = 1.0          # half of the envs drive forward
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        log = []
+        for t in range(16):
+            prev_ball = env.frame.ball.x.clone()
+            obs, rew, done, trunc, info = env.step(act)
+            log.append((obs, rew, done, trunc, info["final_obs"], env.steps.clone(), prev_ball, env.last_frame.ball.x.clone()))
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    for t, (obs, rew, done, trunc, fin, steps, prev_ball, last_ball) in enumerate(log):
+        assert torch.equal(last_ball, prev_ball)                      # last_frame IS the pre-step state
+        ended = (done | trunc).cpu().numpy()
+        if t == 6:                                                    # TimeLimit: every env not already re-started
+            assert trunc.cpu().numpy()[128:].all()
+        assert (steps.cpu().numpy()[ended] == 0).all() and (steps.cpu().numpy()[~ended] > 0).all()
+        o, f = obs.cpu().numpy(), fin.cpu().numpy()
+        assert np.array_equal(o[~ended], f[~ended])
+        if ended.any():                                               # re-placed: robots back on their marks
+            assert np.allclose(o[ended][:, 2], env.norm_pos(torch.tensor(-0.5)).item())
+            assert not np.array_equal(o[ended], f[ended])
+    assert any(l[2].any().item() for l in log) and any(l[3].any().item() for l in log)
+    env.close()
+    # host-array placements still work (robosim.reset format), with copies
+    env = _hook_task(32, False, max_episode_steps=5)
+    env.reset()
+    for _ in range(6):
+        obs, rew, done, trunc, info = env.step(torch.zeros(32, 2, device="cuda"))
+    assert int(env.steps.max().item()) == 1
+    env.close()
+
+
+def test_scalar_hook_adapter_equals_independent_single_envs():
+    """VecScalarHookEnv: unmodified reference-shaped task classes (scalar hooks, vss_gym_base.py:197-211)
+    as slots of ONE batched simulator give exactly what the same classes give as independent
+    single-env objects (same global random streams, same call order)."""
+    from rsoccer_amd.ssl.ssl_hw_challenge import SSLHWStaticDefendersEnv
+    from rsoccer_amd.vec import VecScalarHookEnv
+    from rsoccer_amd.vss.env_vss import VSSEnv
+    for cls, kw, T, limit in ((VSSEnv, {}, 60, 25), (SSLHWStaticDefendersEnv, {"field_type": 2}, 40, 15)):
+        B = 6
+        arng = np.random.default_rng(1)
+        adim = cls(**kw).action_space.shape[0]
+        actions = arng.uniform(-1, 1, (T, B, adim)).astype(np.float32)
+        random.seed(9); np.random.seed(9)
+        vec = VecScalarHookEnv(cls, B, max_episode_steps=limit, **kw)
+        o0, _ = vec.reset()
+        got = [vec.step(actions[t]) for t in range(T)]
+        vec.close()
+        random.seed(9); np.random.seed(9)
+        envs = [cls(**kw) for _ in range(B)]
+        obs = np.stack([e.reset()[0] for e in envs])
+        assert np.array_equal(obs, o0)
+        el = np.zeros(B, int)
+        for t in range(T):
+            outs = [e.step(actions[t, i].copy()) for i, e in enumerate(envs)]   # NB: np.random order == adapter's (OU per env, in order)
+            obs = np.stack([o[0] for o in outs]); rew = np.array([o[1] for o in outs]); term = np.array([bool(o[2]) for o in outs])
+            el += 1
+            trunc = el >= limit
+            assert np.array_equal(got[t][4]["final_obs"], obs) and np.array_equal(got[t][1], rew), (cls.__name__, t)
+            assert np.array_equal(got[t][2], term) and np.array_equal(got[t][3], trunc)
+            for i in np.nonzero(term | trunc)[0]:
+                obs[i] = envs[i].reset()[0]; el[i] = 0
+            assert np.array_equal(got[t][0], obs)
+        for e in envs:
+            e.close()
 
 
 @pytest.mark.parametrize("env_id", ["VSS-v0", "SSLStaticDefenders-v0", "SSLDribbling-v0",
