@@ -50,6 +50,14 @@ extern "C" {
 #define RSX_TASK_SSL_DRIBBLING        3 /* ssl/ssl_hw_challenge/dribbling.py:11         (obs 21, act 4)*/
 #define RSX_TASK_SSL_CONTESTED        4 /* ssl/ssl_hw_challenge/contested_possession.py:11 (obs 14, act 5)*/
 #define RSX_TASK_SSL_PASS_ENDURANCE   5 /* ssl/ssl_hw_challenge/pass_endurance.py:11    (obs 16, act 3)*/
+/* synthetic SSL task in the style of the reference's example env (README.md:78-110) for team sizes no
+ * registered id covers (BASELINE.json configs[3]: 11v11 on the division-A field): EVERY robot is
+ * commanded — action [N][4] = v_x, v_y (robot-local, x 2.5 m/s), v_theta (x 10 rad/s), kick (5 m/s
+ * when > 0.9) — obs = normalised ball and robot positions (2 + 2N), reward +1 / -1 and done on a goal
+ * for blue / yellow.  Line-up: jittered 6 x 4 grid over the field (SCRIMMAGE) or packed around the ball,
+ * the worst case for the all-pairs contact sweep (SCRIMMAGE_CROWDED). */
+#define RSX_TASK_SSL_SCRIMMAGE         6
+#define RSX_TASK_SSL_SCRIMMAGE_CROWDED 7
 
 /* error codes */
 #define RSX_OK              0
@@ -84,9 +92,9 @@ typedef struct rsx_dev_view {
 
 typedef struct rsx_task_view {
     int32_t  task;
-    int32_t  obs_dim;       /* 40 | 24 | 21 | 14 | 16                                        */
-    int32_t  act_dim;       /* 2 | 5 | 4 | 5 | 3                                             */
-    int32_t  info_dim;      /* 6 | 8 | 1 | 9 | 2 : cumulative reward-shaping terms, order of the
+    int32_t  obs_dim;       /* 40 | 24 | 21 | 14 | 16 | 2 + 2N                               */
+    int32_t  act_dim;       /* 2 | 5 | 4 | 5 | 3 | 4N                                        */
+    int32_t  info_dim;      /* 6 | 8 | 1 | 9 | 2 | 2 : cumulative reward-shaping terms, order of the
                                reference's reward_shaping_total dict (dribbling, which has
                                none: its checkpoint counter)                                 */
     int32_t  max_episode_steps;
@@ -160,12 +168,19 @@ int rsx_state_buffers(rsx_sim* h, float** current, float** other);
 int rsx_reset_dev(rsx_sim* h, const float* ball_dev, const float* blue_dev, const float* yellow_dev,
                   const uint8_t* env_mask_dev, void* stream);
 
+/* n steps with commands drawn on the device instead of read from view.cmds (benchmark / soak mode of
+ * the raw simulator): robot k of env e takes Philox block
+ * (e, first_tick + i, k, 4) keyed by `seed` in launch i — VSS: wheel speeds U(-1, 1) x the motor
+ * limit; SSL: robot-local velocities U(-1, 1) x (2.5 m/s, 2.5 m/s, 10 rad/s). */
+int rsx_step_dev_random(rsx_sim* h, int n, uint64_t seed, uint32_t first_tick, void* stream);
+
 /* ---- fused task epilogues -------------------------------------------------------------- */
 
 /* Attach a task to a handle whose kind / robot counts match it (VSS_V0: VSS, n_blue >= 1;
- * STATIC_DEFENDERS: SSL 1vN; DRIBBLING: SSL 1v4; CONTESTED: SSL 1v1; PASS_ENDURANCE: SSL 2v0).  seed + (env_id_base + local env index) key every random draw,
+ * STATIC_DEFENDERS: SSL 1vN; DRIBBLING: SSL 1v4; CONTESTED: SSL 1v1; PASS_ENDURANCE: SSL 2v0;
+ * SCRIMMAGE / SCRIMMAGE_CROWDED: SSL, any team sizes).  seed + (env_id_base + local env index) key every random draw,
  * so results do not depend on batch size, batch position or sharding.
- * max_episode_steps <= 0 selects the registry value (1200 / 1000 / 4800 / 1200 / 1200). */
+ * max_episode_steps <= 0 selects the registry value (1200 / 1000 / 4800 / 1200 / 1200; scrimmage 1200). */
 int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base,
                     int max_episode_steps);
 int rsx_task_view_get(rsx_sim* h, rsx_task_view* out);

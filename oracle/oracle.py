@@ -92,6 +92,12 @@ class OracleEnv:
         cmds = np.ascontiguousarray(cmds, dtype=np.float64).reshape(self.N * self.C)
         self._f("rsxo_step")(self.h, _d(cmds))
 
+    def step_random(self, seed, env_id, tick):
+        """step() with commands drawn from Philox (mirror of rsx_step_dev_random)"""
+        f = self._f("rsxo_step_random")
+        f.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32]
+        f(self.h, int(seed), int(env_id), int(tick))
+
     def get_state(self):
         out = np.zeros(self.state_dim)
         self._f("rsxo_get_state")(self.h, _d(out))
@@ -117,9 +123,9 @@ class OracleEnv:
                         2: 4 + 8 * self.n_blue + 2 * self.n_yellow,
                         3: 5 + 8 * self.n_blue + 2 * self.n_yellow,
                         4: 4 + 8 * self.n_blue + 2 * self.n_yellow,
-                        5: 4 + 6 * self.n_blue}[task]
-        self.act_dim = {1: 2, 2: 5, 3: 4, 4: 5, 5: 3}[task]
-        self.info_dim = {1: 6, 2: 8, 3: 1, 4: 9, 5: 2}[task]
+                        5: 4 + 6 * self.n_blue, 6: 2 + 2 * self.N, 7: 2 + 2 * self.N}[task]
+        self.act_dim = {1: 2, 2: 5, 3: 4, 4: 5, 5: 3, 6: 4 * self.N, 7: 4 * self.N}[task]
+        self.info_dim = {1: 6, 2: 8, 3: 1, 4: 9, 5: 2, 6: 2, 7: 2}[task]
 
     def task_reset(self):
         self._f("rsxo_task_reset")(self.h)

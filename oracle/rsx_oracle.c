@@ -175,6 +175,7 @@ void rsxo_philox4x32_7(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
  * (robot 0: random action, robots >= 1: the two uniforms of their Box-Muller OU draw) */
 #define RSXO_DOM_ACT   1u
 #define RSXO_DOM_PLACE 3u
+#define RSXO_DOM_RAW   4u /* rsx_step_dev_random: counter = (env id, tick, robot, RAW) */
 
 /* float-only elementary functions with a fixed operation order (mirrored instruction for
  * instruction by rsoccer_amd/csrc/rsx_math.hpp); coefficients: Cephes sinf/cosf/logf.

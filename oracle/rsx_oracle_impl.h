@@ -47,6 +47,7 @@ typedef struct SUF(rsxo_env) {
     R pen_x, half_pen_wid, inv_bd_scale, inv_bg_scale, inv_en_scale;
     R pl_xlo, pl_xspan, pl_ylo, pl_yspan, pl_min_d2;
     R ou_theta_dt, ou_sig_sqdt;
+    R sc_sx, sc_sy, sc_j, sc_jb;   /* scrimmage line-up: grid spacing, robot jitter, ball jitter */
 } SUF(rsxo_env);
 
 static inline R SUF(clampr)(R v, R lo, R hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -515,10 +516,32 @@ void SUF(rsxo_step)(void* p, const double* cmds) {
     SUF(step_core)(e, q);
 }
 
+/* 24-bit uniform in [0, 1) */
+static inline R SUF(u01)(uint32_t x) { return RC(x >> 8) * RC(5.9604644775390625e-08); }
+
+/* robosim.step() with commands drawn on the spot (the device-side random-command mode of the raw
+ * simulator, rsx_step_dev_random): robot k takes block (env_id, tick, k, RAW) of Philox keyed by seed.
+ * VSS: wheel speeds U(-1, 1) * w_max; SSL: local velocities U(-1, 1) * (2.5 m/s, 2.5 m/s, 10 rad/s)
+ *  */
+void SUF(rsxo_step_random)(void* p, uint64_t seed, uint64_t env_id, uint32_t tick) {
+    SUF(rsxo_env)* e = (SUF(rsxo_env)*)p;
+    const int N = e->cfg.n_robots, ssl = e->cfg.kind == 1;
+    R q[MAXROB * 8];
+    memset(q, 0, sizeof(q));
+    const uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    for (int k = 0; k < N; ++k) {
+        uint32_t ctr[4] = {(uint32_t)env_id, tick, (uint32_t)k, RSXO_DOM_RAW}, u[4];
+        rsxo_philox4x32_7(ctr, key, u);
+        R a0 = SUF(u01)(u[0]) * RC(2) - RC(1), a1 = SUF(u01)(u[1]) * RC(2) - RC(1), a2 = SUF(u01)(u[2]) * RC(2) - RC(1);
+        if (ssl) { q[8 * k + 1] = a0 * RC(2.5); q[8 * k + 2] = a1 * RC(2.5); q[8 * k + 3] = a2 * RC(10.0); }
+        else { q[2 * k] = a0 * e->w_max; q[2 * k + 1] = a1 * e->w_max; }
+    }
+    SUF(step_core)(e, q);
+}
+
 /* ==========================================================================================
  * TASKS
  * ======================================================================================== */
-static inline R SUF(u01)(uint32_t x) { return RC(x >> 8) * RC(5.9604644775390625e-08); }
 
 static void SUF(draw)(const SUF(rsxo_env)* e, uint32_t tick, uint32_t dom, uint32_t out[4]) {
     uint32_t ctr[4] = {e->env_id, e->episode, tick, dom};
@@ -549,6 +572,10 @@ int SUF(rsxo_task_attach)(void* p, int task, uint64_t seed, uint64_t env_id, int
         if (c->kind != 1 || c->n_blue != 2 || c->n_yellow != 0) return -1;
         e->obs_dim = 4 + 6 * c->n_blue; e->act_dim = 3; e->info_dim = 2;
         e->max_steps = max_steps > 0 ? max_steps : 1200;
+    } else if (task == 6 || task == 7) {  /* synthetic scrimmage (every robot commanded), spread / crowded line-up */
+        if (c->kind != 1 || c->n_robots < 1) return -1;
+        e->obs_dim = 2 + 2 * c->n_robots; e->act_dim = 4 * c->n_robots; e->info_dim = 2;
+        e->max_steps = max_steps > 0 ? max_steps : 1200;
     } else return -1;
     e->task = task;
     e->key[0] = (uint32_t)seed; e->key[1] = (uint32_t)(seed >> 32);
@@ -576,6 +603,12 @@ int SUF(rsxo_task_attach)(void* p, int task, uint64_t seed, uint64_t env_id, int
         e->pl_min_d2 = RC(0.2 * 0.2);
     }
     e->pl_ylo = RC(-(f[1] / 2) + 0.1); e->pl_yspan = RC((f[1] / 2 - 0.1) - (-(f[1] / 2) + 0.1));
+    if (task == 6) { /* jittered grid over the field: >= 0.2 m apart by construction */
+        double sx = f[0] / 8.0, sy = f[1] / 5.0, j = 0.3 * (sx < sy ? sx : sy);
+        e->sc_sx = RC(sx); e->sc_sy = RC(sy); e->sc_j = RC(j); e->sc_jb = RC(0.1);
+    } else if (task == 7) { /* the same grid packed around the ball: worst-case all-pairs contacts */
+        e->sc_sx = RC(0.25); e->sc_sy = RC(0.25); e->sc_j = RC(0.02); e->sc_jb = RC(0.02);
+    }
     e->ou_theta_dt = RC(0.17 * dt);          /* Utils.py:6,17 */
     e->ou_sig_sqdt = RC(0.5 * sqrt(dt));     /* Utils.py:8,18 */
     memset(e->metrics, 0, sizeof(e->metrics));
@@ -588,6 +621,16 @@ static void SUF(task_obs)(const SUF(rsxo_env)* e, R* o) {
     const R* s = e->state;
     const R lo = RC(-1.2), hi = RC(1.2);
     int n = 0;
+    if (e->task >= 6) { /* scrimmage, README.md:88-90 style: positions only */
+        o[n++] = SUF(clampr)(s[0] * e->inv_max_pos, lo, hi);
+        o[n++] = SUF(clampr)(s[1] * e->inv_max_pos, lo, hi);
+        for (int k = 0; k < c->n_robots; ++k) {
+            const R* r = s + 5 + e->RS * k;
+            o[n++] = SUF(clampr)(r[0] * e->inv_max_pos, lo, hi);
+            o[n++] = SUF(clampr)(r[1] * e->inv_max_pos, lo, hi);
+        }
+        return;
+    }
     if (e->task == 3) o[n++] = ((e->prev_pot / RC(6)) * RC(2)) - RC(1);  /* checkpoint progress, dribbling.py:80 */
     o[n++] = SUF(clampr)(s[0] * e->inv_max_pos, lo, hi);
     o[n++] = SUF(clampr)(s[1] * e->inv_max_pos, lo, hi);
@@ -691,6 +734,10 @@ static void SUF(task_reward)(SUF(rsxo_env)* e, const R* last, const R* cmds, int
             reward = (t_move + t_grad) + t_en;
             e->info[1] += t_move; e->info[2] += t_grad; e->info[3] += t_en;
         }
+    } else if (e->task >= 6) { /* scrimmage, README.md:96-102 style: a goal ends the episode */
+        R bx = s[0], by = s[1];
+        if (bx > e->half_len && R_FABS(by) < e->ghw) { reward = RC(1); done = 1; e->info[0] += RC(1); }
+        else if (bx < -e->half_len && R_FABS(by) < e->ghw) { reward = RC(-1); done = 1; e->info[1] += RC(1); }
     } else if (e->task == 3) { /* dribbling.py:137-185; prev_pot holds checkpoints_count */
         const R* r0 = s + 5;
         R bx = s[0], by = s[1], lby = last[1], rx = r0[0], ry = r0[1];
@@ -778,6 +825,19 @@ static void SUF(task_place)(SUF(rsxo_env)* e) {
     uint32_t n = 0, u[4];
     R px[MAXBOD], py[MAXBOD]; int np = 0;
     int first = 0;
+    if (e->task >= 6) { /* scrimmage: robot k in cell (k % 6, k / 6) of a 6 x 4 grid, one Philox block each */
+        for (int k = 0; k < c->n_robots; ++k) {
+            SUF(draw)(e, (uint32_t)k, RSXO_DOM_PLACE, u);
+            R* r = s + 5 + 11 * k;
+            r[0] = e->sc_sx * (RC(k % 6) - RC(2.5)) + e->sc_j * (SUF(u01)(u[0]) * RC(2) - RC(1));
+            r[1] = e->sc_sy * (RC(k / 6) - RC(1.5)) + e->sc_j * (SUF(u01)(u[1]) * RC(2) - RC(1));
+            r[2] = RC(360) * SUF(u01)(u[2]);
+        }
+        SUF(draw)(e, (uint32_t)c->n_robots, RSXO_DOM_PLACE, u);
+        s[0] = e->sc_jb * (SUF(u01)(u[0]) * RC(2) - RC(1));
+        s[1] = e->sc_jb * (SUF(u01)(u[1]) * RC(2) - RC(1));
+        return;
+    }
     if (e->task == 3) { /* dribbling.py:187-202: fixed course */
         s[0] = RC(-0.1); s[1] = RC(0);
         s[5 + 2] = RC(180);
@@ -880,7 +940,8 @@ void SUF(rsxo_task_step)(void* p, const float* action) {
     if (first_step) { memset(e->info, 0, sizeof(e->info)); e->ep_ret = RC(0); }
     R a[8];
     SUF(draw)(e, t, RSXO_DOM_ACT, u);   /* block 0 of the step (VSS-v0: robot 1 owns its words 2, 3) */
-    if (action) for (int i = 0; i < e->act_dim; ++i) a[i] = RC(action[i]);
+    if (e->task >= 6) { /* handled per robot below */ }
+    else if (action) for (int i = 0; i < e->act_dim; ++i) a[i] = RC(action[i]);
     else {
         for (int i = 0; i < 4 && i < e->act_dim; ++i) a[i] = SUF(u01)(u[i]) * RC(2) - RC(1);
         if (e->act_dim > 4) { /* fifth component: the low bytes u01 leaves unused in words 0..2 of the same block */
@@ -908,6 +969,18 @@ void SUF(rsxo_task_step)(void* p, const float* action) {
             act[2 * k] = e->ou[k][0]; act[2 * k + 1] = e->ou[k][1];
         }
         SUF(vss_cmds)(e, act, cmds);
+    } else if (e->task >= 6) { /* scrimmage: every robot gets (v_x, v_y, v_theta, kick), block k of the step */
+        memset(cmds, 0, sizeof(R) * 8 * N);
+        for (int k = 0; k < N; ++k) {
+            R q[4];
+            if (action) for (int i = 0; i < 4; ++i) q[i] = RC(action[4 * k + i]);
+            else {
+                SUF(draw)(e, t, RSXO_DOM_ACT | ((uint32_t)k << 8), u);
+                for (int i = 0; i < 4; ++i) q[i] = SUF(u01)(u[i]) * RC(2) - RC(1);
+            }
+            cmds[8 * k + 1] = q[0] * e->max_v; cmds[8 * k + 2] = q[1] * e->max_v; cmds[8 * k + 3] = q[2] * RC(10.0);
+            cmds[8 * k + 5] = q[3] > RC(0.9) ? RC(5.0) : RC(0);
+        }
     } else {
         SUF(sd_cmds)(e, a, e->state[5 + 2], cmds);
     }
@@ -925,6 +998,7 @@ void SUF(rsxo_task_step)(void* p, const float* action) {
         if (e->task == 1) { e->metrics[2] += e->info[4] > RC(0); e->metrics[3] += e->info[5] > RC(0); }
         else if (e->task == 2 || e->task == 4) e->metrics[2] += e->info[0] > RC(0);  /* goal */
         else if (e->task == 3) e->metrics[2] += e->info[0] >= RC(7);                  /* course completed */
+        else if (e->task >= 6) { e->metrics[2] += e->info[0] > RC(0); e->metrics[3] += e->info[1] > RC(0); }
         else e->metrics[2] += e->terminated && e->state[5 + 11 + 6] != RC(0);         /* pass received */
         /* VSS-v0: the return is taken from the cumulative reward terms (no running sum is kept) */
         R ret = e->task == 1 ? ((e->info[1] + e->info[2]) + e->info[3]) + RC(10) * e->info[0] : e->ep_ret;

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("RSX_LIB") or os.path.join(_HERE, "librsx_hip.so")  # 
 KIND_VSS, KIND_SSL = 0, 1
 TASK_NONE, TASK_VSS_V0, TASK_SSL_STATIC_DEFENDERS = 0, 1, 2
 TASK_SSL_DRIBBLING, TASK_SSL_CONTESTED, TASK_SSL_PASS_ENDURANCE = 3, 4, 5
+TASK_SSL_SCRIMMAGE, TASK_SSL_SCRIMMAGE_CROWDED = 6, 7
 FIELD_KEYS = (
     "length", "width", "penalty_length", "penalty_width", "goal_width", "goal_depth",
     "ball_radius", "rbt_distance_center_kicker", "rbt_kicker_thickness", "rbt_kicker_width",
@@ -30,7 +31,7 @@ METRIC_NAMES = ("env_steps", "episodes", "goals_for", "goals_against", "return_s
 SYMBOLS = (
     "rsx_abi_version", "rsx_last_error", "rsx_device_count", "rsx_create", "rsx_destroy",
     "rsx_get_field_params", "rsx_reset", "rsx_step", "rsx_get_state", "rsx_set_state",
-    "rsx_get_state_full", "rsx_dev_view_get", "rsx_step_dev", "rsx_step_dev_flip", "rsx_state_buffers",
+    "rsx_get_state_full", "rsx_dev_view_get", "rsx_step_dev", "rsx_step_dev_random", "rsx_step_dev_flip", "rsx_state_buffers",
     "rsx_reset_dev", "rsx_task_attach",
     "rsx_task_view_get", "rsx_task_reset", "rsx_task_reset_to", "rsx_task_step",
     "rsx_task_step_n", "rsx_task_rollout", "rsx_read_metrics", "rsx_check_finite",
@@ -85,6 +86,7 @@ def load():
     lib.rsx_get_state_full.argtypes = [vp, vp, vp]
     lib.rsx_dev_view_get.argtypes = [vp, C.POINTER(DevView)]
     lib.rsx_step_dev.argtypes = [vp, vp]
+    lib.rsx_step_dev_random.argtypes = [vp, ip, C.c_uint64, C.c_uint32, vp]
     lib.rsx_step_dev_flip.argtypes = [vp, vp]
     lib.rsx_state_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     lib.rsx_reset_dev.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -216,6 +218,10 @@ class Sim:
     # ---- device-resident path ----
     def step_dev(self, stream=None):
         _chk(self._lib.rsx_step_dev(self._h, self._stream(stream)))
+
+    def step_dev_random(self, n=1, seed=0, first_tick=0, stream=None):
+        """n steps with commands drawn on the device (Philox keyed by seed; ticks first_tick...)."""
+        _chk(self._lib.rsx_step_dev_random(self._h, int(n), int(seed), int(first_tick), self._stream(stream)))
 
     def step_dev_flip(self, stream=None):
         """Double-buffered step_dev(): the two tensors of state_buffers() trade roles."""

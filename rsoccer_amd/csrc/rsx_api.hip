@@ -129,32 +129,35 @@ void pick_variant(rsx_sim* h) {
 
 // hot arguments first (preloaded into SGPRs, see RSX_HOT_ARGS), then the by-value structs
 #define RSX_LAUNCH_SIM(kernel, P, b) hipLaunchKernelGGL((kernel), grid, dim3(64), 0, s, (b).state, state_out, (b).cmds, (b).flags, \
-                                                        (P).num_envs, (P).state_dim, (int)(grid.x >> 3), 1, (P), (b))
+                                                        (P).num_envs, (P).state_dim, (int)(grid.x >> 3), rand_tick, (P), (b))
 #define RSX_LAUNCH(kernel, P, b, n) hipLaunchKernelGGL((kernel), grid, dim3(64), 0, s, (b).state, (b).aux, (b).actions, (b).flags, \
                                                        (P).num_envs, (P).state_dim, (int)(grid.x >> 3), (n), (P), (b))
 
 template <int KIND>
-void launch_sim_k(const rsx_sim* h, float* state_out, hipStream_t s) {
+void launch_sim_k(const rsx_sim* h, const Params& P_, float* state_out, int rand_tick, hipStream_t s) {
     const dim3 grid = grid_for(h);
     const Buffers b = buffers_of(h, nullptr);
-    if (KIND == RSX_KIND_VSS && h->NR == 6) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 8, (KIND == RSX_KIND_VSS ? 6 : 0)>), h->P, b); return; }
-    if (KIND == RSX_KIND_VSS && h->NR == 10) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 16, (KIND == RSX_KIND_VSS ? 10 : 0)>), h->P, b); return; }
-    if (KIND == RSX_KIND_SSL && h->NR == 7) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 8, (KIND == RSX_KIND_SSL ? 7 : 0)>), h->P, b); return; }
-    if (KIND == RSX_KIND_SSL && h->NR == 12) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 16, (KIND == RSX_KIND_SSL ? 12 : 0)>), h->P, b); return; }
-    if (KIND == RSX_KIND_SSL && h->NR == 22) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 32, (KIND == RSX_KIND_SSL ? 22 : 0)>), h->P, b); return; }
+    if (KIND == RSX_KIND_VSS && h->NR == 6) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 8, (KIND == RSX_KIND_VSS ? 6 : 0)>), P_, b); return; }
+    if (KIND == RSX_KIND_VSS && h->NR == 10) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 16, (KIND == RSX_KIND_VSS ? 10 : 0)>), P_, b); return; }
+    if (KIND == RSX_KIND_SSL && h->NR == 7) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 8, (KIND == RSX_KIND_SSL ? 7 : 0)>), P_, b); return; }
+    if (KIND == RSX_KIND_SSL && h->NR == 12) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 16, (KIND == RSX_KIND_SSL ? 12 : 0)>), P_, b); return; }
+    if (KIND == RSX_KIND_SSL && h->NR == 22) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 32, (KIND == RSX_KIND_SSL ? 22 : 0)>), P_, b); return; }
     switch (h->L) {
-        case 8: RSX_LAUNCH_SIM((sim_step_kernel<KIND, 8, 0>), h->P, b); break;
-        case 16: RSX_LAUNCH_SIM((sim_step_kernel<KIND, 16, 0>), h->P, b); break;
-        case 32: RSX_LAUNCH_SIM((sim_step_kernel<KIND, 32, 0>), h->P, b); break;
-        default: RSX_LAUNCH_SIM((sim_step_kernel<KIND, 64, 0>), h->P, b); break;
+        case 8: RSX_LAUNCH_SIM((sim_step_kernel<KIND, 8, 0>), P_, b); break;
+        case 16: RSX_LAUNCH_SIM((sim_step_kernel<KIND, 16, 0>), P_, b); break;
+        case 32: RSX_LAUNCH_SIM((sim_step_kernel<KIND, 32, 0>), P_, b); break;
+        default: RSX_LAUNCH_SIM((sim_step_kernel<KIND, 64, 0>), P_, b); break;
     }
 }
 
 // state_out: where the new state is written (nullptr = in place)
-void launch_sim(const rsx_sim* h, hipStream_t s, float* state_out = nullptr) {
+// rand_tick >= 0: commands drawn in the kernel with Philox key `seed` (rsx_step_dev_random)
+void launch_sim(const rsx_sim* h, hipStream_t s, float* state_out = nullptr, int rand_tick = -1, uint64_t seed = 0) {
     if (!state_out) state_out = h->d_state;
-    if (h->P.kind == RSX_KIND_VSS) launch_sim_k<RSX_KIND_VSS>(h, state_out, s);
-    else launch_sim_k<RSX_KIND_SSL>(h, state_out, s);
+    Params P = h->P;
+    if (rand_tick >= 0) { P.key0 = (uint32_t)seed; P.key1 = (uint32_t)(seed >> 32); P.env_id_base = 0; }
+    if (h->P.kind == RSX_KIND_VSS) launch_sim_k<RSX_KIND_VSS>(h, P, state_out, rand_tick, s);
+    else launch_sim_k<RSX_KIND_SSL>(h, P, state_out, rand_tick, s);
 }
 
 // teleport of rsim.py:52-75 from device arrays: one thread per env, rows are coalesced across threads
@@ -181,7 +184,11 @@ void launch_task_m(const rsx_sim* h, const float* actions, int n_steps, hipStrea
         return;
     }
     const dim3 grid = grid_for(h);
-    if (h->NR == NRS && h->L == 8) { RSX_LAUNCH((task_step_kernel<KIND, 8, TASK, NRS, MODE>), h->P, b, n_steps); return; }
+    if (NRS <= 7 && h->NR == NRS && h->L == 8) { RSX_LAUNCH((task_step_kernel<KIND, 8, TASK, (NRS <= 7 ? NRS : 0), MODE>), h->P, b, n_steps); return; }
+    if (TASK == RSX_TASK_SSL_SCRIMMAGE && h->NR == 22 && h->L == 32) {   // 11v11: robot count known at compile time
+        RSX_LAUNCH((task_step_kernel<KIND, 32, TASK, (TASK == RSX_TASK_SSL_SCRIMMAGE ? 22 : 0), MODE>), h->P, b, n_steps);
+        return;
+    }
     if (TASK == RSX_TASK_VSS_V0 && h->NR == 10 && h->L == 16) {   // VSS-v0 on the 5v5 field
         RSX_LAUNCH((task_step_kernel<KIND, 16, TASK, (TASK == RSX_TASK_VSS_V0 ? 10 : 0), MODE>), h->P, b, n_steps);
         return;
@@ -229,6 +236,8 @@ void launch_task(const rsx_sim* h, const float* actions, int n_steps, int mode, 
         case RSX_TASK_SSL_STATIC_DEFENDERS: launch_task_k<RSX_KIND_SSL, RSX_TASK_SSL_STATIC_DEFENDERS, 7>(h, actions, n_steps, mode, s); break;
         case RSX_TASK_SSL_DRIBBLING: launch_fixed<RSX_TASK_SSL_DRIBBLING, 5>(h, actions, n_steps, mode, s); break;
         case RSX_TASK_SSL_CONTESTED: launch_fixed<RSX_TASK_SSL_CONTESTED, 2>(h, actions, n_steps, mode, s); break;
+        case RSX_TASK_SSL_SCRIMMAGE: case RSX_TASK_SSL_SCRIMMAGE_CROWDED:
+            launch_task_k<RSX_KIND_SSL, RSX_TASK_SSL_SCRIMMAGE, 22>(h, actions, n_steps, mode, s); break;
         default: launch_fixed<RSX_TASK_SSL_PASS_ENDURANCE, 2>(h, actions, n_steps, mode, s); break;
     }
 }
@@ -535,6 +544,16 @@ int rsx_state_buffers(rsx_sim* h, float** current, float** other) {
     return RSX_OK;
 }
 
+int rsx_step_dev_random(rsx_sim* h, int n, uint64_t seed, uint32_t first_tick, void* stream) {
+    RSX_ENTER(h);
+    if (n < 1) return fail(RSX_ERR_ARG, "n must be >= 1");
+    if ((uint64_t)first_tick + (uint64_t)n > 0x7FFFFFFFull) return fail(RSX_ERR_ARG, "tick range exceeds 2^31");
+    h->host_state_valid = false;
+    for (int i = 0; i < n; ++i) launch_sim(h, (hipStream_t)stream, nullptr, (int)(first_tick + (uint32_t)i), seed);
+    HIP_TRY(hipGetLastError());
+    return debug_finite(h, (hipStream_t)stream, "rsx_step_dev_random");
+}
+
 int rsx_step_dev_flip(rsx_sim* h, void* stream) {
     RSX_ENTER(h);
     if (int rc = ensure_alt(h)) return rc;
@@ -562,9 +581,9 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
     if (h->P.task != RSX_TASK_NONE) return fail(RSX_ERR_STATE, "a task is already attached");
     Params P = h->P;
     if (derive_task(task, seed, env_id_base, max_episode_steps, h->M, P))
-        return fail(RSX_ERR_ARG, "task does not match the simulator (VSS_V0: VSS, n_blue >= 1; STATIC_DEFENDERS: SSL 1vN; DRIBBLING: SSL 1v4; CONTESTED: SSL 1v1; PASS_ENDURANCE: SSL 2v0)");
+        return fail(RSX_ERR_ARG, "task does not match the simulator (VSS_V0: VSS, n_blue >= 1; STATIC_DEFENDERS: SSL 1vN; DRIBBLING: SSL 1v4; CONTESTED: SSL 1v1; PASS_ENDURANCE: SSL 2v0; SCRIMMAGE: SSL)");
     if (P.obs_dim > 64) return fail(RSX_ERR_ARG, "observation wider than 64 floats is not supported");
-    if (task >= RSX_TASK_SSL_DRIBBLING && h->L != 8)
+    if (task >= RSX_TASK_SSL_DRIBBLING && task <= RSX_TASK_SSL_PASS_ENDURANCE && h->L != 8)
         return fail(RSX_ERR_ARG, "this task runs with 8 lanes per env only (unset RSX_LANES_PER_ENV)");
     const size_t B = (size_t)P.num_envs;
     const size_t n_aux = align_up((size_t)aux_rows(P.n_robots) * B * sizeof(float));

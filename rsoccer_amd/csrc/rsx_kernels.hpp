@@ -759,7 +759,7 @@ __global__ __launch_bounds__(64) void sim_step_kernel(RSX_HOT_ARGS, const Params
     Params P = P_; P.num_envs = hp_num_envs; P.state_dim = hp_state_dim;
     Buffers bufs = bufs_; bufs.state = hp_state; bufs.cmds = hp_in;   // hp_in: the command buffer
     float* const state_out = hp_aux;   // this kernel's second pointer slot: where the new state goes (== hp_state: in place)
-    (void)hp_flags; (void)hp_n_steps;
+    (void)hp_flags;
     using K = KC<KIND>;
     constexpr int G = 64 / L;
     constexpr int CD = ModelD<KIND>::cmd_dim;
@@ -778,10 +778,18 @@ __global__ __launch_bounds__(64) void sim_step_kernel(RSX_HOT_ARGS, const Params
     Body o; float od, wd, w[4];
     const RawBody raw = load_raw<KIND>(P, bufs.state, e, b, is_robot, is_ball);
     float q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int rand_tick = hp_n_steps;   // >= 0: commands are drawn here (rsx_step_dev_random), < 0: read from memory
     if (is_robot) {
-        const float* c = bufs.cmds + (size_t)(b * CD) * B + e;
+        if (rand_tick >= 0) {
+            const u32x4 u = philox4x32(P.env_id_base + (uint32_t)e, (uint32_t)rand_tick, (uint32_t)b, DOM_RAW, P.key0, P.key1);
+            const float a0 = u01(u.x) * 2.0f - 1.0f, a1 = u01(u.y) * 2.0f - 1.0f, a2 = u01(u.z) * 2.0f - 1.0f;
+            if (KIND == RSX_KIND_SSL) { q[1] = a0 * 2.5f; q[2] = a1 * 2.5f; q[3] = a2 * 10.0f; }
+            else { q[0] = a0 * K::w_max; q[1] = a1 * K::w_max; }
+        } else {
+            const float* c = bufs.cmds + (size_t)(b * CD) * B + e;
 #pragma unroll
-        for (int i = 0; i < CD; ++i) q[i] = c[i * B];
+            for (int i = 0; i < CD; ++i) q[i] = c[i * B];
+        }
     }
     interpret_body<KIND>(raw, is_robot, is_ball, o, od, wd, w);
     if (is_robot) robot_targets<KIND>(P, o, q);
@@ -808,6 +816,14 @@ __device__ __forceinline__ void write_obs(const Params& P, float* __restrict__ r
     // sn / cs = sin / cos of (theta_deg * deg2rad), i.e. of the wire-format heading
     using T = TC<TASK>;
     const float lo = -1.2f, hi = 1.2f;
+    if (TASK == RSX_TASK_SSL_SCRIMMAGE) {   // positions only (README.md:88-90 style)
+        if (is_ball || is_robot) {
+            float* r = row + (is_ball ? 0 : 2 + 2 * b);
+            r[0] = clampf(x * P.inv_max_pos, lo, hi);
+            r[1] = clampf(y * P.inv_max_pos, lo, hi);
+        }
+        return;
+    }
     constexpr int OFF = TASK == RSX_TASK_SSL_DRIBBLING ? 1 : 0;   // dribbling: slot 0 = checkpoint progress
     constexpr int WB = TASK == RSX_TASK_VSS_V0 ? 7 : (TASK == RSX_TASK_SSL_PASS_ENDURANCE ? 6 : 8);
     constexpr int WY = TASK == RSX_TASK_VSS_V0 ? 5 : 2;
@@ -875,7 +891,7 @@ __device__ __forceinline__ float vss_wheel(float a) {
 // they are needed.
 template <int TASK, int L>
 __host__ __device__ constexpr int predraw_count() {
-    return TASK == RSX_TASK_SSL_DRIBBLING ? 0 : TASK == RSX_TASK_SSL_CONTESTED ? 1 : (L < 16 ? 16 : L);
+    return (TASK == RSX_TASK_SSL_DRIBBLING || TASK == RSX_TASK_SSL_SCRIMMAGE) ? 0 : TASK == RSX_TASK_SSL_CONTESTED ? 1 : (L < 16 ? 16 : L);
 }
 
 template <int TASK, int L>
@@ -1106,6 +1122,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
     constexpr int OD_C = NR == 0 ? 0
         : TASK == RSX_TASK_VSS_V0 ? 4 + 6 * NR                // equal teams: 4 + 7*nb + 5*ny (vss_gym.py:64-67): 40 for 3v3, 64 for 5v5
         : TASK == RSX_TASK_SSL_STATIC_DEFENDERS ? 4 + 8 + 2 * (NR - 1)
+        : TASK == RSX_TASK_SSL_SCRIMMAGE ? 2 + 2 * NR
         : TASK == RSX_TASK_SSL_DRIBBLING ? 21 : TASK == RSX_TASK_SSL_CONTESTED ? 14 : 16;
     const int OD = OD_C ? OD_C : P.obs_dim;
     float* const auxe = bufs.aux + e;  // column of this env in the scalar arena
@@ -1146,13 +1163,19 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
     if (counts_steps) steps_before = bufs.metrics[0];
     float reward = 0.0f; int term = 0, trunc = 0;
     bool success = false;  // goal scored / course completed / pass received (metrics[2])
+    bool against = false;  // goal conceded (metrics[3]; scrimmage)
     bool was_reset = false;
     // caller-fed actions of the agent lane (robot 0); fed launches run a single step
     const bool fed = MODE == MODE_STEP && bufs.actions != nullptr;
     float act[AD];
 #pragma unroll
     for (int i = 0; i < AD; ++i) act[i] = 0.0f;
-    if (fed && is_robot && b == 0) {
+    if (TASK == RSX_TASK_SSL_SCRIMMAGE) {   // every robot is commanded: [B][N][4]
+        if (fed && is_robot) {
+#pragma unroll
+            for (int i = 0; i < AD; ++i) act[i] = bufs.actions[((size_t)e * N + b) * AD + i];
+        }
+    } else if (fed && is_robot && b == 0) {
 #pragma unroll
         for (int i = 0; i < AD; ++i) act[i] = bufs.actions[(size_t)e * AD + i];
     }
@@ -1225,6 +1248,20 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
                         a0 = ou0; a1 = ou1;
                     }
                     q[0] = vss_wheel(a0); q[1] = vss_wheel(a1);
+                }
+            } else if (TASK == RSX_TASK_SSL_SCRIMMAGE) {  // every robot: (v_x, v_y, v_theta, kick), block b of the step
+                if (is_robot) {
+                    float a[4];
+                    if (fed) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) a[i] = act[i];
+                    } else {
+                        const u32x4 u = philox4x32(env_id, episode, t, DOM_ACT | ((uint32_t)b << 8), P.key0, P.key1);
+                        a[0] = u01(u.x) * 2.0f - 1.0f; a[1] = u01(u.y) * 2.0f - 1.0f;
+                        a[2] = u01(u.z) * 2.0f - 1.0f; a[3] = u01(u.w) * 2.0f - 1.0f;
+                    }
+                    q[1] = a[0] * T::max_v; q[2] = a[1] * T::max_v; q[3] = a[2] * 10.0f;
+                    q[5] = a[3] > 0.9f ? 5.0f : 0.0f;
                 }
             } else {  // the SSL tasks: only blue 0 is driven by the agent
                 if (is_robot && b == 0) {
@@ -1326,6 +1363,10 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
                         reward = (t_move + t_grad) + t_en;
                         info[1] += t_move; info[2] += t_grad; info[3] += t_en;
                     }
+                } else if (TASK == RSX_TASK_SSL_SCRIMMAGE) {  // README.md:96-102 style: a goal ends the episode
+                    if (bx > P.half_len && fabsf(by) < P.ghw) { reward = 1.0f; term = 1; info[0] += 1.0f; }
+                    else if (bx < -P.half_len && fabsf(by) < P.ghw) { reward = -1.0f; term = 1; info[1] += 1.0f; }
+                    success = info[0] > 0.0f; against = info[1] > 0.0f;
                 } else if (TASK == RSX_TASK_SSL_DRIBBLING) {  // dribbling.py:137-185; prev_pot = checkpoints_count
                     const float rx = xr[0], ry = xr[1];
                     if (xr[2] != 0.0f || xr[3] != 0.0f || xr[4] != 0.0f || xr[5] != 0.0f) term = 1;  // an obstacle was hit
@@ -1441,7 +1482,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
                     unsigned long long inc[6];
                     inc[0] = 1ull;
                     inc[1] = success ? 1ull : 0ull;
-                    inc[2] = 0ull;
+                    inc[2] = against ? 1ull : 0ull;
                     inc[3] = (unsigned long long)__float2ll_rn(ep_ret * 1048576.0f);
                     inc[4] = (unsigned long long)steps;
                     inc[5] = (trunc && !term) ? 1ull : 0ull;
@@ -1462,7 +1503,16 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
             // A single-step launch waits for its slowest wave, which is one that resets an env:
             // there the placement runs in its parallel form.  A multi-step launch pays for the
             // average wave instead, and the sequential form issues fewer instructions.
-            if ((TASK == RSX_TASK_VSS_V0 || TASK == RSX_TASK_SSL_STATIC_DEFENDERS) && MODE != MODE_ROLLOUT) {
+            if (TASK == RSX_TASK_SSL_SCRIMMAGE) {
+                // robot k in cell (k % 6, k / 6) of a 6 x 4 grid, one Philox block per body: every lane places itself
+                if (ended && (is_robot || is_ball)) {
+                    const u32x4 u = philox4x32(env_id, episode, (uint32_t)b, DOM_PLACE, P.key0, P.key1);
+                    const float jx = u01(u.x) * 2.0f - 1.0f, jy = u01(u.y) * 2.0f - 1.0f;
+                    if (is_ball) pz = make_float4(P.sc_jb * jx, P.sc_jb * jy, 0.0f, 0.0f);
+                    else pz = make_float4(P.sc_sx * ((float)(b % 6) - 2.5f) + P.sc_j * jx,
+                                          P.sc_sy * ((float)(b / 6) - 1.5f) + P.sc_j * jy, 360.0f * u01(u.z), 0.0f);
+                }
+            } else if ((TASK == RSX_TASK_VSS_V0 || TASK == RSX_TASK_SSL_STATIC_DEFENDERS) && MODE != MODE_ROLLOUT) {
                 if (ended) pz = place_env_parallel<TASK, L, NR>(P, N, env_id, episode, b, g, is_robot, sh.A, sh.draws[g]);
             } else {
                 if (ended && is_ball) place_env<TASK, L>(P, N, env_id, episode, g, sh.A, sh.draws[g]);

@@ -130,7 +130,7 @@ __device__ __forceinline__ u32x4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c
 // from block 0; VSS-v0 gives robot k the words (2 (k & 1), 2 (k & 1) + 1) of block k >> 1 (robot 0:
 // random action, robots >= 1: the two uniforms of their Box-Muller OU draw) — one block serves two
 // robots, which the one-lane-per-env kernel turns into half the Philox work.
-constexpr uint32_t DOM_ACT = 1u, DOM_PLACE = 3u;
+constexpr uint32_t DOM_ACT = 1u, DOM_PLACE = 3u, DOM_RAW = 4u;   // RAW: rsx_step_dev_random, counter (env, tick, robot, RAW)
 
 // 24-bit uniform in [0, 1)
 __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }

@@ -147,6 +147,12 @@ template <> struct TC<RSX_TASK_SSL_PASS_ENDURANCE> : TCSslBase {
     static constexpr int n_blue = 2, n_yellow = 0;                     // pass_endurance.py:48-49
 };
 
+template <> struct TC<RSX_TASK_SSL_SCRIMMAGE> : TCSslBase {   // both line-ups run this variant
+    static constexpr float inv_en_scale = 0.0f;
+    static constexpr int info_dim = 2, act_dim = 4 /* per robot */, max_steps = 1200;
+    static constexpr int n_blue = -1, n_yellow = -1;
+};
+
 // ---------------------------------------------------------------------------------------------
 // run-time block (kernel argument)
 // ---------------------------------------------------------------------------------------------
@@ -164,6 +170,7 @@ struct Params {
     float pen_x, half_pen_wid, inv_bd_scale, inv_bg_scale;
     float pl_xlo, pl_xspan, pl_ylo, pl_yspan, pl_min_d2;
     float ou_theta_dt, ou_sig_sqdt;
+    float sc_sx, sc_sy, sc_j, sc_jb;   // scrimmage line-up: grid spacing, robot jitter, ball jitter
 };
 
 struct HostModel {
@@ -287,6 +294,18 @@ inline int derive_task(int task, uint64_t seed, uint64_t env_id_base, int max_st
         P.obs_dim = 4 + 6 * P.n_blue;                    // pass_endurance.py:55
         M.act_dim = T::act_dim; M.info_dim = T::info_dim;
         P.max_steps = max_steps > 0 ? max_steps : T::max_steps;
+    } else if (task == RSX_TASK_SSL_SCRIMMAGE || task == RSX_TASK_SSL_SCRIMMAGE_CROWDED) {
+        using T = TC<RSX_TASK_SSL_SCRIMMAGE>;
+        if (P.kind != RSX_KIND_SSL || P.n_robots < 1) return -1;
+        P.obs_dim = 2 + 2 * P.n_robots;
+        M.act_dim = T::act_dim * P.n_robots; M.info_dim = T::info_dim;
+        P.max_steps = max_steps > 0 ? max_steps : T::max_steps;
+        if (task == RSX_TASK_SSL_SCRIMMAGE) {   // jittered grid over the field: >= 0.2 m apart by construction
+            const double sx = f[0] / 8.0, sy = f[1] / 5.0, j = 0.3 * (sx < sy ? sx : sy);
+            P.sc_sx = (float)sx; P.sc_sy = (float)sy; P.sc_j = (float)j; P.sc_jb = 0.1f;
+        } else {                                // the same grid packed around the ball
+            P.sc_sx = 0.25f; P.sc_sy = 0.25f; P.sc_j = 0.02f; P.sc_jb = 0.02f;
+        }
     } else {
         return -1;
     }

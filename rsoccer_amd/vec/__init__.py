@@ -14,10 +14,10 @@
   vss_gym_base.py:197-211), ``num_envs`` Python objects over ONE batched simulator.
 """
 from rsoccer_amd.vec.fused import (VecFusedEnv, VecSSLContestedPossessionEnv, VecSSLDribblingEnv,
-                                   VecSSLPassEnduranceEnv, VecSSLStaticDefendersEnv, VecVSSEnv)
+                                   VecSSLPassEnduranceEnv, VecSSLScrimmageEnv, VecSSLStaticDefendersEnv, VecVSSEnv)
 from rsoccer_amd.vec.hooks import VecFrame, VecSSLBaseEnv, VecVSSBaseEnv
 from rsoccer_amd.vec.scalar import VecScalarHookEnv
 
 __all__ = ["VecFusedEnv", "VecVSSEnv", "VecSSLStaticDefendersEnv", "VecSSLDribblingEnv",
-           "VecSSLContestedPossessionEnv", "VecSSLPassEnduranceEnv", "VecFrame", "VecVSSBaseEnv", "VecSSLBaseEnv",
+           "VecSSLContestedPossessionEnv", "VecSSLPassEnduranceEnv", "VecSSLScrimmageEnv", "VecFrame", "VecVSSBaseEnv", "VecSSLBaseEnv",
            "VecScalarHookEnv"]

@@ -178,3 +178,19 @@ class VecSSLPassEnduranceEnv(VecFusedEnv):
     TimeLimit 1200."""
     KIND, TASK, FIELD_TYPE, N_BLUE, N_YELLOW = _lib.KIND_SSL, _lib.TASK_SSL_PASS_ENDURANCE, 2, 2, 0
     INFO_KEYS = ("reversed_dist", "ball_grad")
+
+
+class VecSSLScrimmageEnv(VecFusedEnv):
+    """Synthetic SSL task in the style of the reference's example env (README.md:78-110) for team sizes
+    no registered id covers — BASELINE.json configs[3]: 11v11 on the division-A field.  EVERY robot
+    is commanded: action ``[B, 4 N]`` = per robot (v_x, v_y robot-local x 2.5 m/s, v_theta x 10 rad/s,
+    kick 5 m/s when > 0.9); obs ``[B, 2 + 2 N]`` = normalised ball and robot positions; reward +1 / -1
+    and done on a goal for blue / yellow; TimeLimit 1200.  ``crowded=True`` packs the line-up around
+    the ball (worst-case all-pairs contacts)."""
+    KIND = _lib.KIND_SSL
+    INFO_KEYS = ("goals_blue", "goals_yellow")
+
+    def __init__(self, num_envs, n_blue=11, n_yellow=11, field_type=1, crowded=False, **kw):
+        self.N_BLUE, self.N_YELLOW, self.FIELD_TYPE = int(n_blue), int(n_yellow), int(field_type)
+        self.TASK = _lib.TASK_SSL_SCRIMMAGE_CROWDED if crowded else _lib.TASK_SSL_SCRIMMAGE
+        super().__init__(num_envs, **kw)

@@ -79,6 +79,33 @@ def test_raw_step_bitexact(oracle_mod, kind, ft, nb, ny, B, steps, spread):
     sim.close()
 
 
+@pytest.mark.parametrize("kind,ft,nb,ny,B", [(0, 0, 3, 3, 70), (1, 1, 11, 11, 21), (1, 2, 1, 6, 33)])
+def test_raw_step_with_device_random_commands_bitexact(oracle_mod, kind, ft, nb, ny, B):
+    """rsx_step_dev_random: commands drawn in the kernel (Philox, SURVEY.md 8(d) config 4 distribution)
+    equal the oracle's restatement; the tick range continues across calls."""
+    L = _lib()
+    rng = np.random.default_rng(12)
+    sim = L.Sim(kind, ft, nb, ny, 25, B)
+    f = sim.get_field_params()
+    ball, blue, yellow = random_placement(rng, B, nb, ny, f["length"] / 2 - 0.3, f["width"] / 2 - 0.3, 2.3 * f["rbt_radius"], 0.5)
+    sim.reset(ball, blue, yellow)
+    refs = _mk_oracles(oracle_mod, kind, ft, nb, ny, B)
+    for e, r in enumerate(refs):
+        r.reset(ball[e], blue[e], yellow[e])
+    seed = 0xABCDEF0123
+    sim.step_dev_random(25, seed, 0)
+    sim.step_dev_random(15, seed, 25)
+    for e, r in enumerate(refs):
+        for t in range(40):
+            r.step_random(seed, e, t)
+    got = sim.get_state_full()
+    for e, r in enumerate(refs):
+        assert f32_equal(got[e], r.get_state_full()), mismatch_report(got[e], r.get_state_full(), f"env {e}")
+    moved = np.abs(got[:, 5] - np.array([b[0, 0] if nb else 0 for b in blue])).max()
+    assert moved > 0.05
+    sim.close()
+
+
 def test_set_get_state_roundtrip():
     L = _lib()
     sim = L.Sim(1, 2, 1, 6, 25, 9)
@@ -122,6 +149,10 @@ TASKS = [
     (3, 1, 2, 1, 4, 29, 220, 70),      # SSLDribbling-v0
     (4, 1, 2, 1, 1, 53, 220, 50),      # SSLContestedPossession-v0
     (5, 1, 2, 2, 0, 21, 220, 40),      # SSLPassEndurance-v0
+    (6, 1, 1, 11, 11, 13, 90, 35),     # scrimmage 11v11, division-A field, spread line-up (32 lanes per env, 22 robots unrolled)
+    (7, 1, 1, 11, 11, 11, 90, 35),     # scrimmage 11v11, crowded line-up: contacts in every sub-step
+    (7, 1, 2, 3, 2, 27, 120, 30),      # scrimmage 3v2 on the small field (8 lanes per env, run-time robot count)
+    (6, 1, 0, 6, 6, 9, 80, 40),        # scrimmage 6v6 (16 lanes per env)
 ]
 
 
@@ -229,7 +260,8 @@ def test_many_resets_placement_bitexact(oracle_mod, task, kind, ft, nb, ny):
 
 @pytest.mark.parametrize("task,kind,ft,nb,ny,B,steps", [(1, 0, 0, 3, 3, 4096, 6000), (2, 1, 2, 1, 6, 2048, 3000),
                                                        (3, 1, 2, 1, 4, 2048, 2000), (4, 1, 2, 1, 1, 2048, 2000),
-                                                       (5, 1, 2, 2, 0, 2048, 2000)])
+                                                       (5, 1, 2, 2, 0, 2048, 2000),
+                                                       (7, 1, 1, 11, 11, 1024, 1500)])   # configs[3], crowded, full size
 def test_full_size_soak_invariants(task, kind, ft, nb, ny, B, steps):
     """BASELINE.json's batch sizes, thousands of steps (tens of millions of env-steps, thousands of
     contacts and resets): size-independent properties instead of the oracle.  Everything stays

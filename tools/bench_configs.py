@@ -61,12 +61,34 @@ def raw_ssl(name, ft, nb, ny, B, crowded, bytes_per_step, K=1000):
     sim.close()
 
 
+def raw_random(name, kind, ft, nb, ny, B, bytes_per_step, K=1000):
+    """raw simulator with commands drawn in the kernel (rsx_step_dev_random): no torch op in the loop"""
+    sim = L.Sim(kind, ft, nb, ny, 25, B)
+    sim.task_attach(L.TASK_SSL_SCRIMMAGE_CROWDED if "crowded" in name else L.TASK_SSL_SCRIMMAGE, 0, 0, 0)
+    sim.task_reset()                      # the scrimmage line-up, then the raw kernel takes over
+    tick = [0]
+    def run(n):
+        sim.step_dev_random(n, 1, tick[0], s); tick[0] += n
+    us = timeit(run, K)
+    rows.append((name, B, us, B / us, bytes_per_step * B / us / 1e3, float("nan"), float("nan")))
+    sim.close()
+
+
+SCRIM_BYTES = 2 * 4 * (5 + 11 * 22) + 4 * (2 + 2 * 22) + 4 + 1   # state r/w + obs + reward + done (commands are drawn on the device)
 fused("configs[1] VSS-v0 3v3 fused", 0, 0, 3, 3, 1, 4096, 541)
 fused("configs[2] SSLStaticDefenders-v0 1v6 fused", 1, 2, 1, 6, 2, 2048, 981)
 fused("SSLDribbling-v0 1v4 fused", 1, 2, 1, 4, 3, 2048, 2 * 4 * 60 + 4 * 40 + 4 * 21 + 5)
 fused("SSLContestedPossession-v0 1v1 fused", 1, 2, 1, 1, 4, 2048, 2 * 4 * 27 + 4 * 16 + 4 * 14 + 5)
 fused("SSLPassEndurance-v0 2v0 fused", 1, 2, 2, 0, 5, 2048, 2 * 4 * 27 + 4 * 16 + 4 * 16 + 5)
 fused("VSS-v0 on the 5v5 field (field_type 1) fused", 0, 1, 5, 5, 1, 4096, 2 * 4 * 66 + 4 * 20 + 4 * 64 + 5)
+fused("configs[3] SSL 11v11 scrimmage task (fused, every robot commanded), spread", 1, 1, 11, 11, L.TASK_SSL_SCRIMMAGE, 1024, SCRIM_BYTES)
+fused("configs[3] SSL 11v11 scrimmage task (fused), crowded: worst-case contacts", 1, 1, 11, 11, L.TASK_SSL_SCRIMMAGE_CROWDED, 1024, SCRIM_BYTES)
+fused("configs[3] SSL 11v11 scrimmage task (fused), spread", 1, 1, 11, 11, L.TASK_SSL_SCRIMMAGE, 65536, SCRIM_BYTES, K=200)
+fused("configs[3] SSL 11v11 scrimmage task (fused), crowded", 1, 1, 11, 11, L.TASK_SSL_SCRIMMAGE_CROWDED, 65536, SCRIM_BYTES, K=200)
+raw_random("configs[3] SSL 11v11 raw sim, device-drawn commands, spread", 1, 1, 11, 11, 1024, 2680)
+raw_random("configs[3] SSL 11v11 raw sim, device-drawn commands, crowded", 1, 1, 11, 11, 1024, 2680)
+raw_random("configs[3] SSL 11v11 raw sim, device-drawn commands, spread", 1, 1, 11, 11, 65536, 2680, K=200)
+raw_random("configs[3] SSL 11v11 raw sim, device-drawn commands, crowded", 1, 1, 11, 11, 65536, 2680, K=200)
 raw_ssl("configs[3] SSL 11v11 raw sim, spread", 1, 11, 11, 1024, False, 2680)
 raw_ssl("configs[3] SSL 11v11 raw sim, crowded (worst-case contacts)", 1, 11, 11, 1024, True, 2680)
 for B in (256, 1024, 16384, 65536, 262144, 1048576, 4194304):
