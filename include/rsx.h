@@ -208,6 +208,22 @@ int rsx_task_step_n(rsx_sim* h, int n, void* stream);
  * steps; obs / reward / done buffers hold the values of the last step). */
 int rsx_task_rollout(rsx_sim* h, int n, void* stream);
 
+/* ---- serving: policy-in-the-loop stepping without a kernel boundary per step ----------------- *
+ * rsx_serve_start launches ONE persistent kernel (on a stream of the handle's own) that keeps the
+ * state in registers and waits for doorbells.  rsx_serve_step(actions_dev, stream) is stream-ordered
+ * on the CALLER's stream: (copy the actions into the handle's action buffer unless they already are
+ * task_view.actions,) ring the doorbell, wait for the step's completion counter — two one-thread
+ * kernels, no host synchronisation, no state reload, no grid launch.  Work enqueued on
+ * `stream` afterwards sees the observations / rewards / flags of that step in the task view.  Results
+ * are bit-identical to rsx_task_step with the same actions.  While serving, every other call on the
+ * handle returns RSX_ERR_STATE; rsx_serve_stop stores the state back and ends the kernel.  The kernel
+ * also ends by itself when no doorbell arrives for timeout_ms (<= 0: 2000): a lost caller must not
+ * keep the GPU busy; the next rsx_serve_step then reports RSX_ERR_STATE.
+ * Supported: VSS-v0 3v3 and SSLStaticDefenders 1v6, at most 32768 envs per handle. */
+int rsx_serve_start(rsx_sim* h, int timeout_ms);
+int rsx_serve_step(rsx_sim* h, const float* actions_dev, void* stream);
+int rsx_serve_stop(rsx_sim* h);
+
 /* Debugging aid: number of non-finite floats in the state rows and, with a task attached, in the
  * observations, rewards and info rows.  Synchronises `stream`.  With RSX_DEBUG_FINITE=1 in the
  * environment every stepping call (rsx_step_dev, rsx_task_step, rsx_task_step_n, rsx_task_rollout)

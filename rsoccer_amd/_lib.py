@@ -35,6 +35,7 @@ SYMBOLS = (
     "rsx_reset_dev", "rsx_task_attach",
     "rsx_task_view_get", "rsx_task_reset", "rsx_task_reset_to", "rsx_task_step",
     "rsx_task_step_n", "rsx_task_rollout", "rsx_read_metrics", "rsx_check_finite",
+    "rsx_serve_start", "rsx_serve_step", "rsx_serve_stop",
 )
 
 
@@ -99,6 +100,9 @@ def load():
     lib.rsx_task_rollout.argtypes = [vp, ip, vp]
     lib.rsx_read_metrics.argtypes = [vp, vp, vp]
     lib.rsx_check_finite.argtypes = [vp, C.POINTER(C.c_int64), vp]
+    lib.rsx_serve_start.argtypes = [vp, ip]
+    lib.rsx_serve_step.argtypes = [vp, vp, vp]
+    lib.rsx_serve_stop.argtypes = [vp]
     if lib.rsx_abi_version() != 2:
         raise RsxError("librsx_hip.so ABI version mismatch")
     _lib = lib
@@ -320,6 +324,18 @@ class Sim:
 
     def task_rollout(self, n, stream=None):
         _chk(self._lib.rsx_task_rollout(self._h, int(n), self._stream(stream)))
+
+    def serve_start(self, timeout_ms=2000):
+        """persistent kernel: steps are requested with serve_step() (doorbell), no launch per step"""
+        _chk(self._lib.rsx_serve_start(self._h, int(timeout_ms)))
+
+    def serve_step(self, actions_ptr, stream=None):
+        rc = self._lib.rsx_serve_step(self._h, actions_ptr, stream)
+        if rc:
+            _chk(rc)
+
+    def serve_stop(self):
+        _chk(self._lib.rsx_serve_stop(self._h))
 
     def check_finite(self, stream=None):
         """Number of non-finite floats in state / obs / reward / info (debugging aid; synchronises)."""

@@ -72,6 +72,14 @@ struct rsx_sim {
     bool host_state_valid = false;
     bool host_state_cache = true;
     bool task_ready = false;   // a reset has opened the first episode
+    // persistent serving kernel (rsx_serve_*)
+    bool serving = false;
+    hipStream_t serve_stream = nullptr;
+    unsigned long long* sig_seq = nullptr;    // signal memory: doorbell
+    unsigned long long* sig_done = nullptr;   // signal memory: completion counter
+    unsigned long long serve_req = 0;         // steps requested so far
+    unsigned long long serve_waves = 0;       // waves of the serving grid
+    unsigned long long serve_timeout_ticks = 0;
 };
 
 namespace {
@@ -96,6 +104,20 @@ dim3 grid_for(const rsx_sim* h) {
 unsigned long long* g_dbg = nullptr;  // development builds: s_memtime stamps
 #endif
 
+// Serving doorbell and completion wait as one-thread kernels on the caller's stream.  (The stream memory
+// operations hipStreamWriteValue64 / hipStreamWaitValue64 would be the natural tools, but each costs
+// ~1.1 ms on this ROCm stack — measured, tools/exp_serve2.py — against ~2.5 us for a launch.)
+__global__ void serve_ring_kernel(unsigned long long* seq, unsigned long long value) {
+    __hip_atomic_store(seq, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void serve_wait_kernel(const unsigned long long* done, unsigned long long target, unsigned long long timeout) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < target) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > timeout) break;   // the serving kernel is gone: do not hang the stream
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
 // debugging aid (rsx_check_finite / RSX_DEBUG_FINITE=1): counts the non-finite floats of a buffer
 __global__ void count_nonfinite_kernel(const float* __restrict__ p, size_t n, unsigned long long* out) {
     unsigned long long bad = 0;
@@ -108,6 +130,7 @@ Buffers buffers_of(const rsx_sim* h, const float* actions) {
     Buffers b;
     b.state = h->d_state; b.aux = h->d_aux; b.obs = h->d_obs; b.final_obs = h->d_final_obs;
     b.flags = h->d_flags; b.cmds = h->d_cmds; b.actions = actions; b.metrics = h->d_metrics;
+    b.serve_seq = h->sig_seq; b.serve_done = h->sig_done; b.serve_base = 0; b.serve_timeout = 0;
 #ifdef RSX_TIMING
     b.dbg = g_dbg;
 #endif
@@ -263,8 +286,12 @@ struct DeviceGuard {
     DeviceGuard _guard;                                           \
     if (int _rc = _guard.enter((h)->device)) return _rc
 
+#define RSX_NOT_SERVING(h) \
+    if ((h)->serving) return fail(RSX_ERR_STATE, "the handle is serving (rsx_serve_start): only rsx_serve_step / rsx_serve_stop are valid until it stops")
+
 #define RSX_ENTER_TASK(h)                                                                        \
     RSX_ENTER(h);                                                                                \
+    RSX_NOT_SERVING(h);                                                                          \
     (h)->host_state_valid = false; /* every task call may change the state */                    \
     if ((h)->P.task == RSX_TASK_NONE) return fail(RSX_ERR_STATE, "no task attached (rsx_task_attach)")
 
@@ -315,6 +342,10 @@ void free_all(rsx_sim* h) {
     if (h->pin_cmds) (void)hipHostFree(h->pin_cmds);
     if (h->pin_state) (void)hipHostFree(h->pin_state);
     h->pin_cmds = h->pin_state = nullptr;
+    if (h->serve_stream) (void)hipStreamDestroy(h->serve_stream);
+    if (h->sig_seq) (void)hipFree(h->sig_seq);
+    if (h->sig_done) (void)hipFree(h->sig_done);
+    h->serve_stream = nullptr; h->sig_seq = h->sig_done = nullptr;
     if (h->d_state_alt) (void)hipFree(h->d_state_alt);
     h->d_state_alt = nullptr;
     if (h->d_check) (void)hipFree(h->d_check);
@@ -360,6 +391,8 @@ static int debug_finite(rsx_sim* h, hipStream_t s, const char* where) {
     if (bad) return fail(RSX_ERR_STATE, std::string("RSX_DEBUG_FINITE: ") + std::to_string(bad) + " non-finite value(s) after " + where);
     return RSX_OK;
 }
+
+static int serve_stop_impl(rsx_sim* h);
 
 extern "C" {
 
@@ -431,6 +464,7 @@ int rsx_destroy(rsx_sim* h) {
     if (!h) return RSX_OK;
     DeviceGuard guard;
     (void)guard.enter(h->device);
+    (void)serve_stop_impl(h);
     free_all(h);
     delete h;
     return RSX_OK;
@@ -445,6 +479,7 @@ int rsx_get_field_params(const rsx_sim* h, double out[RSX_FIELD_PARAMS]) {
 int rsx_reset(rsx_sim* h, const double* ball, const double* blue, const double* yellow,
               const uint8_t* env_mask, void* stream) {
     RSX_ENTER(h);
+    RSX_NOT_SERVING(h);
     if (!ball || (h->P.n_blue && !blue) || (h->P.n_yellow && !yellow)) return fail(RSX_ERR_ARG, "null placement array");
     hipStream_t s = (hipStream_t)stream;
     std::vector<float> soa;
@@ -456,6 +491,7 @@ int rsx_reset(rsx_sim* h, const double* ball, const double* blue, const double* 
 
 int rsx_step(rsx_sim* h, const double* cmds, void* stream) {
     RSX_ENTER(h);
+    RSX_NOT_SERVING(h);
     if (!cmds) return fail(RSX_ERR_ARG, "cmds is null");
     hipStream_t s = (hipStream_t)stream;
     const Params& P = h->P;
@@ -488,18 +524,21 @@ static int get_state_impl(rsx_sim* h, double* out, int rows, hipStream_t s) {
 
 int rsx_get_state(rsx_sim* h, double* out, void* stream) {
     RSX_ENTER(h);
+    RSX_NOT_SERVING(h);
     if (!out) return fail(RSX_ERR_ARG, "out is null");
     return get_state_impl(h, out, h->P.state_dim, (hipStream_t)stream);
 }
 
 int rsx_get_state_full(rsx_sim* h, double* out, void* stream) {
     RSX_ENTER(h);
+    RSX_NOT_SERVING(h);
     if (!out) return fail(RSX_ERR_ARG, "out is null");
     return get_state_impl(h, out, h->P.state_dim + X_ROWS, (hipStream_t)stream);
 }
 
 int rsx_set_state(rsx_sim* h, const double* state, void* stream) {
     RSX_ENTER(h);
+    RSX_NOT_SERVING(h);
     if (!state) return fail(RSX_ERR_ARG, "state is null");
     const size_t B = (size_t)h->P.num_envs;
     const int rows = h->P.state_dim + X_ROWS;
@@ -520,6 +559,7 @@ int rsx_dev_view_get(rsx_sim* h, rsx_dev_view* out) {
 
 int rsx_step_dev(rsx_sim* h, void* stream) {
     RSX_ENTER(h);
+    RSX_NOT_SERVING(h);
     h->host_state_valid = false;
     launch_sim(h, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
@@ -546,6 +586,7 @@ int rsx_state_buffers(rsx_sim* h, float** current, float** other) {
 
 int rsx_step_dev_random(rsx_sim* h, int n, uint64_t seed, uint32_t first_tick, void* stream) {
     RSX_ENTER(h);
+    RSX_NOT_SERVING(h);
     if (n < 1) return fail(RSX_ERR_ARG, "n must be >= 1");
     if ((uint64_t)first_tick + (uint64_t)n > 0x7FFFFFFFull) return fail(RSX_ERR_ARG, "tick range exceeds 2^31");
     h->host_state_valid = false;
@@ -556,6 +597,7 @@ int rsx_step_dev_random(rsx_sim* h, int n, uint64_t seed, uint32_t first_tick, v
 
 int rsx_step_dev_flip(rsx_sim* h, void* stream) {
     RSX_ENTER(h);
+    RSX_NOT_SERVING(h);
     if (int rc = ensure_alt(h)) return rc;
     h->host_state_valid = false;
     launch_sim(h, (hipStream_t)stream, h->d_state_alt);
@@ -567,6 +609,7 @@ int rsx_step_dev_flip(rsx_sim* h, void* stream) {
 int rsx_reset_dev(rsx_sim* h, const float* ball_dev, const float* blue_dev, const float* yellow_dev,
                   const uint8_t* env_mask_dev, void* stream) {
     RSX_ENTER(h);
+    RSX_NOT_SERVING(h);
     if (!ball_dev || (h->P.n_blue && !blue_dev) || (h->P.n_yellow && !yellow_dev)) return fail(RSX_ERR_ARG, "null placement array");
     h->host_state_valid = false;
     const int B = h->P.num_envs;
@@ -697,6 +740,87 @@ int rsx_task_rollout(rsx_sim* h, int n, void* stream) {
     launch_task(h, nullptr, n, MODE_ROLLOUT, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return debug_finite(h, (hipStream_t)stream, "rsx_task_rollout");
+}
+
+// ---- persistent serving kernel ----------------------------------------------------------------
+static int serve_stop_impl(rsx_sim* h) {
+    if (!h->serving) return RSX_OK;
+    // the stop request goes through a stream-ordered write like every doorbell; the kernel stores the
+    // state and leaves, then the serving stream drains
+    hipLaunchKernelGGL(serve_ring_kernel, dim3(1), dim3(1), 0, h->cap_stream, h->sig_seq, SERVE_STOP | h->serve_req);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(h->cap_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->serve_stream);
+    h->serving = false;
+    if (e != hipSuccess) return fail(RSX_ERR_HIP, std::string("rsx_serve_stop: ") + hipGetErrorString(e));
+    return RSX_OK;
+}
+
+int rsx_serve_start(rsx_sim* h, int timeout_ms) {
+    RSX_ENTER_TASK(h);
+    RSX_NEED_RESET(h);
+    const Params& P = h->P;
+    const bool vss = P.task == RSX_TASK_VSS_V0 && h->NR == 6 && h->L == 8;
+    const bool sd = P.task == RSX_TASK_SSL_STATIC_DEFENDERS && h->NR == 7 && h->L == 8;
+    if (!vss && !sd) return fail(RSX_ERR_ARG, "serving supports VSS-v0 3v3 and SSLStaticDefenders 1v6 (8 lanes per env)");
+    const dim3 grid = grid_for(h);
+    if (grid.x > 4096) return fail(RSX_ERR_ARG, "serving needs every workgroup resident at once: at most 32768 envs");
+    if (timeout_ms <= 0) timeout_ms = 2000;
+    if (!h->sig_seq) {
+        HIP_TRY(hipExtMallocWithFlags((void**)&h->sig_seq, 8, hipMallocSignalMemory));
+        HIP_TRY(hipExtMallocWithFlags((void**)&h->sig_done, 8, hipMallocSignalMemory));
+    }
+    if (!h->serve_stream) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // numerically lowest = highest priority
+        int prio = lo;                                     // the serving kernel: lowest priority by default
+        if (const char* p = std::getenv("RSX_SERVE_PRIO")) prio = std::atoi(p);
+        HIP_TRY(hipStreamCreateWithPriority(&h->serve_stream, hipStreamNonBlocking, prio));
+    }
+    HIP_TRY(hipDeviceSynchronize());   // everything issued so far (resets, steps) is in memory
+    const unsigned long long zero = 0;
+    HIP_TRY(hipMemcpy(h->sig_seq, &zero, 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->sig_done, &zero, 8, hipMemcpyHostToDevice));
+    h->serve_req = 0;
+    h->serve_waves = grid.x;
+    Buffers b = buffers_of(h, h->d_actions);
+    b.serve_timeout = (unsigned long long)timeout_ms * 100000ull;   // s_memrealtime ticks at 100 MHz
+    h->serve_timeout_ticks = b.serve_timeout;
+    hipStream_t s = h->serve_stream;
+    if (vss) RSX_LAUNCH((task_step_kernel<RSX_KIND_VSS, 8, RSX_TASK_VSS_V0, 6, MODE_SERVE>), h->P, b, 0);
+    else RSX_LAUNCH((task_step_kernel<RSX_KIND_SSL, 8, RSX_TASK_SSL_STATIC_DEFENDERS, 7, MODE_SERVE>), h->P, b, 0);
+    HIP_TRY(hipGetLastError());
+    (void)hipStreamQuery(h->serve_stream);   // make sure the launch is submitted now, not with the caller's next call
+    h->serving = true;
+    return RSX_OK;
+}
+
+int rsx_serve_step(rsx_sim* h, const float* actions_dev, void* stream) {
+    RSX_ENTER(h);
+    if (!h->serving) return fail(RSX_ERR_STATE, "rsx_serve_start first");
+    if (hipStreamQuery(h->serve_stream) != hipErrorNotReady) {   // the kernel left on its own: no request within the timeout
+        h->serving = false;
+        return fail(RSX_ERR_STATE, "the serving kernel is no longer running (no request within its timeout): state saved, serving ended");
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (actions_dev && actions_dev != h->d_actions)
+        HIP_TRY(hipMemcpyAsync(h->d_actions, actions_dev, (size_t)h->P.num_envs * h->M.act_dim * sizeof(float), hipMemcpyDeviceToDevice, s));
+    h->serve_req += 1;
+    static const bool memops = std::getenv("RSX_SERVE_MEMOPS") != nullptr;   // development: the stream-memory-operation form (slow)
+    if (memops) {
+        HIP_TRY(hipStreamWriteValue64(s, h->sig_seq, h->serve_req, 0));
+        HIP_TRY(hipStreamWaitValue64(s, h->sig_done, h->serve_req * h->serve_waves, hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull));
+        return RSX_OK;
+    }
+    hipLaunchKernelGGL(serve_ring_kernel, dim3(1), dim3(1), 0, s, h->sig_seq, h->serve_req);
+    hipLaunchKernelGGL(serve_wait_kernel, dim3(1), dim3(1), 0, s, h->sig_done, h->serve_req * h->serve_waves, h->serve_timeout_ticks);
+    HIP_TRY(hipGetLastError());
+    return RSX_OK;
+}
+
+int rsx_serve_stop(rsx_sim* h) {
+    RSX_ENTER(h);
+    return serve_stop_impl(h);
 }
 
 int rsx_check_finite(rsx_sim* h, int64_t* n_bad, void* stream) {
