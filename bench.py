@@ -24,6 +24,9 @@ Prints ONE JSON line on rank 0 (see the driver contract).  Besides the contract'
   rollout       the same K steps inside ONE launch
   sweep         (N = 1) per-step and one-launch legs at 65 536 / 1 048 576 / 4 194 304 envs with their
                 own roofline fractions: where the path is bandwidth-bound
+  configs       (N = 1) BASELINE.json configs[2] (SSLStaticDefenders 1v6 @ 2048) and configs[3] (SSL 11v11
+                @ 1024, spread and crowded line-ups: the scrimmage task, every robot commanded on device),
+                each also at a bandwidth-bound batch, with SURVEY.md 8(d)'s algorithmic bytes
   python_layer  (N = 1) rate of the Python API on top of the C-ABI, and the reference's Python-layer
                 ceiling restated from SURVEY.md
   cpu_baseline  (N = 1) the CPU oracle on this box's host cores, bounded sample
@@ -356,6 +359,7 @@ def main():
 
     if rank == 0 and world == 1 and extra:
         line["sweep"] = sweep(L, torch, dev, timed)
+        line["configs"] = other_configs(L, torch, dev, timed)
         line["python_layer"] = python_layer(torch, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(B)
@@ -392,6 +396,34 @@ def sweep(L, torch, dev, timed, n=100, warm=30):
                         "steps": n, "warmup": warm})
         except Exception as ex:   # a failed sweep point must not lose the headline line
             out.append({"envs": B, "error": repr(ex)})
+    return out
+
+
+def other_configs(L, torch, dev, timed):
+    """The other single-GPU configurations of BASELINE.json, fused, one launch per step, device-side random
+    actions; algorithmic bytes per env-step from SURVEY.md 8(d): state r/w + commands + obs + reward + done."""
+    SD = 2 * 4 * (5 + 11 * 7) + 4 * 8 * 7 + 4 * 24 + 5          # 981
+    SC = 2 * 4 * (5 + 11 * 22) + 4 * 8 * 22 + 4 * 46 + 5        # 2869
+    cases = (("configs[2] SSLStaticDefenders-v0 1v6", 1, 2, 1, 6, L.TASK_SSL_STATIC_DEFENDERS, 2048, SD, 2000, 200),
+             ("SSLStaticDefenders-v0 1v6, bandwidth-bound batch", 1, 2, 1, 6, L.TASK_SSL_STATIC_DEFENDERS, 262144, SD, 100, 30),
+             ("configs[3] SSL 11v11 division-A, scrimmage task, spread line-up", 1, 1, 11, 11, L.TASK_SSL_SCRIMMAGE, 1024, SC, 1000, 100),
+             ("configs[3] SSL 11v11 division-A, scrimmage task, crowded line-up (worst-case contacts)", 1, 1, 11, 11,
+              L.TASK_SSL_SCRIMMAGE_CROWDED, 1024, SC, 1000, 100),
+             ("SSL 11v11 scrimmage, crowded, bandwidth-bound batch", 1, 1, 11, 11, L.TASK_SSL_SCRIMMAGE_CROWDED, 65536, SC, 60, 20))
+    out = []
+    for name, kind, ft, nb, ny, task, B, bytes_, n, warm in cases:
+        try:
+            s = L.Sim(kind, ft, nb, ny, 25, B, dev)
+            s.task_attach(task, seed=0, env_id_base=0, max_episode_steps=0)
+            s.task_reset(torch.cuda.current_stream().cuda_stream)
+            w, d = timed(s, n, warm, "step")
+            s.close()
+            us = d * 1e3 / n
+            out.append({"workload": name, "envs": B, "us_per_step": us, "value": B * n / w, "unit": "env-steps/s",
+                        "algorithmic_bytes_per_env_step": bytes_, "roofline_frac": bytes_ * B / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                        "steps": n, "warmup": warm})
+        except Exception as ex:
+            out.append({"workload": name, "envs": B, "error": repr(ex)})
     return out
 
 

@@ -28,7 +28,7 @@ struct EplShared {
     // phase 1 (contacts of a sub-step, only when some lane touches something): snapshot + sums,
     // phase 2 (after the physics): observation rows; the two never live together
     union {
-        struct { float snap[5][EPL_NB][64]; float acc[4][EPL_NB][64]; float accw[64]; } c;
+        struct { float acc[4][EPL_NB][64]; float accw[64]; } c;
         float stage[64 * EPL_ODP];
     } u;
     // (the reset placement keeps its poses in the resetting env's own observation row: that row
@@ -226,17 +226,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             for (int sweep = 0; sweep < 2; ++sweep) {   // the second sweep runs the same (cached) instructions
                 const unsigned touching = (sweep == 0 || deep) ? find_touching() : 0u;   // second: envs with a deep pair only
                 if (!__any(touching != 0)) break;
-                // some env of the wave has a contact: bodies are addressed by index from here on,
-                // so the snapshot and the sums go through LDS (column = lane, conflict free)
-#pragma unroll
-                for (int k = 0; k < N; ++k) {
-                    sh.u.c.snap[0][k][lane] = r[k].x; sh.u.c.snap[1][k][lane] = r[k].y;
-                    sh.u.c.snap[2][k][lane] = r[k].vx; sh.u.c.snap[3][k][lane] = r[k].vy;
-                    sh.u.c.snap[4][k][lane] = r[k].om;
-                }
-                sh.u.c.snap[0][N][lane] = ball.x; sh.u.c.snap[1][N][lane] = ball.y;
-                sh.u.c.snap[2][N][lane] = ball.vx; sh.u.c.snap[3][N][lane] = ball.vy;
-                sh.u.c.snap[4][N][lane] = ball.om;
+                // some env of the wave has a contact: the sums are addressed by body index and go through
+                // LDS (column = lane, conflict free); the bodies themselves are picked out of the registers
+                // by select chains (a snapshot in LDS would cost a wave of occupancy: 9 KB per wave)
 #pragma unroll
                 for (int k = 0; k < EPL_NB; ++k) {
                     sh.u.c.acc[0][k][lane] = 0.0f; sh.u.c.acc[1][k][lane] = 0.0f;
@@ -253,9 +245,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     epl_pair(p, i, j);
                     const bool rb = j == N;
                     Body bi = Body{}, bj = Body{};
-                    bi.x = sh.u.c.snap[0][i][lane]; bi.y = sh.u.c.snap[1][i][lane]; bi.vx = sh.u.c.snap[2][i][lane]; bi.vy = sh.u.c.snap[3][i][lane];
-                    bj.x = sh.u.c.snap[0][j][lane]; bj.y = sh.u.c.snap[1][j][lane]; bj.vx = sh.u.c.snap[2][j][lane]; bj.vy = sh.u.c.snap[3][j][lane];
-                    const float wi = sh.u.c.snap[4][i][lane], wj = sh.u.c.snap[4][j][lane];
+                    float wi = 0.0f, wj = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < N; ++k) {   // i < N always; j may be the ball
+                        if (i == k) { bi.x = r[k].x; bi.y = r[k].y; bi.vx = r[k].vx; bi.vy = r[k].vy; wi = r[k].om; }
+                        if (j == k) { bj.x = r[k].x; bj.y = r[k].y; bj.vx = r[k].vx; bj.vy = r[k].vy; wj = r[k].om; }
+                    }
+                    if (j == N) { bj.x = ball.x; bj.y = ball.y; bj.vx = ball.vx; bj.vy = ball.vy; wj = ball.om; }
                     const float rs = rb ? K::rs_rb : K::rs_rr, ope = rb ? K::ope_rb : K::ope_rr;
                     const float mu = rb ? K::mu_rb : K::mu_rr;
                     const float lever_j = rb ? K::r_ball : K::r_robot;
@@ -284,26 +280,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     }
                 }
                 wave_sync();
-                // Positions and velocities come back from the snapshot (their registers were free during
-                // the walk: that is a wave of occupancy); only a body that touched something is updated,
-                // the others keep their bits
+                // only a body that touched something is updated (the others keep their bits); the registers
+                // still hold the snapshot: nothing was modified during the walk
 #pragma unroll
                 for (int k = 0; k < N; ++k) {
-                    const bool got = (touching & PM[k]) != 0;
-                    const float sx = sh.u.c.snap[0][k][lane], sy = sh.u.c.snap[1][k][lane];
-                    const float svx = sh.u.c.snap[2][k][lane], svy = sh.u.c.snap[3][k][lane];
-                    const float a0 = sh.u.c.acc[0][k][lane], a1 = sh.u.c.acc[1][k][lane];
-                    const float a2 = sh.u.c.acc[2][k][lane], a3 = sh.u.c.acc[3][k][lane];
-                    r[k].vx = got ? svx + a0 : svx; r[k].vy = got ? svy + a1 : svy;
-                    r[k].x = got ? sx + a2 : sx; r[k].y = got ? sy + a3 : sy;
+                    if (touching & PM[k]) {
+                        r[k].vx = r[k].vx + sh.u.c.acc[0][k][lane]; r[k].vy = r[k].vy + sh.u.c.acc[1][k][lane];
+                        r[k].x = r[k].x + sh.u.c.acc[2][k][lane]; r[k].y = r[k].y + sh.u.c.acc[3][k][lane];
+                    }
                 }
-                {
-                    const bool got = (touching & PM[N]) != 0;
-                    const float sx = sh.u.c.snap[0][N][lane], sy = sh.u.c.snap[1][N][lane];
-                    const float svx = sh.u.c.snap[2][N][lane], svy = sh.u.c.snap[3][N][lane], sw = sh.u.c.snap[4][N][lane];
-                    ball.vx = got ? svx + sh.u.c.acc[0][N][lane] : svx; ball.vy = got ? svy + sh.u.c.acc[1][N][lane] : svy;
-                    ball.x = got ? sx + sh.u.c.acc[2][N][lane] : sx; ball.y = got ? sy + sh.u.c.acc[3][N][lane] : sy;
-                    ball.om = got ? sw + sh.u.c.accw[lane] : sw;
+                if (touching & PM[N]) {
+                    ball.vx = ball.vx + sh.u.c.acc[0][N][lane]; ball.vy = ball.vy + sh.u.c.acc[1][N][lane];
+                    ball.x = ball.x + sh.u.c.acc[2][N][lane]; ball.y = ball.y + sh.u.c.acc[3][N][lane];
+                    ball.om = ball.om + sh.u.c.accw[lane];
                 }
                 wave_sync();
             }
