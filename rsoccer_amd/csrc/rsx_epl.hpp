@@ -117,8 +117,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     ball.z = rawb[2] - K::r_ball; ball.vz = rawb[5]; ball.om = rawb[6];
     // the three internal ball rows (height, vertical speed, spin) rarely change in VSS: they are
     // written back only when they did
-    const float z_in = rawb[2], vz_in = rawb[5], spin_in = rawb[6];
-    const uint32_t episode_in = episode;
+    const bool ball_extra_in = rawb[2] != K::r_ball || rawb[5] != 0.0f || rawb[6] != 0.0f;   // anything but "resting, no spin"
+    bool new_episode = false;
 
     float reward = 0.0f; int term = 0, trunc = 0;
 
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         if (__any(ended)) {
             if (ended) {
                 for (int i = 0; i < EPL_OD; ++i) bufs.final_obs[(size_t)e * EPL_OD + i] = row[i];
-                episode += 1;
+                episode += 1; new_episode = true;
                 atomicAdd(&bufs.metrics[1], 1ull);
                 if (info[4] > 0.0f) atomicAdd(&bufs.metrics[2], 1ull);
                 if (info[5] > 0.0f) atomicAdd(&bufs.metrics[3], 1ull);
@@ -468,11 +468,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         st[0] = ball.x; st[B] = ball.y; st[3 * B] = ball.vx; st[4 * B] = ball.vy;
         const float z_out = K::r_ball + ball.z;
-        if (z_out != z_in) st[2 * B] = z_out;
-        if (ball.vz != vz_in) st[(size_t)P.state_dim * B] = ball.vz;
-        if (ball.om != spin_in) st[(size_t)(P.state_dim + 1) * B] = ball.om;
+        if (ball_extra_in || z_out != K::r_ball || ball.vz != 0.0f || ball.om != 0.0f) {   // was or is off its resting values
+            st[2 * B] = z_out; st[(size_t)P.state_dim * B] = ball.vz; st[(size_t)(P.state_dim + 1) * B] = ball.om;
+        }
         auxe[(size_t)ROW_STEPS * B] = __int_as_float(steps);
-        if (!STEP || episode != episode_in) auxe[(size_t)ROW_EPISODE * B] = __uint_as_float(episode);
+        if (!STEP || new_episode) auxe[(size_t)ROW_EPISODE * B] = __uint_as_float(episode);
     }
     if (counts_steps) bufs.metrics[0] = steps_before + (unsigned long long)P.num_envs * (unsigned long long)n_steps;
 }

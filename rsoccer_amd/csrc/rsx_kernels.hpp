@@ -1169,8 +1169,11 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
     float info[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     float prev_pot = 0.0f, ep_ret = 0.0f;
     if (is_ball) {
+        // VSS-v0: rows 0, 4, 5 (goal counters) are zero except on a terminal step, and the step after it
+        // clears them: they are neither read nor — in the common case — written
 #pragma unroll
-        for (int i = 0; i < ID; ++i) info[i] = auxe[(size_t)(ROW_INFO + i) * B];
+        for (int i = 0; i < ID; ++i)
+            if (!(TASK == RSX_TASK_VSS_V0 && (i == 0 || i >= 4))) info[i] = auxe[(size_t)(ROW_INFO + i) * B];
         prev_pot = auxe[(size_t)ROW_PREV_POT * B];
         if (TASK != RSX_TASK_VSS_V0) ep_ret = auxe[(size_t)ROW_EP_RET * B];   // VSS-v0: derived from the info terms
     }
@@ -1501,7 +1504,8 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
                 // info is reported as it stands after this step (cleared lazily at the next
                 // episode's first step), like the dict the reference returns with `done`
 #pragma unroll
-                for (int i = 0; i < ID; ++i) auxe[(size_t)(ROW_INFO + i) * B] = info[i];
+                for (int i = 0; i < ID; ++i)
+                    if (!(TASK == RSX_TASK_VSS_V0 && (i == 0 || i >= 4)) || term || first_step) auxe[(size_t)(ROW_INFO + i) * B] = info[i];
                 auxe[(size_t)ROW_REWARD * B] = reward;
                 bufs.flags[e] = (uint8_t)term; bufs.flags[B + e] = (uint8_t)trunc;
             }

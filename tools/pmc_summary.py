@@ -19,8 +19,8 @@ res = {
     "WRITE_SIZE_KB_median_per_launch": vals["WRITE_SIZE"],
     "correction": "MI355X_MICROARCH.md HBM section: counters are in KB; on gfx950 FETCH_SIZE reports half of the fetched bytes -> doubled; WRITE_SIZE taken as is",
     "bytes_per_launch": None if None in vals.values() else int(2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024),
-    "expected_from_layout": {"read_B_per_env": 248, "write_B_per_env": 414,
-                             "note": "state 42 f32 + steps/episode + OU 10 + info 6 + prev_pot/ep_ret read; the same + obs 40 f32 + reward + 2 flag bytes written"},
+    "expected_from_layout": {"read_B_per_env": 252, "write_B_per_env": 418,
+                             "note": "state 44 f32 (36 robot + 5 ball + height, vz, spin) + steps/episode + OU 10 + info 6 + prev_pot read; the same + obs 40 f32 + reward + 2 flag bytes written"},
     "algorithmic_bytes_per_launch": 541 * B,
 }
 print(json.dumps(res, indent=1))

@@ -2,7 +2,7 @@
 # Runs on the MI355X box (via gpurun): regenerates every artefact kept under profiles/.
 # usage: tools/refresh_profiles.sh <tag>     (outputs under gpurun_out/<tag>/)
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -24,3 +24,17 @@ python tools/rocpd_summary.py $(find $OUT/sq -name "*.db" | head -1) > $OUT/sq_c
 grep "task_step_kernel<0, 8, 1, 6, 3>" $OUT/sq_counters_rollout200.txt | head -12
 python tools/bench_configs.py $OUT/configs_and_sweep.md > $OUT/configs.log 2>&1
 cat $OUT/configs_and_sweep.md
+# the driver's own flags
+python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_flags.json 2> $OUT/bench_driver_flags.err
+# one-lane-per-env kernel at 1 M envs: SQ + HBM counters
+tools/prof_epl.sh $OUT/epl > $OUT/epl.log 2>&1
+cat $OUT/epl/*.txt > $OUT/epl_counters_1M.txt
+# batched hooks: no host <-> device copy inside step()
+rocprofv3 --memory-copy-trace --kernel-trace --stats --output-format csv -d $OUT/hooks -- python tools/hooks_nocopy.py > $OUT/hooks.log 2>&1
+find $OUT/hooks -name "*memory_copy_stats.csv" -o -name "*memory_copy_trace.csv" | head -3
+( echo "# rocprofv3 --memory-copy-trace -- python tools/hooks_nocopy.py (4096 envs, 300 steps of a hook-written task)"; grep -E "STEPS" $OUT/hooks.log;
+  for f in $(find $OUT/hooks -name "*memory_copy_trace.csv" | head -1); do echo "memory copies in the whole run: $(($(wc -l < $f) - 1))"; python tools/memcopy_window.py $f $OUT/hooks; done ) > $OUT/hooks_memcopy.txt 2>&1
+cat $OUT/hooks_memcopy.txt
+# in-kernel timeline of the headline kernel
+tools/build_timing.sh > /dev/null 2>&1 && RSX_LIB=tools/_dev/librsx_hip_timing.so python tools/exp_timeline2.py > $OUT/timeline.txt 2>&1
+head -40 $OUT/timeline.txt
