@@ -23,6 +23,13 @@
  *   - a handle is not thread-safe; distinct handles are independent.
  *   - there is NO CPU fallback: creation fails (RSX_ERR_NO_DEVICE) without a gfx950 device.
  *
+ * Precision: the engine computes in float32.  Stated tolerance against the float64 instantiation
+ * of the same model (the reference's boundary type, rsim.py:105), from the same state under the same
+ * commands over 1 s (40 steps): |position| <= 1e-4 m, |velocity| <= 1e-3 m/s for every body
+ * (tests/test_model_tolerance.py; crowded 22-robot scrums: 1e-2 m / 0.1 m/s, >= 95 % of the envs
+ * within the tight bound).  The physics is this project's own 2-D model: rc-robosim's
+ * sources are not part of the reference tree, so trajectories are not comparable with rSim's.
+ *
  * Units (Entities/Frame.py:8): m, m/s, degrees, degrees/s.  VSS commands are wheel rad/s
  * (vss_gym.py:250-252); SSL commands are robot-local m/s and rad/s or wheel rad/s
  * (rsim.py:137-153).
