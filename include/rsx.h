@@ -188,6 +188,9 @@ int rsx_step_dev_random(rsx_sim* h, int n, uint64_t seed, uint32_t first_tick, v
  * SCRIMMAGE / SCRIMMAGE_CROWDED: SSL, any team sizes).  seed + (env_id_base + local env index) key every random draw,
  * so results do not depend on batch size, batch position or sharding.
  * max_episode_steps <= 0 selects the registry value (1200 / 1000 / 4800 / 1200 / 1200; scrimmage 1200). */
+/* Random streams: placement draws are keyed by (seed, global env id, episode, index); the per-step draws
+ * (random actions, OU noise) by (seed, global env id, number of fused steps the handle has taken since
+ * attach) — a run is reproducible from its seed and its sequence of calls. */
 int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base,
                     int max_episode_steps);
 int rsx_task_view_get(rsx_sim* h, rsx_task_view* out);
@@ -208,8 +211,8 @@ int rsx_task_reset_to(rsx_sim* h, const double* ball, const double* blue, const 
  * done, TimeLimit and same-step auto-reset. */
 int rsx_task_step(rsx_sim* h, const float* actions_dev, void* stream);
 /* n consecutive random-action steps = n kernel launches issued from C (no per-step FFI cost).
- * With RSX_USE_GRAPH=1 in the environment they are replayed from a cached hipGraph instead
- * (measured slower on MI355X / ROCm 7: ~2.7 us per graph node vs back-to-back eager launches). */
+ * (A hipGraph replay of the same launches was measured slower on MI355X / ROCm 7 — ~2.7 us per graph
+ * node vs back-to-back eager launches — and is not offered.) */
 int rsx_task_step_n(rsx_sim* h, int n, void* stream);
 /* n consecutive random-action steps inside ONE launch (state stays in registers between
  * steps; obs / reward / done buffers hold the values of the last step). */

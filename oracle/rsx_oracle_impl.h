@@ -33,6 +33,7 @@ typedef struct SUF(rsxo_env) {
     /* ---- task ---- */
     int task, obs_dim, act_dim, info_dim, max_steps;
     uint32_t key[2], env_id, episode;
+    uint32_t tick;   /* step() calls since attach: what the per-step draws are keyed by */
     int steps;
     R max_pos, inv_max_pos, max_v, inv_max_v, inv_max_w, deadzone;
     R ou[MAXROB][2];
@@ -543,6 +544,14 @@ void SUF(rsxo_step_random)(void* p, uint64_t seed, uint64_t env_id, uint32_t tic
  * TASKS
  * ======================================================================================== */
 
+/* per-step draws (actions, OU noise): keyed by the number of step() calls since attach, NOT by the env's
+ * episode / step counters — the engine can then draw while those counters are still on their way from
+ * memory (they are only needed for TimeLimit and placement) */
+static void SUF(draw_step)(const SUF(rsxo_env)* e, uint32_t dom, uint32_t out[4]) {
+    uint32_t ctr[4] = {e->env_id, 0u, e->tick, dom};
+    rsxo_philox4x32_7(ctr, e->key, out);
+}
+/* placement draws: keyed by (episode, index of the draw) */
 static void SUF(draw)(const SUF(rsxo_env)* e, uint32_t tick, uint32_t dom, uint32_t out[4]) {
     uint32_t ctr[4] = {e->env_id, e->episode, tick, dom};
     rsxo_philox4x32_7(ctr, e->key, out);
@@ -579,7 +588,7 @@ int SUF(rsxo_task_attach)(void* p, int task, uint64_t seed, uint64_t env_id, int
     } else return -1;
     e->task = task;
     e->key[0] = (uint32_t)seed; e->key[1] = (uint32_t)(seed >> 32);
-    e->env_id = (uint32_t)env_id; e->episode = 0xFFFFFFFFu; e->steps = 0;
+    e->env_id = (uint32_t)env_id; e->episode = 0xFFFFFFFFu; e->steps = 0; e->tick = 0;
     /* normalisers — vss_gym_base.py:52-58 / ssl_gym_base.py:53-59 */
     double max_pos = fmax(f[1] / 2, f[0] / 2 + f[2]);
     double max_v = (f[16] / 60.0) * 2.0 * RSXO_PI * f[15];
@@ -935,11 +944,10 @@ void SUF(rsxo_task_step)(void* p, const float* action) {
     const rsxo_cfg* c = &e->cfg;
     const int N = c->n_robots;
     uint32_t u[4];
-    const uint32_t t = (uint32_t)e->steps;
     const int first_step = e->steps == 0;
     if (first_step) { memset(e->info, 0, sizeof(e->info)); e->ep_ret = RC(0); }
     R a[8];
-    SUF(draw)(e, t, RSXO_DOM_ACT, u);   /* block 0 of the step (VSS-v0: robot 1 owns its words 2, 3) */
+    SUF(draw_step)(e, RSXO_DOM_ACT, u);   /* block 0 of the step (VSS-v0: robot 1 owns its words 2, 3) */
     if (e->task >= 6) { /* handled per robot below */ }
     else if (action) for (int i = 0; i < e->act_dim; ++i) a[i] = RC(action[i]);
     else {
@@ -956,7 +964,7 @@ void SUF(rsxo_task_step)(void* p, const float* action) {
         R act[MAXROB * 2];
         act[0] = a[0]; act[1] = a[1];
         for (int k = 1; k < N; ++k) { /* Utils.py:14-21, Box-Muller on Philox: words of block k >> 1 */
-            if (k % 2 == 0) SUF(draw)(e, t, RSXO_DOM_ACT | ((uint32_t)(k >> 1) << 8), u);
+            if (k % 2 == 0) SUF(draw_step)(e, RSXO_DOM_ACT | ((uint32_t)(k >> 1) << 8), u);
             const uint32_t w0 = u[2 * (k & 1)], w1 = u[2 * (k & 1) + 1];
             R u1 = RC((w0 >> 8) + 1u) * RC(5.9604644775390625e-08);
             R ang = (SUF(u01)(w1) - RC(0.5)) * RC(6.283185307179586);
@@ -975,7 +983,7 @@ void SUF(rsxo_task_step)(void* p, const float* action) {
             R q[4];
             if (action) for (int i = 0; i < 4; ++i) q[i] = RC(action[4 * k + i]);
             else {
-                SUF(draw)(e, t, RSXO_DOM_ACT | ((uint32_t)k << 8), u);
+                SUF(draw_step)(e, RSXO_DOM_ACT | ((uint32_t)k << 8), u);
                 for (int i = 0; i < 4; ++i) q[i] = SUF(u01)(u[i]) * RC(2) - RC(1);
             }
             cmds[8 * k + 1] = q[0] * e->max_v; cmds[8 * k + 2] = q[1] * e->max_v; cmds[8 * k + 3] = q[2] * RC(10.0);
@@ -989,6 +997,7 @@ void SUF(rsxo_task_step)(void* p, const float* action) {
     SUF(task_obs)(e, e->obs);
     SUF(task_reward)(e, last, cmds, first_step);
     e->steps += 1;
+    e->tick += 1;
     e->ep_ret = e->ep_ret + e->reward;
     e->truncated = (uint8_t)(e->steps >= e->max_steps);
     e->metrics[0] += 1;

@@ -9,7 +9,6 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
-#include <map>
 #include <string>
 #include <vector>
 
@@ -60,8 +59,7 @@ struct rsx_sim {
     uint8_t* d_flags = nullptr;
     unsigned long long* d_metrics = nullptr;
     unsigned long long* d_check = nullptr;   // rsx_check_finite counter
-    hipStream_t cap_stream = nullptr;
-    std::map<int, hipGraphExec_t> graphs;
+    hipStream_t cap_stream = nullptr;   // utility stream (serve stop)
     std::vector<float> h_f32;
     // host-format path: pinned staging; rsx_step() brings the new state back with its own
     // synchronisation, so the rsx_get_state() that follows it (rsim.py:102 then :105) is a pure
@@ -80,6 +78,7 @@ struct rsx_sim {
     unsigned long long serve_req = 0;         // steps requested so far
     unsigned long long serve_waves = 0;       // waves of the serving grid
     unsigned long long serve_timeout_ticks = 0;
+    uint32_t tick = 0;                        // fused steps taken since attach (key of the per-step draws)
 };
 
 namespace {
@@ -336,8 +335,6 @@ void apply_reset(const rsx_sim* h, std::vector<float>& soa, const double* ball, 
 }
 
 void free_all(rsx_sim* h) {
-    for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
-    h->graphs.clear();
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     if (h->pin_cmds) (void)hipHostFree(h->pin_cmds);
     if (h->pin_state) (void)hipHostFree(h->pin_state);
@@ -703,6 +700,7 @@ int rsx_task_reset_to(rsx_sim* h, const double* ball, const double* blue, const 
 int rsx_task_step(rsx_sim* h, const float* actions_dev, void* stream) {
     RSX_ENTER_TASK(h);
     RSX_NEED_RESET(h);
+    h->P.tick_base = h->tick++;
     launch_task(h, actions_dev, 1, MODE_STEP, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return debug_finite(h, (hipStream_t)stream, "rsx_task_step");
@@ -712,31 +710,16 @@ int rsx_task_step_n(rsx_sim* h, int n, void* stream) {
     RSX_ENTER_TASK(h);
     RSX_NEED_RESET(h);
     if (n < 1) return fail(RSX_ERR_ARG, "n must be >= 1");
-    static const bool use_graph = std::getenv("RSX_USE_GRAPH") != nullptr;
-    if (!use_graph) {
-        for (int i = 0; i < n; ++i) launch_task(h, nullptr, 1, MODE_STEP, (hipStream_t)stream);
-        HIP_TRY(hipGetLastError());
-        return debug_finite(h, (hipStream_t)stream, "rsx_task_step_n");
-    }
-    auto it = h->graphs.find(n);
-    if (it == h->graphs.end()) {
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
-        HIP_TRY(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-        for (int i = 0; i < n; ++i) launch_task(h, nullptr, 1, MODE_STEP, h->cap_stream);
-        HIP_TRY(hipStreamEndCapture(h->cap_stream, &graph));
-        HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-        (void)hipGraphDestroy(graph);
-        it = h->graphs.emplace(n, exec).first;
-    }
-    HIP_TRY(hipGraphLaunch(it->second, (hipStream_t)stream));
-    return RSX_OK;
+    for (int i = 0; i < n; ++i) { h->P.tick_base = h->tick++; launch_task(h, nullptr, 1, MODE_STEP, (hipStream_t)stream); }
+    HIP_TRY(hipGetLastError());
+    return debug_finite(h, (hipStream_t)stream, "rsx_task_step_n");
 }
 
 int rsx_task_rollout(rsx_sim* h, int n, void* stream) {
     RSX_ENTER_TASK(h);
     RSX_NEED_RESET(h);
     if (n < 0) return fail(RSX_ERR_ARG, "n must be >= 0");  // 0 = load + store only (profiling)
+    h->P.tick_base = h->tick; h->tick += (uint32_t)n;
     launch_task(h, nullptr, n, MODE_ROLLOUT, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return debug_finite(h, (hipStream_t)stream, "rsx_task_rollout");
@@ -752,6 +735,7 @@ static int serve_stop_impl(rsx_sim* h) {
     if (e == hipSuccess) e = hipStreamSynchronize(h->cap_stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->serve_stream);
     h->serving = false;
+    h->tick += (uint32_t)h->serve_req;   // every requested step was served before the kernel left
     if (e != hipSuccess) return fail(RSX_ERR_HIP, std::string("rsx_serve_stop: ") + hipGetErrorString(e));
     return RSX_OK;
 }
@@ -784,6 +768,7 @@ int rsx_serve_start(rsx_sim* h, int timeout_ms) {
     h->serve_req = 0;
     h->serve_waves = grid.x;
     Buffers b = buffers_of(h, h->d_actions);
+    h->P.tick_base = h->tick;
     b.serve_timeout = (unsigned long long)timeout_ms * 100000ull;   // s_memrealtime ticks at 100 MHz
     h->serve_timeout_ticks = b.serve_timeout;
     hipStream_t s = h->serve_stream;
@@ -800,6 +785,7 @@ int rsx_serve_step(rsx_sim* h, const float* actions_dev, void* stream) {
     if (!h->serving) return fail(RSX_ERR_STATE, "rsx_serve_start first");
     if (hipStreamQuery(h->serve_stream) != hipErrorNotReady) {   // the kernel left on its own: no request within the timeout
         h->serving = false;
+        h->tick += (uint32_t)h->serve_req;
         return fail(RSX_ERR_STATE, "the serving kernel is no longer running (no request within its timeout): state saved, serving ended");
     }
     hipStream_t s = (hipStream_t)stream;

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 
     for (int it = 0; it < n_steps; ++it) {
         const bool first_step = steps == 0;
-        const uint32_t t = (uint32_t)steps;
+        const uint32_t t = P.tick_base + (uint32_t)it;   // see task_step_kernel
         if (STEP || it == 0) {
             // The previous ball potential (vss_gym.py:256-283) is the potential of the ball where this step
             // finds it: the same expression on the same floats as last step's, so the same number as the one
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             float a0, a1;
-            if ((k & 1) == 0) blk = philox4x32(env_id, episode, t, DOM_ACT | ((uint32_t)(k >> 1) << 8), P.key0, P.key1);   // one block serves two robots
+            if ((k & 1) == 0) blk = philox4x32(env_id, 0u, t, DOM_ACT | ((uint32_t)(k >> 1) << 8), P.key0, P.key1);   // one block serves two robots
             const uint32_t w0 = (k & 1) ? blk.z : blk.x, w1 = (k & 1) ? blk.w : blk.y;
             if (k == 0) {
                 if (fed) { a0 = act0; a1 = act1; }

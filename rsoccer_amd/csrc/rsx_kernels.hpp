@@ -1086,6 +1086,54 @@ __device__ __forceinline__ float4 place_env_parallel(const Params& P, const int 
     return is_robot ? make_float4(x, y, th, 0.0f) : make_float4(bx, by, 0.0f, 0.0f);
 }
 
+// The random numbers of one step for the body of this lane.  They depend on (seed, global env id,
+// handle step count) only — not on anything in memory — so a single-step launch computes them while
+// its state loads are in flight (Philox + Box-Muller: ~1.5 k cycles that used to follow the ~1.8 k
+// cycle load wait).  VSS-v0: robot 0 -> two uniforms in [-1, 1) (its random action), robots >= 1 ->
+// two standard normals (Box-Muller, Utils/Utils.py:18); scrimmage: four uniforms per robot; the other
+// SSL tasks: up to five uniforms for robot 0.
+struct StepDraw { float v[5]; };
+
+template <int KIND, int TASK>
+__device__ __forceinline__ StepDraw draw_for_step(const Params& P, const uint32_t env_id, const uint32_t t,
+                                                  const int b, const bool is_robot, const bool fed) {
+    StepDraw d;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) d.v[i] = 0.0f;
+    if (TASK == RSX_TASK_VSS_V0) {
+        if (is_robot && !(fed && b == 0)) {
+            // one Philox call per lane: block b >> 1 of the step, this robot's pair of words
+            const u32x4 u = philox4x32(env_id, 0u, t, DOM_ACT | ((uint32_t)(b >> 1) << 8), P.key0, P.key1);
+            const uint32_t w0 = (b & 1) ? u.z : u.x, w1 = (b & 1) ? u.w : u.y;
+            if (b == 0) { d.v[0] = u01(w0) * 2.0f - 1.0f; d.v[1] = u01(w1) * 2.0f - 1.0f; }
+            else {
+                float u1 = (float)((w0 >> 8) + 1u) * 5.9604644775390625e-08f;
+                float ang = (u01(w1) - 0.5f) * 6.283185307179586f;
+                float rad = sqrtf(-2.0f * log_f32(u1));
+                float sn, cs;
+                sincos_f32(ang, sn, cs);
+                d.v[0] = rad * cs; d.v[1] = rad * sn;
+            }
+        }
+    } else if (TASK == RSX_TASK_SSL_SCRIMMAGE) {
+        if (is_robot && !fed) {
+            const u32x4 u = philox4x32(env_id, 0u, t, DOM_ACT | ((uint32_t)b << 8), P.key0, P.key1);
+            d.v[0] = u01(u.x) * 2.0f - 1.0f; d.v[1] = u01(u.y) * 2.0f - 1.0f;
+            d.v[2] = u01(u.z) * 2.0f - 1.0f; d.v[3] = u01(u.w) * 2.0f - 1.0f;
+        }
+    } else {
+        if (is_robot && b == 0 && !fed) {
+            const u32x4 u = philox4x32(env_id, 0u, t, DOM_ACT, P.key0, P.key1);
+            d.v[0] = u01(u.x) * 2.0f - 1.0f; d.v[1] = u01(u.y) * 2.0f - 1.0f;
+            d.v[2] = u01(u.z) * 2.0f - 1.0f; d.v[3] = u01(u.w) * 2.0f - 1.0f;
+            // fifth component: the low bytes u01 leaves unused in x, y, z (one block per step)
+            const uint32_t w = (u.x & 0xFFu) | ((u.y & 0xFFu) << 8) | ((u.z & 0xFFu) << 16);
+            d.v[4] = u01(w << 8) * 2.0f - 1.0f;
+        }
+    }
+    return d;
+}
+
 // MODE (compile-time, so the per-step launch carries no loop and none of the reset-only code):
 //   MODE_STEP    one step(action) per launch
 //   MODE_ROLLOUT n_steps random-action steps per launch (state stays in registers)
@@ -1203,6 +1251,10 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
         }
     }
 
+    // single-step launches: this step's random numbers, computed in the shadow of the loads
+    StepDraw pre;
+    if (MODE == MODE_STEP) pre = draw_for_step<KIND, TASK>(P, env_id, P.tick_base, b, is_robot, fed);
+
     // All loads land here, once.  Without this the compiler parks a vmcnt(0) at the top of the
     // step loop (loop-carried values come from loads on the first trip), and on gfx9-class
     // counters that wait also drains the previous trip's global STORES: one HBM write round
@@ -1272,7 +1324,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
             }
         } else {
             const bool first_step = steps == 0;
-            const uint32_t t = (uint32_t)steps;
+            const uint32_t t = P.tick_base + (uint32_t)it;   // per-step draws are keyed by the handle's step count, not by the env's counters
             if (is_ball && first_step) {
 #pragma unroll
                 for (int i = 0; i < 10; ++i) info[i] = 0.0f;
@@ -1282,25 +1334,16 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
 
             // ---- actions -> commands ----
             float q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const StepDraw dr = MODE == MODE_STEP ? pre : draw_for_step<KIND, TASK>(P, env_id, t, b, is_robot, fed);
             if (TASK == RSX_TASK_VSS_V0) {
                 if (is_robot) {
                     float a0, a1;
-                    // one Philox call per lane: block b >> 1 of the step, this robot's pair of words
-                    // (robot 0: the agent's random action; the others: their OU draw)
-                    const u32x4 u = philox4x32(env_id, episode, t, DOM_ACT | ((uint32_t)(b >> 1) << 8), P.key0, P.key1);
-                    const uint32_t w0 = (b & 1) ? u.z : u.x, w1 = (b & 1) ? u.w : u.y;
-                    if (b == 0) {
+                    if (b == 0) {   // the agent: fed action or the step's uniform draw
                         if (fed) { a0 = act[0]; a1 = act[1]; }
-                        else { a0 = u01(w0) * 2.0f - 1.0f; a1 = u01(w1) * 2.0f - 1.0f; }
-                    } else {  // Ornstein-Uhlenbeck noise, Utils/Utils.py:14-21 (Box-Muller on Philox)
-                        float u1 = (float)((w0 >> 8) + 1u) * 5.9604644775390625e-08f;
-                        float ang = (u01(w1) - 0.5f) * 6.283185307179586f;
-                        float rad = sqrtf(-2.0f * log_f32(u1));
-                        float sn, cs;
-                        sincos_f32(ang, sn, cs);
-                        float n0 = rad * cs, n1 = rad * sn;
-                        ou0 = (ou0 + P.ou_theta_dt * (0.0f - ou0)) + P.ou_sig_sqdt * n0;
-                        ou1 = (ou1 + P.ou_theta_dt * (0.0f - ou1)) + P.ou_sig_sqdt * n1;
+                        else { a0 = dr.v[0]; a1 = dr.v[1]; }
+                    } else {  // Ornstein-Uhlenbeck noise, Utils/Utils.py:14-21, on the step's two normals
+                        ou0 = (ou0 + P.ou_theta_dt * (0.0f - ou0)) + P.ou_sig_sqdt * dr.v[0];
+                        ou1 = (ou1 + P.ou_theta_dt * (0.0f - ou1)) + P.ou_sig_sqdt * dr.v[1];
                         a0 = ou0; a1 = ou1;
                     }
                     q[0] = vss_wheel(a0); q[1] = vss_wheel(a1);
@@ -1308,33 +1351,16 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
             } else if (TASK == RSX_TASK_SSL_SCRIMMAGE) {  // every robot: (v_x, v_y, v_theta, kick), block b of the step
                 if (is_robot) {
                     float a[4];
-                    if (fed) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) a[i] = act[i];
-                    } else {
-                        const u32x4 u = philox4x32(env_id, episode, t, DOM_ACT | ((uint32_t)b << 8), P.key0, P.key1);
-                        a[0] = u01(u.x) * 2.0f - 1.0f; a[1] = u01(u.y) * 2.0f - 1.0f;
-                        a[2] = u01(u.z) * 2.0f - 1.0f; a[3] = u01(u.w) * 2.0f - 1.0f;
-                    }
+                    for (int i = 0; i < 4; ++i) a[i] = fed ? act[i] : dr.v[i];
                     q[1] = a[0] * T::max_v; q[2] = a[1] * T::max_v; q[3] = a[2] * 10.0f;
                     q[5] = a[3] > 0.9f ? 5.0f : 0.0f;
                 }
             } else {  // the SSL tasks: only blue 0 is driven by the agent
                 if (is_robot && b == 0) {
                     float a[5] = {0, 0, 0, 0, 0};
-                    if (fed) {
 #pragma unroll
-                        for (int i = 0; i < AD; ++i) a[i] = act[i];
-                    } else {
-                        u32x4 u = philox4x32(env_id, episode, t, DOM_ACT, P.key0, P.key1);
-                        a[0] = u01(u.x) * 2.0f - 1.0f; a[1] = u01(u.y) * 2.0f - 1.0f;
-                        a[2] = u01(u.z) * 2.0f - 1.0f;
-                        if (AD > 3) a[3] = u01(u.w) * 2.0f - 1.0f;
-                        if (AD > 4) {   // fifth component: the low bytes u01 leaves unused in x, y, z (one block per step)
-                            const uint32_t w = (u.x & 0xFFu) | ((u.y & 0xFFu) << 8) | ((u.z & 0xFFu) << 16);
-                            a[4] = u01(w << 8) * 2.0f - 1.0f;
-                        }
-                    }
+                    for (int i = 0; i < AD; ++i) a[i] = fed ? act[i] : dr.v[i];
                     if (TASK == RSX_TASK_SSL_PASS_ENDURANCE) {  // pass_endurance.py:106-130
                         float k = fabsf(a[1]) > 0.5f ? a[1] : 0.0f;
                         q[3] = a[0] * 10.0f;

@@ -166,6 +166,7 @@ struct Params {
     // task
     int task, obs_dim, max_steps;
     uint32_t key0, key1, env_id_base;
+    uint32_t tick_base;   // step launches of this handle since attach: key of the per-step draws
     float inv_max_pos, hl_goal, inv_len_cm, inv_dt;
     float pen_x, half_pen_wid, inv_bd_scale, inv_bg_scale;
     float pl_xlo, pl_xspan, pl_ylo, pl_yspan, pl_min_d2;
