@@ -405,7 +405,8 @@ def other_configs(L, torch, dev, timed):
     SD = 2 * 4 * (5 + 11 * 7) + 4 * 8 * 7 + 4 * 24 + 5          # 981
     SC = 2 * 4 * (5 + 11 * 22) + 4 * 8 * 22 + 4 * 46 + 5        # 2869
     cases = (("configs[2] SSLStaticDefenders-v0 1v6", 1, 2, 1, 6, L.TASK_SSL_STATIC_DEFENDERS, 2048, SD, 2000, 200),
-             ("SSLStaticDefenders-v0 1v6, bandwidth-bound batch", 1, 2, 1, 6, L.TASK_SSL_STATIC_DEFENDERS, 262144, SD, 100, 30),
+             ("SSLStaticDefenders-v0 1v6, 262 144 envs (one-lane-per-env kernel)", 1, 2, 1, 6, L.TASK_SSL_STATIC_DEFENDERS, 262144, SD, 100, 30),
+             ("SSLStaticDefenders-v0 1v6, 1 048 576 envs (one-lane-per-env kernel)", 1, 2, 1, 6, L.TASK_SSL_STATIC_DEFENDERS, 1048576, SD, 60, 20),
              ("configs[3] SSL 11v11 division-A, scrimmage task, spread line-up", 1, 1, 11, 11, L.TASK_SSL_SCRIMMAGE, 1024, SC, 1000, 100),
              ("configs[3] SSL 11v11 division-A, scrimmage task, crowded line-up (worst-case contacts)", 1, 1, 11, 11,
               L.TASK_SSL_SCRIMMAGE_CROWDED, 1024, SC, 1000, 100),

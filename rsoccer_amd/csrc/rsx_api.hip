@@ -18,6 +18,7 @@
 namespace rsx {
 // rsx_epl.hip (own translation unit, own compiler flags)
 void launch_vss_epl(bool rollout, const Params& P, const Buffers& b, int n_steps, hipStream_t s);
+void launch_ssl_sd_epl(bool rollout, const Params& P, const Buffers& b, int n_steps, hipStream_t s);
 }
 
 using namespace rsx;
@@ -48,7 +49,7 @@ struct rsx_sim {
     int device = 0;
     int L = 8;   // lanes per env
     int NR = 0;  // compile-time robot count of the selected kernel variant (0 = generic)
-    bool epl = false;  // VSS-v0 3v3 step / rollout launches use the one-lane-per-env kernel (large batches)
+    bool epl = false;  // VSS-v0 3v3 / SSLStaticDefenders 1v6 step and rollout launches use the one-lane-per-env kernels (large batches)
     // one allocation per lifetime stage (few pages -> few TLB entries per launch)
     char* arena_sim = nullptr;   // state | cmds
     char* arena_task = nullptr;  // aux | obs | final_obs | flags | actions | metrics
@@ -203,6 +204,10 @@ void launch_task_m(const rsx_sim* h, const float* actions, int n_steps, hipStrea
     const Buffers b = buffers_of(h, actions);
     if (TASK == RSX_TASK_VSS_V0 && (MODE == MODE_STEP || MODE == MODE_ROLLOUT) && h->epl && h->NR == 6 && h->L == 8) {
         launch_vss_epl(MODE == MODE_ROLLOUT, h->P, b, n_steps, s);
+        return;
+    }
+    if (TASK == RSX_TASK_SSL_STATIC_DEFENDERS && (MODE == MODE_STEP || MODE == MODE_ROLLOUT) && h->epl && h->NR == 7 && h->L == 8) {
+        launch_ssl_sd_epl(MODE == MODE_ROLLOUT, h->P, b, n_steps, s);
         return;
     }
     const dim3 grid = grid_for(h);
@@ -647,7 +652,7 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
     // VSS-v0 3v3: which tile layout steps the envs.  Both give identical results; the one-lane-
     // per-env kernel needs enough envs to fill the chip with its long waves.
     h->epl = false;
-    if (task == RSX_TASK_VSS_V0 && h->NR == 6 && h->L == 8) {
+    if ((task == RSX_TASK_VSS_V0 && h->NR == 6 && h->L == 8) || (task == RSX_TASK_SSL_STATIC_DEFENDERS && h->NR == 7 && h->L == 8)) {
         const char* lay = std::getenv("RSX_LAYOUT");
         if (lay && std::strcmp(lay, "epl") == 0) h->epl = true;
         else if (lay && std::strcmp(lay, "lanes") == 0) h->epl = false;

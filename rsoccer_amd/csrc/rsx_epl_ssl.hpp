@@ -1,0 +1,532 @@
+// rsx_epl_ssl.hpp — SSLStaticDefenders-v0 (1 blue + 6 yellow) fused step, "one lane per env" layout for
+// LARGE batches: the SSL counterpart of rsx_epl.hpp.
+//
+// Same path, same buffers, same arithmetic as task_step_kernel<SSL, 8, STATIC_DEFENDERS, 7, ...>
+// (reference: ssl/ssl_hw_challenge/static_defenders.py:90-322 around robosim.SSL.step, rsim.py:155,158),
+// other mapping: lane = env, a wave owns 64 envs and walks the 8 bodies of each one after the other.  The
+// 8-lane layout has no idle lane here, but its ball lane and robot lanes run different code one after
+// the other and every robot pair is tested from both sides; at scale that kernel is VALU-bound
+// (DESIGN.md 5).  Results are bit-identical: every body sums its partners in index order (robot-robot
+// pairs first, then the ball), the ball sums the robots' records in robot order, each side of a pair
+// evaluates its own response with the same expressions, draws use the same Philox counters
+// (tests/test_gpu_parity.py::test_ssl_env_per_lane_layout_is_bit_identical).
+//
+// What differs from the VSS kernel: holonomic actuation (only blue 0 is commanded: the six defenders
+// hold still unless they are hit), the kicker mouth / infrared / kick / dribbler of the robot-ball
+// contact (evaluated only for robots whose centre is within 13 cm of the ball: a mouth or infrared
+// contact needs < 12.6 cm), the ball's flight, SSL walls, eleven state rows per robot (infrared and
+// four wheel speeds are outputs: written every step, read only when the step has no physics).
+#pragma once
+#include "rsx_kernels.hpp"
+
+namespace rsx {
+
+constexpr int SEPL_NR = 7;            // 1 blue + 6 yellow (static_defenders.py:47-48)
+constexpr int SEPL_NB = SEPL_NR + 1;  // + ball (body index SEPL_NR)
+constexpr int SEPL_OD = 24, SEPL_ODP = 25;
+constexpr int SEPL_PAIRS = SEPL_NR * (SEPL_NR - 1) / 2;   // 21 robot-robot pairs
+
+struct SeplShared {
+    union {
+        struct { float acc[4][SEPL_NB][64]; float accw[64]; } c;   // contact sums (column = lane)
+        float stage[64 * SEPL_ODP];                                 // observation rows
+    } u;
+};
+
+// pair p -> (i, j), i < j < 7, lexicographic: rows of the upper triangle start at 0, 6, 11, 15, 18, 20
+__device__ __forceinline__ void sepl_pair(int p, int& i, int& j) {
+    i = p >= 20 ? 5 : p >= 18 ? 4 : p >= 15 ? 3 : p >= 11 ? 2 : p >= 6 ? 1 : 0;
+    const int start = i == 0 ? 0 : i == 1 ? 6 : i == 2 ? 11 : i == 3 ? 15 : i == 4 ? 18 : 20;
+    j = i + 1 + (p - start);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4)))
+void ssl_sd_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
+    constexpr int KIND = RSX_KIND_SSL, TASK = RSX_TASK_SSL_STATIC_DEFENDERS, N = SEPL_NR, RS = 11;
+    using K = KC<KIND>;
+    using T = TC<TASK>;
+    constexpr int ID = T::info_dim;
+    constexpr bool STEP = MODE == MODE_STEP;
+    Params P = P_; P.num_envs = hp_num_envs; P.state_dim = hp_state_dim;
+    Buffers bufs = bufs_; bufs.state = hp_state; bufs.aux = hp_aux; bufs.actions = hp_in; bufs.flags = hp_flags;
+    const int n_steps = MODE == MODE_ROLLOUT ? hp_n_steps : 1;
+    __shared__ SeplShared sh;
+    const int lane = threadIdx.x;
+    const int tile = tile_of_block(hp_per_xcd);
+    const int e = tile * 64 + lane;
+    const bool live = e < P.num_envs;
+    const size_t B = (size_t)P.num_envs;
+    const uint32_t env_id = P.env_id_base + (uint32_t)e;
+    float* const st = bufs.state + e;
+    float* const auxe = bufs.aux + e;
+
+    // ---- load ----
+    Body r[N];
+    Body ball = Body{};
+    float wdeg[N], wheels[N][4];
+    float info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float ep_ret = 0.0f;
+    int steps = 0; uint32_t episode = 0;
+    float raw[N][6], rawb[7] = {0, 0, 0, 0, 0, 0, 0};
+    int ir_in[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+#pragma unroll
+        for (int f = 0; f < 6; ++f) raw[k][f] = live ? st[(size_t)(5 + RS * k + f) * B] : 0.0f;
+        ir_in[k] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wheels[k][i] = 0.0f;
+        // infrared is refreshed by every step that has physics; a step without (time_step 0) keeps the stored flag
+        if (P.n_sub == 0 && live) ir_in[k] = st[(size_t)(5 + RS * k + 6) * B] != 0.0f;
+    }
+    if (live) {
+#pragma unroll
+        for (int f = 0; f < 5; ++f) rawb[f] = st[(size_t)f * B];
+        rawb[5] = st[(size_t)P.state_dim * B];
+        rawb[6] = st[(size_t)(P.state_dim + 1) * B];
+        steps = __float_as_int(auxe[(size_t)ROW_STEPS * B]);
+        episode = __float_as_uint(auxe[(size_t)ROW_EPISODE * B]);
+#pragma unroll
+        for (int i = 0; i < ID; ++i) info[i] = auxe[(size_t)(ROW_INFO + i) * B];
+        ep_ret = auxe[(size_t)ROW_EP_RET * B];
+    }
+    const bool counts_steps = blockIdx.x == 0 && lane == 0;   // metrics[0]: see task_step_kernel
+    unsigned long long steps_before = 0;
+    if (counts_steps) steps_before = bufs.metrics[0];
+    const bool fed = MODE == MODE_STEP && bufs.actions != nullptr;
+    float act[5] = {0, 0, 0, 0, 0};
+    if (fed && live) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) act[i] = bufs.actions[(size_t)e * 5 + i];
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): all loads land once, before the step loop
+#pragma unroll
+    for (int k = 0; k < N; ++k) {   // interpret_body, robot
+        r[k] = Body{};
+        r[k].x = raw[k][0]; r[k].y = raw[k][1]; r[k].vx = raw[k][3]; r[k].vy = raw[k][4];
+        r[k].th = raw[k][2];
+        wdeg[k] = raw[k][5];
+        r[k].om = raw[k][5] * K::deg2rad;
+        r[k].ir = ir_in[k];
+        sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
+    }
+    ball.x = rawb[0]; ball.y = rawb[1]; ball.vx = rawb[3]; ball.vy = rawb[4];
+    ball.z = rawb[2] - K::r_ball; ball.vz = rawb[5]; ball.om = rawb[6];
+
+    float reward = 0.0f; int term = 0, trunc = 0;
+
+    for (int it = 0; it < n_steps; ++it) {
+        const bool first_step = steps == 0;
+        const uint32_t t = P.tick_base + (uint32_t)it;   // see task_step_kernel
+        if (first_step) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) info[i] = 0.0f;
+            ep_ret = 0.0f;
+        }
+        const float last_bx = ball.x, last_by = ball.y;        // the reference's last_frame (pre-step)
+        const float last_rx = r[0].x, last_ry = r[0].y;
+
+        // ---- action -> commands: only blue 0 is driven (static_defenders.py:114-148) ----
+        {
+            float a[5];
+            const StepDraw dr = draw_for_step<KIND, TASK>(P, env_id, t, 0, true, fed);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) a[i] = fed ? act[i] : dr.v[i];
+            float q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            float sn, cs;
+            sincos_f32(r[0].th * K::deg2rad, sn, cs);
+            float gx = a[0] * T::max_v, gy = a[1] * T::max_v, vth = a[2] * 10.0f;
+            float lx = gx * cs + gy * sn, ly = gy * cs - gx * sn;
+            float nrm = sqrtf(lx * lx + ly * ly);
+            if (!(nrm < T::max_v)) { float sc = T::max_v / nrm; lx = lx * sc; ly = ly * sc; }
+            q[1] = lx; q[2] = ly; q[3] = vth;
+            q[5] = a[3] > 0.0f ? 5.0f : 0.0f;
+            q[7] = a[4] > 0.0f ? 1.0f : 0.0f;
+            robot_targets<KIND>(P, r[0], q);
+            const float zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int k = 1; k < N; ++k) robot_targets<KIND>(P, r[k], zero);
+        }
+
+        // ---- physics: n_sub sub-steps, the whole env in registers ----
+        if (P.n_sub && !(ball.z > 0.0f || ball.vz > 0.0f)) {   // rolling resistance + spin decay, once per step()
+            float sp2 = fma_(ball.vx, ball.vx, ball.vy * ball.vy);
+            if (sp2 > 0.0f) {
+                float sp = sqrtf(sp2), ns = sp - P.mu_g_dt;
+                if (ns < 0.0f) ns = 0.0f;
+                float kk = ns / sp;
+                ball.vx = ball.vx * kk; ball.vy = ball.vy * kk;
+            }
+            const float aw = fabsf(ball.om) - P.spin_dec_dt;
+            ball.om = aw > 0.0f ? (ball.om < 0.0f ? -aw : aw) : 0.0f;
+        }
+        for (int sub = 0; sub < P.n_sub; ++sub) {
+            // A: actuation + integration (holonomic)
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                Body& o = r[k];
+                float vf = fma_(o.vy, o.s, o.vx * o.c);
+                float vl = fma_(o.vy, o.c, -(o.vx * o.s));
+                float dx = o.t0 - vf, dy = o.t1 - vl;
+                float d2 = fma_(dx, dx, dy * dy);
+                if (d2 > P.a_lin_h2) { float sc = P.a_lin_h / sqrtf(d2); dx = dx * sc; dy = dy * sc; }
+                vf = vf + dx; vl = vl + dy;
+                o.om = o.om + clampf(o.t2 - o.om, -P.a_ang_h, P.a_ang_h);
+                o.vx = fma_(vf, o.c, -(vl * o.s));
+                o.vy = fma_(vf, o.s, vl * o.c);
+                o.x = fma_(o.vx, P.h, o.x);
+                o.y = fma_(o.vy, P.h, o.y);
+                o.th = fma_(o.om, P.h_deg, o.th);
+                if (o.th > 180.0f) o.th = o.th - 360.0f;
+                else if (o.th < -180.0f) o.th = o.th + 360.0f;
+                rotate_heading(o.om * P.h, o.c, o.s);
+            }
+            if (ball.z > 0.0f || ball.vz > 0.0f) {
+                ball.vz = ball.vz - P.g_h;
+                ball.z = fma_(ball.vz, P.h, ball.z);
+                if (ball.z <= 0.0f) {
+                    ball.z = 0.0f;
+                    ball.vz = -ball.vz * K::e_ground;
+                    if (ball.vz < K::vz_min) ball.vz = 0.0f;
+                }
+            }
+            ball.x = fma_(ball.vx, P.h, ball.x);
+            ball.y = fma_(ball.vy, P.h, ball.y);
+
+            // B: contacts.  One bit per touching robot pair (exact integer form of 0 < d2 < thr, see
+            // rsx_kernels.hpp), one bit per robot whose centre is near enough to the ball for a mouth,
+            // circle or infrared contact; a second sweep over the corrected snapshot where a pair was deep.
+            const bool ball_low = ball.z < K::robot_h;
+            constexpr uint32_t T_RR = __builtin_bit_cast(uint32_t, K::rs_rr2) - 1u;
+            constexpr float NEAR2 = 0.13f * 0.13f;   // > (dck_rb + ir_tol)^2 + half_kw^2 = 0.126^2 and > rs_rb^2
+            auto find_pairs = [&]() -> unsigned {
+                unsigned touching = 0;
+                int p = 0;
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+#pragma unroll
+                    for (int j = i + 1; j < N; ++j, ++p) {
+                        const float dx = r[j].x - r[i].x, dy = r[j].y - r[i].y;
+                        const uint32_t u = __float_as_uint(fma_(dx, dx, dy * dy)) - 1u;
+                        touching |= (u < T_RR) ? 1u << p : 0u;
+                    }
+                }
+                return touching;
+            };
+            auto find_near = [&]() -> unsigned {
+                unsigned near = 0;
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    const float dx = ball.x - r[k].x, dy = ball.y - r[k].y;
+                    near |= (ball_low & (fma_(dx, dx, dy * dy) < NEAR2)) ? 1u << k : 0u;
+                }
+                return near;
+            };
+            bool deep = false;
+            BallOverride bo{false, false, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < N; ++k) r[k].ir = 0;   // refreshed by the first sweep; robots far from the ball: no infrared
+            for (int sweep = 0; sweep < 2; ++sweep) {   // the second sweep runs the same (cached) instructions
+                const bool mine = sweep == 0 || deep;   // second: envs with a deep pair only
+                const unsigned touching = mine ? find_pairs() : 0u;
+                const unsigned near = mine ? find_near() : 0u;
+                if (!__any((touching | near) != 0)) break;
+                const bool first = sweep == 0;
+#pragma unroll
+                for (int k = 0; k < SEPL_NB; ++k) {
+                    sh.u.c.acc[0][k][lane] = 0.0f; sh.u.c.acc[1][k][lane] = 0.0f;
+                    sh.u.c.acc[2][k][lane] = 0.0f; sh.u.c.acc[3][k][lane] = 0.0f;
+                }
+                sh.u.c.accw[lane] = 0.0f;
+                wave_sync();
+                deep = false;
+                // robot-robot pairs, in pair order: every body receives its partners in index order
+                unsigned todo = touching;
+                while (todo) {
+                    const int p = __builtin_ctz(todo);
+                    todo &= todo - 1;
+                    int i, j;
+                    sepl_pair(p, i, j);
+                    Body bi = Body{}, bj = Body{};
+                    float wi = 0.0f, wj = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < N; ++k) {
+                        if (i == k) { bi.x = r[k].x; bi.y = r[k].y; bi.vx = r[k].vx; bi.vy = r[k].vy; wi = r[k].om; }
+                        if (j == k) { bj.x = r[k].x; bj.y = r[k].y; bj.vx = r[k].vx; bj.vy = r[k].vy; wj = r[k].om; }
+                    }
+                    float unused = 0.0f;
+                    {
+                        const float dx = bj.x - bi.x, dy = bj.y - bi.y;
+                        float a0 = sh.u.c.acc[0][i][lane], a1 = sh.u.c.acc[1][i][lane], a2 = sh.u.c.acc[2][i][lane], a3 = sh.u.c.acc[3][i][lane];
+                        contact_response(bi, make_float4(bj.x, bj.y, bj.vx, bj.vy), fma_(dx, dx, dy * dy), K::rs_rr, K::ope_rr, K::w_rr, K::kt_rr,
+                                         K::mu_rr, 0.0f, fma_(wj, K::r_robot, wi * K::r_robot), K::beta, K::pen2, a0, a1, a2, a3, unused, deep);
+                        sh.u.c.acc[0][i][lane] = a0; sh.u.c.acc[1][i][lane] = a1; sh.u.c.acc[2][i][lane] = a2; sh.u.c.acc[3][i][lane] = a3;
+                    }
+                    {
+                        const float dx = bi.x - bj.x, dy = bi.y - bj.y;
+                        float a0 = sh.u.c.acc[0][j][lane], a1 = sh.u.c.acc[1][j][lane], a2 = sh.u.c.acc[2][j][lane], a3 = sh.u.c.acc[3][j][lane];
+                        contact_response(bj, make_float4(bi.x, bi.y, bi.vx, bi.vy), fma_(dx, dx, dy * dy), K::rs_rr, K::ope_rr, K::w_rr, K::kt_rr,
+                                         K::mu_rr, 0.0f, fma_(wi, K::r_robot, wj * K::r_robot), K::beta, K::pen2, a0, a1, a2, a3, unused, deep);
+                        sh.u.c.acc[0][j][lane] = a0; sh.u.c.acc[1][j][lane] = a1; sh.u.c.acc[2][j][lane] = a2; sh.u.c.acc[3][j][lane] = a3;
+                    }
+                }
+                // robot-ball, robot by robot (the ball sums the robots' records in robot order): kicker mouth
+                // (flat face at dck) or body circle; n points robot -> ball.  Mirrors ssl_sweep.
+                unsigned rb_touch = 0;   // robots that touch the ball in this sweep
+                unsigned nr = near;
+                while (nr) {
+                    const int k = __builtin_ctz(nr);
+                    nr &= nr - 1;
+                    Body o = Body{};
+                    float kick_x = 0.0f, kick_z = 0.0f; int drib = 0;
+#pragma unroll
+                    for (int q = 0; q < N; ++q)
+                        if (k == q) { o.x = r[q].x; o.y = r[q].y; o.vx = r[q].vx; o.vy = r[q].vy; o.om = r[q].om; o.c = r[q].c; o.s = r[q].s; }
+                    if (k == 0) { kick_x = r[0].kick_x; kick_z = r[0].kick_z; drib = r[0].drib; }   // the defenders get zero commands
+                    float dx = ball.x - o.x, dy = ball.y - o.y;
+                    float nx = 0.0f, ny = 0.0f, pen = -1.0f;
+                    bool mouth = false, touch = false;
+                    {
+                        float lx = fma_(dx, o.c, dy * o.s), ly = fma_(dy, o.c, -(dx * o.s));
+                        if (fabsf(ly) < K::half_kw && lx > 0.0f) {
+                            mouth = true; pen = K::dck_rb - lx; nx = o.c; ny = o.s; touch = pen > 0.0f;
+                        } else {
+                            float d2 = fma_(dx, dx, dy * dy);
+                            if (d2 < K::rs_rb2 && d2 > 0.0f) {
+                                float d = sqrtf(d2), inv = 1.0f / d;
+                                nx = dx * inv; ny = dy * inv; pen = K::rs_rb - d; touch = true;
+                            }
+                        }
+                    }
+                    if (touch) {
+                        rb_touch |= 1u << k;
+                        deep |= pen > K::pen2;
+                        float a0 = sh.u.c.acc[0][k][lane], a1 = sh.u.c.acc[1][k][lane], a2 = sh.u.c.acc[2][k][lane], a3 = sh.u.c.acc[3][k][lane];
+                        float b0 = sh.u.c.acc[0][N][lane], b1 = sh.u.c.acc[1][N][lane], b2 = sh.u.c.acc[2][N][lane], b3 = sh.u.c.acc[3][N][lane];
+                        float bw = sh.u.c.accw[lane];
+                        const float dvx = ball.vx - o.vx, dvy = ball.vy - o.vy;
+                        float vn = fma_(dvx, nx, dvy * ny);
+                        if (vn < 0.0f) {
+                            float q = K::ope_rb * vn * K::w_rb_r; a0 = fma_(q, nx, a0); a1 = fma_(q, ny, a1);
+                            const float wsum = fma_(ball.om, K::r_ball, o.om * (mouth ? K::dck : K::r_robot));
+                            const float vt = fma_(dvy, nx, -(dvx * ny)) - wsum;
+                            const float lim = q * K::mu_rb;
+                            const float ft = clampf(vt * K::kt_rb_r, lim, -lim);
+                            a0 = fma_(-ft, ny, a0); a1 = fma_(ft, nx, a1);
+                            // the ball's side of the same contact
+                            float qb = K::ope_rb * vn * K::w_rb_b;
+                            const float limb = qb * K::mu_rb;
+                            const float ftb = clampf(vt * K::kt_rb_b, limb, -limb);
+                            b0 = b0 - fma_(-ftb, ny, qb * nx); b1 = b1 - fma_(ftb, nx, qb * ny); bw = bw + ftb * K::spin_c;
+                        }
+                        float pc = K::beta * pen * K::w_rb_r;
+                        a2 = fma_(-pc, nx, a2); a3 = fma_(-pc, ny, a3);
+                        float pb = K::beta * pen * K::w_rb_b;
+                        b2 = b2 + pb * nx; b3 = b3 + pb * ny;
+                        sh.u.c.acc[0][k][lane] = a0; sh.u.c.acc[1][k][lane] = a1; sh.u.c.acc[2][k][lane] = a2; sh.u.c.acc[3][k][lane] = a3;
+                        sh.u.c.acc[0][N][lane] = b0; sh.u.c.acc[1][N][lane] = b1; sh.u.c.acc[2][N][lane] = b2; sh.u.c.acc[3][N][lane] = b3;
+                        sh.u.c.accw[lane] = bw;
+                    }
+                    if (first) {
+                        const bool ir = mouth && pen > -K::ir_tol;
+#pragma unroll
+                        for (int q = 0; q < N; ++q) if (k == q) r[q].ir = ir;
+                        if (ir) {  // infrared: kicker / dribbler act on the ball (the last robot in index order wins)
+                            if (kick_x > 0.0f || kick_z > 0.0f) {
+                                bo.ovr = true; bo.okick = true;
+                                bo.ovx = o.vx + kick_x * o.c; bo.ovy = o.vy + kick_x * o.s; bo.ovz = kick_z;
+                            } else if (drib) {
+                                float hx = o.x + K::dck_rb * o.c, hy = o.y + K::dck_rb * o.s;
+                                float cvx = (hx - ball.x) * P.drib_gain, cvy = (hy - ball.y) * P.drib_gain;
+                                float m2 = cvx * cvx + cvy * cvy;
+                                if (m2 > K::drib_vmax2) { float sc = K::drib_vmax / sqrtf(m2); cvx = cvx * sc; cvy = cvy * sc; }
+                                bo.ovr = true; bo.okick = false;
+                                bo.ovx = (o.vx - o.om * K::dck_rb * o.s) + cvx;
+                                bo.ovy = (o.vy + o.om * K::dck_rb * o.c) + cvy;
+                                bo.ovz = 0.0f;
+                            }
+                        }
+                    }
+                }
+                wave_sync();
+                // bits of `touching` that involve robot k (pairs in lexicographic order, see sepl_pair)
+                constexpr unsigned PM[SEPL_NR] = {0x00003Fu, 0x0007C1u, 0x007842u, 0x038884u, 0x0C9108u, 0x152210u, 0x1A4420u};
+                // only a body that touched something is updated (the others keep their bits)
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    if ((touching & PM[k]) | (rb_touch & (1u << k))) {
+                        r[k].vx = r[k].vx + sh.u.c.acc[0][k][lane]; r[k].vy = r[k].vy + sh.u.c.acc[1][k][lane];
+                        r[k].x = r[k].x + sh.u.c.acc[2][k][lane]; r[k].y = r[k].y + sh.u.c.acc[3][k][lane];
+                    }
+                }
+                if (rb_touch) {
+                    ball.vx = ball.vx + sh.u.c.acc[0][N][lane]; ball.vy = ball.vy + sh.u.c.acc[1][N][lane];
+                    ball.x = ball.x + sh.u.c.acc[2][N][lane]; ball.y = ball.y + sh.u.c.acc[3][N][lane];
+                    ball.om = ball.om + sh.u.c.accw[lane];
+                }
+                wave_sync();
+            }
+            if (bo.ovr) {   // kicker / dribbler: decided in the first sweep, applied after the impulses
+                ball.vx = bo.ovx; ball.vy = bo.ovy; ball.om = 0.0f;
+                if (bo.okick && bo.ovz > 0.0f) ball.vz = bo.ovz;
+            }
+            // C: walls
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                int hit;
+                walls<KIND>(P, K::r_robot, K::e_wr, r[k].x, r[k].y, r[k].vx, r[k].vy, hit);
+            }
+            {
+                const float vx0 = ball.vx, vy0 = ball.vy;
+                int hit = 0;
+                walls<KIND>(P, K::r_ball, K::e_wb, ball.x, ball.y, ball.vx, ball.vy, hit);
+                if (hit) ball_wall_spin<KIND>(hit, vx0, vy0, ball.vx, ball.vy, ball.om);
+            }
+        }
+
+        // ---- wire-format values, observation, reward ----
+        float* const row = sh.u.stage + lane * SEPL_ODP;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const float wd = r[k].om * K::rad2deg;
+            wdeg[k] = wd;
+            wheel_speeds<KIND>(P, r[k], wheels[k]);   // from the carried (c, s) and the unrounded rate, like the other layout
+            r[k].om = wd * K::deg2rad;
+            sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
+            write_obs<KIND, TASK>(P, row, k, true, false, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, wd, r[k].ir, 0.0f);
+        }
+        ball.z = (K::r_ball + ball.z) - K::r_ball;
+        write_obs<KIND, TASK>(P, row, N, false, true, ball.x, ball.y, ball.vx, ball.vy, 0.0f, 0.0f, 0.0f, 0, 0.0f);
+        bool success = false;
+        {   // static_defenders.py:150-212,256-322
+            reward = 0.0f; term = 0;
+            const float bx = ball.x, by = ball.y, rx = r[0].x, ry = r[0].y;
+            if (rx < -0.2f || fabsf(ry) > P.half_wid) { term = 1; info[4] += 1.0f; }
+            else if (rx > P.pen_x && fabsf(ry) < P.half_pen_wid) { term = 1; info[1] += 1.0f; }
+            else if (bx < 0.0f || fabsf(by) > P.half_wid) { term = 1; info[2] += 1.0f; }
+            else if (bx > P.half_len) {
+                term = 1;
+                if (fabsf(by) < P.ghw) { reward = 5.0f; info[0] += 1.0f; }
+                else info[3] += 1.0f;
+            } else {
+                float ldx = last_rx - last_bx, ldy = last_ry - last_by;
+                float cdx = rx - bx, cdy = ry - by;
+                float bd = clampf(sqrtf(ldx * ldx + ldy * ldy) - sqrtf(cdx * cdx + cdy * cdy), -1.0f, 1.0f) * P.inv_bd_scale;
+                float lgx = P.half_len - last_bx, cgx = P.half_len - bx;
+                float bg = clampf(sqrtf(lgx * lgx + last_by * last_by) - sqrtf(cgx * cgx + by * by), -1.0f, 1.0f) * P.inv_bg_scale;
+                float en = -(((fabsf(wheels[0][0]) + fabsf(wheels[0][1])) + fabsf(wheels[0][2])) + fabsf(wheels[0][3])) * T::inv_en_scale;
+                info[5] += bd; info[6] += bg; info[7] += en;
+                reward = (bd + bg) + en;
+            }
+            success = info[0] > 0.0f;
+            ep_ret = ep_ret + reward;
+        }
+        steps += 1;
+        trunc = steps >= P.max_steps;
+        const bool ended = live && (term | trunc);
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < ID; ++i) auxe[(size_t)(ROW_INFO + i) * B] = info[i];
+            auxe[(size_t)ROW_REWARD * B] = reward;
+            bufs.flags[e] = (uint8_t)term; bufs.flags[B + e] = (uint8_t)trunc;
+        }
+
+        // ---- episode end: same-step auto-reset, one lane = one env ----
+        if (__any(ended)) {
+            if (ended) {
+                for (int i = 0; i < SEPL_OD; ++i) bufs.final_obs[(size_t)e * SEPL_OD + i] = row[i];
+                episode += 1;
+                atomicAdd(&bufs.metrics[1], 1ull);
+                if (success) atomicAdd(&bufs.metrics[2], 1ull);
+                atomicAdd(&bufs.metrics[4], (unsigned long long)__float2ll_rn(ep_ret * 1048576.0f));
+                atomicAdd(&bufs.metrics[5], (unsigned long long)steps);
+                if (trunc && !term) atomicAdd(&bufs.metrics[6], 1ull);
+                // placement: static_defenders.py:214-254 (sequential rejection sampling, Philox draws)
+                uint32_t n = 0;
+                auto draw = [&]() -> float2 {
+                    const u32x4 u = philox4x32(env_id, episode, n++, DOM_PLACE, P.key0, P.key1);
+                    return make_float2(u01(u.x), u01(u.y));
+                };
+                float bx = 0.0f, by = 0.0f;
+                for (int tt = 0; tt < 64; ++tt) {
+                    const float2 u = draw();
+                    bx = P.pl_xlo + P.pl_xspan * u.x;
+                    by = P.pl_ylo + P.pl_yspan * u.y;
+                    if (!(bx > P.pen_x && fabsf(by) < P.half_pen_wid)) break;
+                }
+                float* const px = row, * const py = row + 8, * const pth = row + 16;   // scratch: this env's obs row
+                px[0] = 0.0f; py[0] = 0.0f; pth[0] = 0.0f;   // blue 0 at the origin
+                for (int k = 1; k < N; ++k) {
+                    float x = 0.0f, y = 0.0f;
+                    for (int tt = 0; tt < 64; ++tt) {
+                        const float2 u = draw();
+                        x = P.pl_xlo + P.pl_xspan * u.x;
+                        y = P.pl_ylo + P.pl_yspan * u.y;
+                        bool ok = true;
+                        { float dx = x - bx, dy = y - by; if (dx * dx + dy * dy < P.pl_min_d2) ok = false; }
+                        for (int q = 0; q < k; ++q) {
+                            float dx = x - px[q], dy = y - py[q];
+                            if (dx * dx + dy * dy < P.pl_min_d2) ok = false;
+                        }
+                        if (ok) break;
+                    }
+                    const float2 u = draw();
+                    px[k] = x; py[k] = y; pth[k] = 360.0f * u.x;
+                }
+                steps = 0;
+                float nx[N], ny[N], nth[N];
+#pragma unroll
+                for (int k = 0; k < N; ++k) { nx[k] = px[k]; ny[k] = py[k]; nth[k] = pth[k]; }   // read all before the row is rewritten
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    r[k] = Body{};
+                    r[k].x = nx[k]; r[k].y = ny[k];
+                    r[k].th = nth[k];
+                    wdeg[k] = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) wheels[k][i] = 0.0f;
+                    sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
+                    write_obs<KIND, TASK>(P, row, k, true, false, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, 0.0f, 0, 0.0f);
+                }
+                ball = Body{};
+                ball.x = bx; ball.y = by;
+                write_obs<KIND, TASK>(P, row, N, false, true, ball.x, ball.y, ball.vx, ball.vy, 0.0f, 0.0f, 0.0f, 0, 0.0f);
+            }
+        }
+        wave_sync();
+        // ---- observation out, coalesced: 64 rows of 24 floats are one contiguous run ----
+        {
+            const size_t base = (size_t)tile * 64 * SEPL_OD;
+            const size_t lim = B * (size_t)SEPL_OD;
+#pragma unroll 8
+            for (int c = 0; c < SEPL_OD; ++c) {
+                const int i = lane + 64 * c;
+                const float v = sh.u.stage[(i / SEPL_OD) * SEPL_ODP + i % SEPL_OD];
+                if (base + i < lim) bufs.obs[base + i] = v;
+            }
+        }
+        wave_sync();
+    }
+
+    // ---- store (wire format: degrees, deg/s, infrared, wheel speeds) ----
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            float* p = st + (size_t)(5 + RS * k) * B;
+            p[0] = r[k].x; p[B] = r[k].y; p[2 * B] = r[k].th; p[3 * B] = r[k].vx; p[4 * B] = r[k].vy; p[5 * B] = wdeg[k];
+            p[6 * B] = r[k].ir ? 1.0f : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) p[(size_t)(7 + i) * B] = wheels[k][i];
+        }
+        st[0] = ball.x; st[B] = ball.y; st[2 * B] = K::r_ball + ball.z; st[3 * B] = ball.vx; st[4 * B] = ball.vy;
+        st[(size_t)P.state_dim * B] = ball.vz;
+        st[(size_t)(P.state_dim + 1) * B] = ball.om;
+        auxe[(size_t)ROW_STEPS * B] = __int_as_float(steps);
+        auxe[(size_t)ROW_EPISODE * B] = __uint_as_float(episode);
+        auxe[(size_t)ROW_EP_RET * B] = ep_ret;
+    }
+    if (counts_steps) bufs.metrics[0] = steps_before + (unsigned long long)P.num_envs * (unsigned long long)n_steps;
+}
+
+}  // namespace rsx

@@ -502,11 +502,12 @@ def test_get_state_after_device_side_writes_is_not_served_from_the_step_copy():
     sim.close()
 
 
-def test_env_per_lane_layout_is_bit_identical(oracle_mod, monkeypatch):
-    """Large VSS-v0 batches are stepped by a second kernel (one lane per env, rsx_epl.hpp).  Forced
-    on a small ragged batch here: it must agree bit for bit with the CPU oracle and with the
-    8-lanes-per-env kernel — fed and random actions, contacts, TimeLimit resets, single-step and
-    multi-step launches, counters."""
+@pytest.mark.parametrize("task,kind,ft,nb,ny,adim", [(1, 0, 0, 3, 3, 2), (2, 1, 2, 1, 6, 5)], ids=["vss-v0", "static-defenders"])
+def test_env_per_lane_layout_is_bit_identical(oracle_mod, monkeypatch, task, kind, ft, nb, ny, adim):
+    """Large VSS-v0 and SSLStaticDefenders batches are stepped by second kernels (one lane per env,
+    rsx_epl.hpp / rsx_epl_ssl.hpp).  Forced on a small ragged batch here: they must agree bit for bit
+    with the CPU oracle and with the 8-lanes-per-env kernel — fed and random actions (kicks, dribbler),
+    contacts, TimeLimit resets, single-step and multi-step launches, counters."""
     import torch
     L = _lib()
     O = oracle_mod
@@ -516,19 +517,19 @@ def test_env_per_lane_layout_is_bit_identical(oracle_mod, monkeypatch):
     refs = None
     for layout in ("epl", "lanes"):
         monkeypatch.setenv("RSX_LAYOUT", layout)
-        sim = L.Sim(0, 0, 3, 3, 25, B)
-        sim.task_attach(1, seed, base, max_steps)
+        sim = L.Sim(kind, ft, nb, ny, 25, B)
+        sim.task_attach(task, seed, base, max_steps)
         tens = sim.task_tensors()
         sim.task_reset()
         if layout == "epl":
-            refs = _mk_oracles(O, 0, 0, 3, 3, B)
+            refs = _mk_oracles(O, kind, ft, nb, ny, B)
             for e, r in enumerate(refs):
-                r.task_attach(1, seed, base + e, max_steps)
+                r.task_attach(task, seed, base + e, max_steps)
                 r.task_reset()
         rng = np.random.default_rng(5)
         for t in range(120):
             if t % 3 == 0:
-                a = rng.uniform(-1, 1, (B, 2)).astype(np.float32)
+                a = rng.uniform(-1, 1, (B, adim)).astype(np.float32)
                 tens["actions"].copy_(torch.from_numpy(a))
                 sim.task_step(tens["actions"].data_ptr())
                 if layout == "epl":
@@ -592,7 +593,32 @@ def test_long_horizon_bitexact(oracle_mod, task, kind, ft, nb, ny, B, steps):
     sim.close()
 
 
-def test_large_batch_switches_layout_and_agrees(monkeypatch):
+def test_static_defenders_env_per_lane_long_run_with_contacts(oracle_mod, monkeypatch):
+    """the SSL one-lane-per-env kernel over 1500 random-action steps x 96 envs (ball carried, kicked into the
+    defenders, robot-robot hits, every termination branch): still the oracle's bits"""
+    L = _lib()
+    monkeypatch.setenv("RSX_LAYOUT", "epl")
+    B = 96
+    sim = L.Sim(1, 2, 1, 6, 25, B)
+    sim.task_attach(2, 99, 0, 0)
+    tens = sim.task_tensors()
+    sim.task_reset()
+    refs = _mk_oracles(oracle_mod, 1, 2, 1, 6, B)
+    for e, r in enumerate(refs):
+        r.task_attach(2, 99, e, 0)
+        r.task_reset()
+    for chunk in range(6):
+        sim.task_step_n(249)
+        sim.task_step(None)
+        oracle_mod.vec_task_step(refs, 250)
+        _cmp_task(sim, refs, tens, chunk)
+    m = sim.read_metrics()
+    assert np.array_equal(m, sum(r.task_out()["metrics"] for r in refs)) and m[1] > B
+    sim.close()
+
+
+@pytest.mark.parametrize("task,kind,ft,nb,ny", [(1, 0, 0, 3, 3), (2, 1, 2, 1, 6)], ids=["vss-v0", "static-defenders"])
+def test_large_batch_switches_layout_and_agrees(monkeypatch, task, kind, ft, nb, ny):
     """At 131 072 envs the library picks the one-lane-per-env kernel by itself; forcing the 8-lane
     kernel on the same seeds must give the same buffers (full size, a few hundred resets)."""
     import torch
@@ -604,8 +630,8 @@ def test_large_batch_switches_layout_and_agrees(monkeypatch):
             monkeypatch.setenv("RSX_LAYOUT", layout)
         else:
             monkeypatch.delenv("RSX_LAYOUT", raising=False)
-        sim = L.Sim(0, 0, 3, 3, 25, B)
-        sim.task_attach(1, 2025, 0, 0)
+        sim = L.Sim(kind, ft, nb, ny, 25, B)
+        sim.task_attach(task, 2025, 0, 0)
         tens = sim.task_tensors()
         sim.task_reset()
         sim.task_step_n(25)
