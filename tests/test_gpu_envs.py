@@ -303,6 +303,33 @@ def test_batched_hooks_timelimit_and_auto_reset_stay_on_the_device():
     env.close()
 
 
+def test_scrimmage_env_11v11_api():
+    """VecSSLScrimmageEnv: BASELINE configs[3] as a fused task (11v11 on the division-A field, every robot
+    commanded): shapes, fed and device-drawn actions, goals end episodes, crowded line-up is a scrum."""
+    import torch
+    from rsoccer_amd.vec import VecSSLScrimmageEnv
+    env = VecSSLScrimmageEnv(256, seed=4)
+    obs, _ = env.reset()
+    assert obs.shape == (256, 46) and env.single_action_space.shape == (88,)
+    x = env.state[5::11][:22]
+    assert float((x[:, None] - x[None]).abs().add(torch.eye(22, device="cuda")[:, :, None] * 9).min()) >= 0.0   # placed
+    for _ in range(30):
+        obs, rew, term, trunc, info = env.step(torch.rand(256, 88, device="cuda") * 2 - 1)
+    obs, rew, term, trunc, info = env.step_random(400)
+    torch.cuda.synchronize()
+    assert torch.isfinite(obs).all() and obs.abs().max() <= 1.2
+    m = env.metrics()
+    assert m["env_steps"] == 256 * 430 and m["goals_for"] + m["goals_against"] == m["episodes"] - m["truncated_episodes"]
+    env.close()
+    crowded = VecSSLScrimmageEnv(64, crowded=True, seed=4)
+    crowded.reset()
+    st = crowded.state
+    assert float(st[5::11][:22].abs().max()) < 0.8 and float(st[6::11][:22].abs().max()) < 0.5    # everyone within the 1.5 m disc
+    crowded.step_random(50)
+    assert crowded.sim.check_finite() == 0
+    crowded.close()
+
+
 def test_serving_kernel_is_bit_identical_and_cannot_hang():
     """rsx_serve_*: a persistent kernel keeps the state in registers and takes one doorbell per step
     (experimental: on this ROCm stack a resident kernel delays every other dispatch by ~1 ms, so it is
