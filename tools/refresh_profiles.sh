@@ -29,6 +29,16 @@ python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_flags.json 2> $OUT/ben
 # one-lane-per-env kernel at 1 M envs: SQ + HBM counters
 tools/prof_epl.sh $OUT/epl > $OUT/epl.log 2>&1
 cat $OUT/epl/*.txt > $OUT/epl_counters_1M.txt
+# SSLStaticDefenders at 1 M envs (one-lane-per-env kernel): kernel stats
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sd_stats -- python -c "
+import sys; sys.path.insert(0, '.')
+import torch
+from rsoccer_amd import _lib as L
+s = L.Sim(1, 2, 1, 6, 25, 1 << 20); s.task_attach(2, 0, 0, 0); s.task_reset(); s.task_step_n(60); torch.cuda.synchronize()
+" > $OUT/sd_stats.log 2>&1
+find $OUT/sd_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/sd_1M_kernel_stats.csv
+head -3 $OUT/sd_1M_kernel_stats.csv
+python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
 # batched hooks: no host <-> device copy inside step()
 rocprofv3 --memory-copy-trace --kernel-trace --stats --output-format csv -d $OUT/hooks -- python tools/hooks_nocopy.py > $OUT/hooks.log 2>&1
 find $OUT/hooks -name "*memory_copy_stats.csv" -o -name "*memory_copy_trace.csv" | head -3
