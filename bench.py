@@ -145,7 +145,9 @@ def cpu_baseline(envs, budget_s=12.0, single_s=1.5):
 def kernel_name(envs, mode):
     lay = os.environ.get("RSX_LAYOUT")
     epl = lay == "epl" or (lay != "lanes" and envs >= EPL_MIN_ENVS)
-    return ("rsx::vss_epl_kernel<%d>" if epl else "rsx::task_step_kernel<0, 8, 1, 6, %d>") % (0 if mode == "step" else 3)
+    if epl:
+        return "rsx::vss_epl_kernel<0>" if mode == "step" else "rsx::vss_epl_rollout_kernel"
+    return "rsx::task_step_kernel<0, 8, 1, 6, %d>" % (0 if mode == "step" else 3)
 
 
 def roofline_of(envs, launch_us, units_per_launch, mode, traffic=None, traffic_source=None):

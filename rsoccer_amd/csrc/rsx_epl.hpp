@@ -22,18 +22,44 @@ namespace rsx {
 
 constexpr int EPL_NR = 6;           // VSS 3v3
 constexpr int EPL_NB = EPL_NR + 1;  // + ball (body index EPL_NR)
-constexpr int EPL_OD = 40, EPL_ODP = 41;
+constexpr int EPL_OD = 40;
 
 struct EplShared {
-    // phase 1 (contacts of a sub-step, only when some lane touches something): snapshot + sums,
-    // phase 2 (after the physics): observation rows; the two never live together
-    union {
-        struct { float acc[4][EPL_NB][64]; float accw[64]; } c;
-        float stage[64 * EPL_ODP];
-    } u;
-    // (the reset placement keeps its poses in the resetting env's own observation row: that row
-    // has been copied out as the terminal observation and is rewritten right after)
+    // contact sums of a sub-step (only when some lane touches something), column = lane; the same words serve
+    // as scratch for the poses of a reset placement.  Observations do NOT pass through LDS: each lane
+    // holds its env's 40 values in registers and stores them as ten 16-byte pieces (the index arithmetic
+    // of a staged, coalesced copy-out cost 5 % of the kernel's VALU instructions and a wave of occupancy).
+    struct { float acc[4][EPL_NB][64]; float accw[64]; } c;
 };
+
+// VSS-v0 observation of a 3v3 env into registers (vss_gym.py:93-117): same values as write_obs<VSS, VSS_V0>
+// with the robot counts known at compile time (a register array cannot be indexed by run-time offsets)
+__device__ __forceinline__ void epl_obs_ball(const Params& P, float* ob, float x, float y, float vx, float vy) {
+    using T = TC<RSX_TASK_VSS_V0>;
+    ob[0] = clampf(x * P.inv_max_pos, -1.2f, 1.2f); ob[1] = clampf(y * P.inv_max_pos, -1.2f, 1.2f);
+    ob[2] = clampf(vx * T::inv_max_v, -1.2f, 1.2f); ob[3] = clampf(vy * T::inv_max_v, -1.2f, 1.2f);
+}
+__device__ __forceinline__ void epl_obs_robot(const Params& P, float* ob, const int k /* constant after unrolling */, float x,
+                                              float y, float vx, float vy, float sn, float cs, float om_deg) {
+    using T = TC<RSX_TASK_VSS_V0>;
+    if (k < 3) {   // blue: 7 values
+        float* r = ob + 4 + 7 * k;
+        r[0] = clampf(x * P.inv_max_pos, -1.2f, 1.2f); r[1] = clampf(y * P.inv_max_pos, -1.2f, 1.2f);
+        r[2] = sn; r[3] = cs;
+        r[4] = clampf(vx * T::inv_max_v, -1.2f, 1.2f); r[5] = clampf(vy * T::inv_max_v, -1.2f, 1.2f);
+        r[6] = clampf(om_deg * T::inv_max_w, -1.2f, 1.2f);
+    } else {        // yellow: 5 values
+        float* r = ob + 4 + 7 * 3 + 5 * (k - 3);
+        r[0] = clampf(x * P.inv_max_pos, -1.2f, 1.2f); r[1] = clampf(y * P.inv_max_pos, -1.2f, 1.2f);
+        r[2] = clampf(vx * T::inv_max_v, -1.2f, 1.2f); r[3] = clampf(vy * T::inv_max_v, -1.2f, 1.2f);
+        r[4] = clampf(om_deg * T::inv_max_w, -1.2f, 1.2f);
+    }
+}
+__device__ __forceinline__ void epl_store_row(float* dst, const float* ob) {   // 40 floats = ten 16-byte stores
+    float4* d4 = reinterpret_cast<float4*>(dst);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) d4[i] = make_float4(ob[4 * i], ob[4 * i + 1], ob[4 * i + 2], ob[4 * i + 3]);
+}
 
 // pair p -> (i, j), i < j, lexicographic: every body then receives its partners in index order
 __device__ __forceinline__ void epl_pair(int p, int& i, int& j) {
@@ -44,7 +70,7 @@ __device__ __forceinline__ void epl_pair(int p, int& i, int& j) {
 }
 
 template <int MODE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void vss_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
+__device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, const Buffers& bufs_) {
     constexpr int KIND = RSX_KIND_VSS, TASK = RSX_TASK_VSS_V0, N = EPL_NR;
     using K = KC<KIND>;
     using T = TC<TASK>;
@@ -242,10 +268,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 // by select chains (a snapshot in LDS would cost a wave of occupancy: 9 KB per wave)
 #pragma unroll
                 for (int k = 0; k < EPL_NB; ++k) {
-                    sh.u.c.acc[0][k][lane] = 0.0f; sh.u.c.acc[1][k][lane] = 0.0f;
-                    sh.u.c.acc[2][k][lane] = 0.0f; sh.u.c.acc[3][k][lane] = 0.0f;
+                    sh.c.acc[0][k][lane] = 0.0f; sh.c.acc[1][k][lane] = 0.0f;
+                    sh.c.acc[2][k][lane] = 0.0f; sh.c.acc[3][k][lane] = 0.0f;
                 }
-                sh.u.c.accw[lane] = 0.0f;
+                sh.c.accw[lane] = 0.0f;
                 wave_sync();
                 deep = false;
                 unsigned todo = touching;
@@ -271,23 +297,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     {
                         const float dx = bj.x - bi.x, dy = bj.y - bi.y;
                         const float d2 = fma_(dx, dx, dy * dy);
-                        float a0 = sh.u.c.acc[0][i][lane], a1 = sh.u.c.acc[1][i][lane], a2 = sh.u.c.acc[2][i][lane], a3 = sh.u.c.acc[3][i][lane];
+                        float a0 = sh.c.acc[0][i][lane], a1 = sh.c.acc[1][i][lane], a2 = sh.c.acc[2][i][lane], a3 = sh.c.acc[3][i][lane];
                         contact_response(bi, make_float4(bj.x, bj.y, bj.vx, bj.vy), d2, rs, ope, rb ? K::w_rb_r : K::w_rr,
                                          rb ? K::kt_rb_r : K::kt_rr, mu, 0.0f, fma_(wj, lever_j, wi * K::r_robot), K::beta, K::pen2,
                                          a0, a1, a2, a3, unused, deep);
-                        sh.u.c.acc[0][i][lane] = a0; sh.u.c.acc[1][i][lane] = a1; sh.u.c.acc[2][i][lane] = a2; sh.u.c.acc[3][i][lane] = a3;
+                        sh.c.acc[0][i][lane] = a0; sh.c.acc[1][i][lane] = a1; sh.c.acc[2][i][lane] = a2; sh.c.acc[3][i][lane] = a3;
                     }
                     // ... and j sees i, from its own point of view (what its lane computes in the other layout)
                     {
                         const float dx = bi.x - bj.x, dy = bi.y - bj.y;
                         const float d2 = fma_(dx, dx, dy * dy);
-                        float a0 = sh.u.c.acc[0][j][lane], a1 = sh.u.c.acc[1][j][lane], a2 = sh.u.c.acc[2][j][lane], a3 = sh.u.c.acc[3][j][lane];
-                        float a4 = rb ? sh.u.c.accw[lane] : 0.0f;
+                        float a0 = sh.c.acc[0][j][lane], a1 = sh.c.acc[1][j][lane], a2 = sh.c.acc[2][j][lane], a3 = sh.c.acc[3][j][lane];
+                        float a4 = rb ? sh.c.accw[lane] : 0.0f;
                         contact_response(bj, make_float4(bi.x, bi.y, bi.vx, bi.vy), d2, rs, ope, rb ? K::w_rb_b : K::w_rr,
                                          rb ? K::kt_rb_b : K::kt_rr, mu, rb ? K::spin_c : 0.0f, fma_(wi, K::r_robot, wj * lever_j), K::beta, K::pen2,
                                          a0, a1, a2, a3, a4, deep);
-                        sh.u.c.acc[0][j][lane] = a0; sh.u.c.acc[1][j][lane] = a1; sh.u.c.acc[2][j][lane] = a2; sh.u.c.acc[3][j][lane] = a3;
-                        if (rb) sh.u.c.accw[lane] = a4;
+                        sh.c.acc[0][j][lane] = a0; sh.c.acc[1][j][lane] = a1; sh.c.acc[2][j][lane] = a2; sh.c.acc[3][j][lane] = a3;
+                        if (rb) sh.c.accw[lane] = a4;
                     }
                 }
                 wave_sync();
@@ -296,14 +322,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #pragma unroll
                 for (int k = 0; k < N; ++k) {
                     if (touching & PM[k]) {
-                        r[k].vx = r[k].vx + sh.u.c.acc[0][k][lane]; r[k].vy = r[k].vy + sh.u.c.acc[1][k][lane];
-                        r[k].x = r[k].x + sh.u.c.acc[2][k][lane]; r[k].y = r[k].y + sh.u.c.acc[3][k][lane];
+                        r[k].vx = r[k].vx + sh.c.acc[0][k][lane]; r[k].vy = r[k].vy + sh.c.acc[1][k][lane];
+                        r[k].x = r[k].x + sh.c.acc[2][k][lane]; r[k].y = r[k].y + sh.c.acc[3][k][lane];
                     }
                 }
                 if (touching & PM[N]) {
-                    ball.vx = ball.vx + sh.u.c.acc[0][N][lane]; ball.vy = ball.vy + sh.u.c.acc[1][N][lane];
-                    ball.x = ball.x + sh.u.c.acc[2][N][lane]; ball.y = ball.y + sh.u.c.acc[3][N][lane];
-                    ball.om = ball.om + sh.u.c.accw[lane];
+                    ball.vx = ball.vx + sh.c.acc[0][N][lane]; ball.vy = ball.vy + sh.c.acc[1][N][lane];
+                    ball.x = ball.x + sh.c.acc[2][N][lane]; ball.y = ball.y + sh.c.acc[3][N][lane];
+                    ball.om = ball.om + sh.c.accw[lane];
                 }
                 wave_sync();
             }
@@ -326,14 +352,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #pragma unroll
             for (int i = 1; i <= 3; ++i) info[i] = auxe[(size_t)(ROW_INFO + i) * B];
         }
-        float* const row = sh.u.stage + lane * EPL_ODP;
+        float ob[EPL_OD];   // this env's observation, in registers
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             const float wd = r[k].om * K::rad2deg;
             wdeg[k] = wd;
             r[k].om = wd * K::deg2rad;
             sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
-            write_obs<KIND, TASK>(P, row, k, true, false, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, wd, 0, prev_pot);
+            epl_obs_robot(P, ob, k, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, wd);
             if (STEP && live) {   // wire format, robot by robot (an env that resets below writes its rows again)
                 float* p = st + (size_t)(5 + 6 * k) * B;
                 p[0] = r[k].x; p[B] = r[k].y; p[2 * B] = r[k].th; p[3 * B] = r[k].vx; p[4 * B] = r[k].vy; p[5 * B] = wd;
@@ -341,7 +367,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             if (STEP) __builtin_amdgcn_sched_barrier(0);
         }
         ball.z = (K::r_ball + ball.z) - K::r_ball;
-        write_obs<KIND, TASK>(P, row, N, false, true, ball.x, ball.y, ball.vx, ball.vy, 0.0f, 0.0f, 0.0f, 0, prev_pot);
+        epl_obs_ball(P, ob, ball.x, ball.y, ball.vx, ball.vy);
         if (first_step) { info[1] = 0.0f; info[2] = 0.0f; info[3] = 0.0f; }
         info[0] = 0.0f; info[4] = 0.0f; info[5] = 0.0f;
         {   // vss_gym.py:144-192,256-311
@@ -383,7 +409,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         // ---- episode end: same-step auto-reset, one lane = one env ----
         if (__any(ended)) {
             if (ended) {
-                for (int i = 0; i < EPL_OD; ++i) bufs.final_obs[(size_t)e * EPL_OD + i] = row[i];
+                epl_store_row(bufs.final_obs + (size_t)e * EPL_OD, ob);   // terminal observation
                 episode += 1; new_episode = true;
                 atomicAdd(&bufs.metrics[1], 1ull);
                 if (info[4] > 0.0f) atomicAdd(&bufs.metrics[2], 1ull);
@@ -399,7 +425,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 };
                 float bx, by;
                 { const float2 u = draw(); bx = P.pl_xlo + P.pl_xspan * u.x; by = P.pl_ylo + P.pl_yspan * u.y; }
-                float* const px = row, * const py = row + 8, * const pth = row + 16;   // scratch: this env's obs row
+                // scratch for the poses placed so far: this lane's column of the (now idle) contact sums
+                float* const px = &sh.c.acc[0][0][lane], * const py = &sh.c.acc[1][0][lane], * const pth = &sh.c.acc[2][0][lane];
                 for (int k = 0; k < N; ++k) {
                     float x = 0.0f, y = 0.0f;
                     for (int tt = 0; tt < 64; ++tt) {
@@ -409,18 +436,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                         bool ok = true;
                         { float dx = x - bx, dy = y - by; if (dx * dx + dy * dy < P.pl_min_d2) ok = false; }
                         for (int q = 0; q < k; ++q) {
-                            float dx = x - px[q], dy = y - py[q];
+                            float dx = x - px[q * 64], dy = y - py[q * 64];
                             if (dx * dx + dy * dy < P.pl_min_d2) ok = false;
                         }
                         if (ok) break;
                     }
                     const float2 u = draw();
-                    px[k] = x; py[k] = y; pth[k] = 360.0f * u.x;
+                    px[k * 64] = x; py[k * 64] = y; pth[k * 64] = 360.0f * u.x;
                 }
                 steps = 0;   // VSS-v0 keeps prev_pot (the first step of an episode ignores it)
                 float nx[N], ny[N], nth[N];
 #pragma unroll
-                for (int k = 0; k < N; ++k) { nx[k] = px[k]; ny[k] = py[k]; nth[k] = pth[k]; }   // read all before the row is rewritten
+                for (int k = 0; k < N; ++k) { nx[k] = px[k * 64]; ny[k] = py[k * 64]; nth[k] = pth[k * 64]; }
 #pragma unroll
                 for (int k = 0; k < N; ++k) {
                     ou[k][0] = 0.0f; ou[k][1] = 0.0f;
@@ -429,7 +456,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     r[k].th = nth[k];
                     wdeg[k] = 0.0f;
                     sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
-                    write_obs<KIND, TASK>(P, row, k, true, false, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, 0.0f, 0, 0.0f);
+                    epl_obs_robot(P, ob, k, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, 0.0f);
                     if (STEP) {   // this env's rows were written before the reset was known
                         float* p = st + (size_t)(5 + 6 * k) * B;
                         p[0] = r[k].x; p[B] = r[k].y; p[2 * B] = r[k].th; p[3 * B] = 0.0f; p[4 * B] = 0.0f; p[5 * B] = 0.0f;
@@ -438,22 +465,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 }
                 ball = Body{};
                 ball.x = bx; ball.y = by;
-                write_obs<KIND, TASK>(P, row, N, false, true, ball.x, ball.y, ball.vx, ball.vy, 0.0f, 0.0f, 0.0f, 0, 0.0f);
+                epl_obs_ball(P, ob, ball.x, ball.y, ball.vx, ball.vy);
             }
         }
-        wave_sync();
-        // ---- observation out, coalesced: 64 rows of 40 floats are one contiguous run ----
-        {
-            const size_t base = (size_t)tile * 64 * EPL_OD;
-            const size_t lim = B * (size_t)EPL_OD;
-#pragma unroll 8
-            for (int c = 0; c < EPL_OD; ++c) {
-                const int i = lane + 64 * c;
-                const float v = sh.u.stage[(i / EPL_OD) * EPL_ODP + i % EPL_OD];
-                if (base + i < lim) bufs.obs[base + i] = v;
-            }
-        }
-        wave_sync();
+        // ---- observation out: this lane's row, ten 16-byte stores ----
+        if (live) epl_store_row(bufs.obs + (size_t)e * EPL_OD, ob);
     }
 
     // ---- store (wire format) ----
@@ -475,6 +491,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         if (!STEP || new_episode) auxe[(size_t)ROW_EPISODE * B] = __uint_as_float(episode);
     }
     if (counts_steps) bufs.metrics[0] = steps_before + (unsigned long long)P.num_envs * (unsigned long long)n_steps;
+}
+
+// Two entry points, two register budgets (measured).  Single-step launches are limited by the
+// memory system: 154 VGPRs without a spill (3 waves per SIMD) beat 128 VGPRs with 84 B of scratch per lane —
+// the spills alone were 150 MB of the 794 MB a 1 M-env launch moved; without them it moves 631 MB, 1.11 x the
+// algorithmic bytes.  Multi-step launches are limited by instruction issue and prefer the fourth wave.
+template <int MODE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void vss_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
+    static_assert(MODE == MODE_STEP, "single-step entry point");
+    vss_epl_body<MODE_STEP>(hp_state, hp_aux, hp_in, hp_flags, hp_num_envs, hp_state_dim, hp_per_xcd, hp_n_steps, P_, bufs_);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void vss_epl_rollout_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
+    vss_epl_body<MODE_ROLLOUT>(hp_state, hp_aux, hp_in, hp_flags, hp_num_envs, hp_state_dim, hp_per_xcd, hp_n_steps, P_, bufs_);
 }
 
 }  // namespace rsx

@@ -23,15 +23,42 @@ namespace rsx {
 
 constexpr int SEPL_NR = 7;            // 1 blue + 6 yellow (static_defenders.py:47-48)
 constexpr int SEPL_NB = SEPL_NR + 1;  // + ball (body index SEPL_NR)
-constexpr int SEPL_OD = 24, SEPL_ODP = 25;
+constexpr int SEPL_OD = 24;
 constexpr int SEPL_PAIRS = SEPL_NR * (SEPL_NR - 1) / 2;   // 21 robot-robot pairs
 
 struct SeplShared {
-    union {
-        struct { float acc[4][SEPL_NB][64]; float accw[64]; } c;   // contact sums (column = lane)
-        float stage[64 * SEPL_ODP];                                 // observation rows
-    } u;
+    // contact sums (column = lane); also scratch for the poses of a reset placement.  Observations stay in
+    // registers and go out as six 16-byte stores per lane (see rsx_epl.hpp).
+    struct { float acc[4][SEPL_NB][64]; float accw[64]; } c;
 };
+
+// SSLStaticDefenders observation of a 1v6 env into registers (static_defenders.py:90-112): the values of
+// write_obs<SSL, STATIC_DEFENDERS> with the team sizes known at compile time
+__device__ __forceinline__ void sepl_obs_ball(const Params& P, float* ob, float x, float y, float vx, float vy) {
+    using T = TC<RSX_TASK_SSL_STATIC_DEFENDERS>;
+    ob[0] = clampf(x * P.inv_max_pos, -1.2f, 1.2f); ob[1] = clampf(y * P.inv_max_pos, -1.2f, 1.2f);
+    ob[2] = clampf(vx * T::inv_max_v, -1.2f, 1.2f); ob[3] = clampf(vy * T::inv_max_v, -1.2f, 1.2f);
+}
+__device__ __forceinline__ void sepl_obs_robot(const Params& P, float* ob, const int k /* constant after unrolling */, float x,
+                                               float y, float vx, float vy, float sn, float cs, float om_deg, int ir) {
+    using T = TC<RSX_TASK_SSL_STATIC_DEFENDERS>;
+    if (k == 0) {   // the agent: 8 values
+        float* r = ob + 4;
+        r[0] = clampf(x * P.inv_max_pos, -1.2f, 1.2f); r[1] = clampf(y * P.inv_max_pos, -1.2f, 1.2f);
+        r[2] = sn; r[3] = cs;
+        r[4] = clampf(vx * T::inv_max_v, -1.2f, 1.2f); r[5] = clampf(vy * T::inv_max_v, -1.2f, 1.2f);
+        r[6] = clampf(om_deg * T::inv_max_w, -1.2f, 1.2f);
+        r[7] = ir ? 1.0f : 0.0f;
+    } else {        // a defender: position only
+        float* r = ob + 12 + 2 * (k - 1);
+        r[0] = clampf(x * P.inv_max_pos, -1.2f, 1.2f); r[1] = clampf(y * P.inv_max_pos, -1.2f, 1.2f);
+    }
+}
+__device__ __forceinline__ void sepl_store_row(float* dst, const float* ob) {   // 24 floats = six 16-byte stores
+    float4* d4 = reinterpret_cast<float4*>(dst);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) d4[i] = make_float4(ob[4 * i], ob[4 * i + 1], ob[4 * i + 2], ob[4 * i + 3]);
+}
 
 // pair p -> (i, j), i < j < 7, lexicographic: rows of the upper triangle start at 0, 6, 11, 15, 18, 20
 __device__ __forceinline__ void sepl_pair(int p, int& i, int& j) {
@@ -235,10 +262,10 @@ void ssl_sd_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
                 const bool first = sweep == 0;
 #pragma unroll
                 for (int k = 0; k < SEPL_NB; ++k) {
-                    sh.u.c.acc[0][k][lane] = 0.0f; sh.u.c.acc[1][k][lane] = 0.0f;
-                    sh.u.c.acc[2][k][lane] = 0.0f; sh.u.c.acc[3][k][lane] = 0.0f;
+                    sh.c.acc[0][k][lane] = 0.0f; sh.c.acc[1][k][lane] = 0.0f;
+                    sh.c.acc[2][k][lane] = 0.0f; sh.c.acc[3][k][lane] = 0.0f;
                 }
-                sh.u.c.accw[lane] = 0.0f;
+                sh.c.accw[lane] = 0.0f;
                 wave_sync();
                 deep = false;
                 // robot-robot pairs, in pair order: every body receives its partners in index order
@@ -258,17 +285,17 @@ void ssl_sd_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
                     float unused = 0.0f;
                     {
                         const float dx = bj.x - bi.x, dy = bj.y - bi.y;
-                        float a0 = sh.u.c.acc[0][i][lane], a1 = sh.u.c.acc[1][i][lane], a2 = sh.u.c.acc[2][i][lane], a3 = sh.u.c.acc[3][i][lane];
+                        float a0 = sh.c.acc[0][i][lane], a1 = sh.c.acc[1][i][lane], a2 = sh.c.acc[2][i][lane], a3 = sh.c.acc[3][i][lane];
                         contact_response(bi, make_float4(bj.x, bj.y, bj.vx, bj.vy), fma_(dx, dx, dy * dy), K::rs_rr, K::ope_rr, K::w_rr, K::kt_rr,
                                          K::mu_rr, 0.0f, fma_(wj, K::r_robot, wi * K::r_robot), K::beta, K::pen2, a0, a1, a2, a3, unused, deep);
-                        sh.u.c.acc[0][i][lane] = a0; sh.u.c.acc[1][i][lane] = a1; sh.u.c.acc[2][i][lane] = a2; sh.u.c.acc[3][i][lane] = a3;
+                        sh.c.acc[0][i][lane] = a0; sh.c.acc[1][i][lane] = a1; sh.c.acc[2][i][lane] = a2; sh.c.acc[3][i][lane] = a3;
                     }
                     {
                         const float dx = bi.x - bj.x, dy = bi.y - bj.y;
-                        float a0 = sh.u.c.acc[0][j][lane], a1 = sh.u.c.acc[1][j][lane], a2 = sh.u.c.acc[2][j][lane], a3 = sh.u.c.acc[3][j][lane];
+                        float a0 = sh.c.acc[0][j][lane], a1 = sh.c.acc[1][j][lane], a2 = sh.c.acc[2][j][lane], a3 = sh.c.acc[3][j][lane];
                         contact_response(bj, make_float4(bi.x, bi.y, bi.vx, bi.vy), fma_(dx, dx, dy * dy), K::rs_rr, K::ope_rr, K::w_rr, K::kt_rr,
                                          K::mu_rr, 0.0f, fma_(wi, K::r_robot, wj * K::r_robot), K::beta, K::pen2, a0, a1, a2, a3, unused, deep);
-                        sh.u.c.acc[0][j][lane] = a0; sh.u.c.acc[1][j][lane] = a1; sh.u.c.acc[2][j][lane] = a2; sh.u.c.acc[3][j][lane] = a3;
+                        sh.c.acc[0][j][lane] = a0; sh.c.acc[1][j][lane] = a1; sh.c.acc[2][j][lane] = a2; sh.c.acc[3][j][lane] = a3;
                     }
                 }
                 // robot-ball, robot by robot (the ball sums the robots' records in robot order): kicker mouth
@@ -302,9 +329,9 @@ void ssl_sd_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
                     if (touch) {
                         rb_touch |= 1u << k;
                         deep |= pen > K::pen2;
-                        float a0 = sh.u.c.acc[0][k][lane], a1 = sh.u.c.acc[1][k][lane], a2 = sh.u.c.acc[2][k][lane], a3 = sh.u.c.acc[3][k][lane];
-                        float b0 = sh.u.c.acc[0][N][lane], b1 = sh.u.c.acc[1][N][lane], b2 = sh.u.c.acc[2][N][lane], b3 = sh.u.c.acc[3][N][lane];
-                        float bw = sh.u.c.accw[lane];
+                        float a0 = sh.c.acc[0][k][lane], a1 = sh.c.acc[1][k][lane], a2 = sh.c.acc[2][k][lane], a3 = sh.c.acc[3][k][lane];
+                        float b0 = sh.c.acc[0][N][lane], b1 = sh.c.acc[1][N][lane], b2 = sh.c.acc[2][N][lane], b3 = sh.c.acc[3][N][lane];
+                        float bw = sh.c.accw[lane];
                         const float dvx = ball.vx - o.vx, dvy = ball.vy - o.vy;
                         float vn = fma_(dvx, nx, dvy * ny);
                         if (vn < 0.0f) {
@@ -324,9 +351,9 @@ void ssl_sd_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
                         a2 = fma_(-pc, nx, a2); a3 = fma_(-pc, ny, a3);
                         float pb = K::beta * pen * K::w_rb_b;
                         b2 = b2 + pb * nx; b3 = b3 + pb * ny;
-                        sh.u.c.acc[0][k][lane] = a0; sh.u.c.acc[1][k][lane] = a1; sh.u.c.acc[2][k][lane] = a2; sh.u.c.acc[3][k][lane] = a3;
-                        sh.u.c.acc[0][N][lane] = b0; sh.u.c.acc[1][N][lane] = b1; sh.u.c.acc[2][N][lane] = b2; sh.u.c.acc[3][N][lane] = b3;
-                        sh.u.c.accw[lane] = bw;
+                        sh.c.acc[0][k][lane] = a0; sh.c.acc[1][k][lane] = a1; sh.c.acc[2][k][lane] = a2; sh.c.acc[3][k][lane] = a3;
+                        sh.c.acc[0][N][lane] = b0; sh.c.acc[1][N][lane] = b1; sh.c.acc[2][N][lane] = b2; sh.c.acc[3][N][lane] = b3;
+                        sh.c.accw[lane] = bw;
                     }
                     if (first) {
                         const bool ir = mouth && pen > -K::ir_tol;
@@ -356,14 +383,14 @@ void ssl_sd_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
 #pragma unroll
                 for (int k = 0; k < N; ++k) {
                     if ((touching & PM[k]) | (rb_touch & (1u << k))) {
-                        r[k].vx = r[k].vx + sh.u.c.acc[0][k][lane]; r[k].vy = r[k].vy + sh.u.c.acc[1][k][lane];
-                        r[k].x = r[k].x + sh.u.c.acc[2][k][lane]; r[k].y = r[k].y + sh.u.c.acc[3][k][lane];
+                        r[k].vx = r[k].vx + sh.c.acc[0][k][lane]; r[k].vy = r[k].vy + sh.c.acc[1][k][lane];
+                        r[k].x = r[k].x + sh.c.acc[2][k][lane]; r[k].y = r[k].y + sh.c.acc[3][k][lane];
                     }
                 }
                 if (rb_touch) {
-                    ball.vx = ball.vx + sh.u.c.acc[0][N][lane]; ball.vy = ball.vy + sh.u.c.acc[1][N][lane];
-                    ball.x = ball.x + sh.u.c.acc[2][N][lane]; ball.y = ball.y + sh.u.c.acc[3][N][lane];
-                    ball.om = ball.om + sh.u.c.accw[lane];
+                    ball.vx = ball.vx + sh.c.acc[0][N][lane]; ball.vy = ball.vy + sh.c.acc[1][N][lane];
+                    ball.x = ball.x + sh.c.acc[2][N][lane]; ball.y = ball.y + sh.c.acc[3][N][lane];
+                    ball.om = ball.om + sh.c.accw[lane];
                 }
                 wave_sync();
             }
@@ -386,7 +413,7 @@ void ssl_sd_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
         }
 
         // ---- wire-format values, observation, reward ----
-        float* const row = sh.u.stage + lane * SEPL_ODP;
+        float ob[SEPL_OD];   // this env's observation, in registers
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             const float wd = r[k].om * K::rad2deg;
@@ -394,10 +421,10 @@ void ssl_sd_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
             wheel_speeds<KIND>(P, r[k], wheels[k]);   // from the carried (c, s) and the unrounded rate, like the other layout
             r[k].om = wd * K::deg2rad;
             sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
-            write_obs<KIND, TASK>(P, row, k, true, false, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, wd, r[k].ir, 0.0f);
+            sepl_obs_robot(P, ob, k, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, wd, r[k].ir);
         }
         ball.z = (K::r_ball + ball.z) - K::r_ball;
-        write_obs<KIND, TASK>(P, row, N, false, true, ball.x, ball.y, ball.vx, ball.vy, 0.0f, 0.0f, 0.0f, 0, 0.0f);
+        sepl_obs_ball(P, ob, ball.x, ball.y, ball.vx, ball.vy);
         bool success = false;
         {   // static_defenders.py:150-212,256-322
             reward = 0.0f; term = 0;
@@ -435,7 +462,7 @@ void ssl_sd_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
         // ---- episode end: same-step auto-reset, one lane = one env ----
         if (__any(ended)) {
             if (ended) {
-                for (int i = 0; i < SEPL_OD; ++i) bufs.final_obs[(size_t)e * SEPL_OD + i] = row[i];
+                sepl_store_row(bufs.final_obs + (size_t)e * SEPL_OD, ob);   // terminal observation
                 episode += 1;
                 atomicAdd(&bufs.metrics[1], 1ull);
                 if (success) atomicAdd(&bufs.metrics[2], 1ull);
@@ -455,7 +482,8 @@ void ssl_sd_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
                     by = P.pl_ylo + P.pl_yspan * u.y;
                     if (!(bx > P.pen_x && fabsf(by) < P.half_pen_wid)) break;
                 }
-                float* const px = row, * const py = row + 8, * const pth = row + 16;   // scratch: this env's obs row
+                // scratch for the poses placed so far: this lane's column of the (now idle) contact sums
+                float* const px = &sh.c.acc[0][0][lane], * const py = &sh.c.acc[1][0][lane], * const pth = &sh.c.acc[2][0][lane];
                 px[0] = 0.0f; py[0] = 0.0f; pth[0] = 0.0f;   // blue 0 at the origin
                 for (int k = 1; k < N; ++k) {
                     float x = 0.0f, y = 0.0f;
@@ -466,18 +494,18 @@ void ssl_sd_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
                         bool ok = true;
                         { float dx = x - bx, dy = y - by; if (dx * dx + dy * dy < P.pl_min_d2) ok = false; }
                         for (int q = 0; q < k; ++q) {
-                            float dx = x - px[q], dy = y - py[q];
+                            float dx = x - px[q * 64], dy = y - py[q * 64];
                             if (dx * dx + dy * dy < P.pl_min_d2) ok = false;
                         }
                         if (ok) break;
                     }
                     const float2 u = draw();
-                    px[k] = x; py[k] = y; pth[k] = 360.0f * u.x;
+                    px[k * 64] = x; py[k * 64] = y; pth[k * 64] = 360.0f * u.x;
                 }
                 steps = 0;
                 float nx[N], ny[N], nth[N];
 #pragma unroll
-                for (int k = 0; k < N; ++k) { nx[k] = px[k]; ny[k] = py[k]; nth[k] = pth[k]; }   // read all before the row is rewritten
+                for (int k = 0; k < N; ++k) { nx[k] = px[k * 64]; ny[k] = py[k * 64]; nth[k] = pth[k * 64]; }
 #pragma unroll
                 for (int k = 0; k < N; ++k) {
                     r[k] = Body{};
@@ -487,26 +515,15 @@ void ssl_sd_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) wheels[k][i] = 0.0f;
                     sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
-                    write_obs<KIND, TASK>(P, row, k, true, false, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, 0.0f, 0, 0.0f);
+                    sepl_obs_robot(P, ob, k, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, 0.0f, 0);
                 }
                 ball = Body{};
                 ball.x = bx; ball.y = by;
-                write_obs<KIND, TASK>(P, row, N, false, true, ball.x, ball.y, ball.vx, ball.vy, 0.0f, 0.0f, 0.0f, 0, 0.0f);
+                sepl_obs_ball(P, ob, ball.x, ball.y, ball.vx, ball.vy);
             }
         }
-        wave_sync();
-        // ---- observation out, coalesced: 64 rows of 24 floats are one contiguous run ----
-        {
-            const size_t base = (size_t)tile * 64 * SEPL_OD;
-            const size_t lim = B * (size_t)SEPL_OD;
-#pragma unroll 8
-            for (int c = 0; c < SEPL_OD; ++c) {
-                const int i = lane + 64 * c;
-                const float v = sh.u.stage[(i / SEPL_OD) * SEPL_ODP + i % SEPL_OD];
-                if (base + i < lim) bufs.obs[base + i] = v;
-            }
-        }
-        wave_sync();
+        // ---- observation out: this lane's row, six 16-byte stores ----
+        if (live) sepl_store_row(bufs.obs + (size_t)e * SEPL_OD, ob);
     }
 
     // ---- store (wire format: degrees, deg/s, infrared, wheel speeds) ----
