@@ -250,6 +250,7 @@ def main():
         (host-asynchronous) collective: measured on MI355X, recording a HIP event on a busy stream
         costs ~200 us of stream time, so the async_op=True / side-stream forms of torch.distributed
         (which record events) are 3 orders of magnitude more expensive than the ~20 us collective."""
+        sim.metrics_fold(stream)
         mbuf.copy_(tens["metrics"], non_blocking=backend == "nccl")
         dist.all_reduce(mbuf)
 

@@ -116,8 +116,10 @@ typedef struct rsx_task_view {
     int32_t* steps;         /* [B] i32: steps taken in the current episode                   */
     float*   actions;       /* [B][act_dim] f32: staging buffer callers may fill and pass to
                                rsx_task_step (any device pointer of that shape works)        */
-    int64_t* metrics;       /* [RSX_METRICS] i64 device counters, all eight maintained by the
-                               step kernels (stream-ordered)                                 */
+    int64_t* metrics;       /* [RSX_METRICS] i64 device counters, maintained by the step kernels
+                               (stream-ordered).  [0] is exact after every launch; the episode
+                               counters [1..6] are exact after rsx_metrics_fold /
+                               rsx_read_metrics (the kernels add into per-block partial sums) */
 } rsx_task_view;
 
 /* ---- diagnostics ---------------------------------------------------------------------- */
@@ -246,6 +248,11 @@ int rsx_check_finite(rsx_sim* h, int64_t* n_bad, void* stream);
  * 4 sum of episode returns in 2^-20 fixed point, 5 sum of episode lengths,
  * 6 truncated episodes, 7 reserved.  Synchronises `stream`. */
 int rsx_read_metrics(rsx_sim* h, int64_t out[RSX_METRICS], void* stream);
+/* Device-side readers of rsx_task_view.metrics (e.g. an RCCL all-reduce of the 64 bytes) call this
+ * first: one tiny launch on `stream` that adds the step kernels' partial episode counters into
+ * metrics[1..6].  (Atomics of a whole grid on one cache line serialise: at 10^6 envs they, not the
+ * physics, set the step time.)  rsx_read_metrics does it itself. */
+int rsx_metrics_fold(rsx_sim* h, void* stream);
 
 #ifdef __cplusplus
 }

@@ -34,7 +34,7 @@ SYMBOLS = (
     "rsx_get_state_full", "rsx_dev_view_get", "rsx_step_dev", "rsx_step_dev_random", "rsx_step_dev_flip", "rsx_state_buffers",
     "rsx_reset_dev", "rsx_task_attach",
     "rsx_task_view_get", "rsx_task_reset", "rsx_task_reset_to", "rsx_task_step",
-    "rsx_task_step_n", "rsx_task_rollout", "rsx_read_metrics", "rsx_check_finite",
+    "rsx_task_step_n", "rsx_task_rollout", "rsx_read_metrics", "rsx_metrics_fold", "rsx_check_finite",
     "rsx_serve_start", "rsx_serve_step", "rsx_serve_stop",
 )
 
@@ -99,6 +99,7 @@ def load():
     lib.rsx_task_step_n.argtypes = [vp, ip, vp]
     lib.rsx_task_rollout.argtypes = [vp, ip, vp]
     lib.rsx_read_metrics.argtypes = [vp, vp, vp]
+    lib.rsx_metrics_fold.argtypes = [vp, vp]
     lib.rsx_check_finite.argtypes = [vp, C.POINTER(C.c_int64), vp]
     lib.rsx_serve_start.argtypes = [vp, ip]
     lib.rsx_serve_step.argtypes = [vp, vp, vp]
@@ -342,6 +343,10 @@ class Sim:
         n = C.c_int64(0)
         _chk(self._lib.rsx_check_finite(self._h, C.byref(n), self._stream(stream)))
         return int(n.value)
+
+    def metrics_fold(self, stream=None):
+        """make the device copy of the episode counters (``task_tensors()["metrics"]``) exact, on ``stream``"""
+        _chk(self._lib.rsx_metrics_fold(self._h, self._stream(stream)))
 
     def read_metrics(self, stream=None):
         out = np.zeros(N_METRICS, dtype=np.int64)

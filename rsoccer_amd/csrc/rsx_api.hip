@@ -18,7 +18,7 @@
 namespace rsx {
 // rsx_epl.hip (own translation unit, own compiler flags)
 void launch_vss_epl(bool rollout, const Params& P, const Buffers& b, int n_steps, hipStream_t s);
-void launch_ssl_sd_epl(bool rollout, const Params& P, const Buffers& b, int n_steps, hipStream_t s);
+void launch_ssl_epl(int task, bool rollout, const Params& P, const Buffers& b, int n_steps, hipStream_t s);
 }
 
 using namespace rsx;
@@ -49,7 +49,7 @@ struct rsx_sim {
     int device = 0;
     int L = 8;   // lanes per env
     int NR = 0;  // compile-time robot count of the selected kernel variant (0 = generic)
-    bool epl = false;  // VSS-v0 3v3 / SSLStaticDefenders 1v6 step and rollout launches use the one-lane-per-env kernels (large batches)
+    bool epl = false;  // VSS-v0 3v3 / the registered SSL tasks: step and rollout launches use the one-lane-per-env kernels (large batches)
     // one allocation per lifetime stage (few pages -> few TLB entries per launch)
     char* arena_sim = nullptr;   // state | cmds
     char* arena_task = nullptr;  // aux | obs | final_obs | flags | actions | metrics
@@ -59,6 +59,7 @@ struct rsx_sim {
     float *d_aux = nullptr, *d_obs = nullptr, *d_final_obs = nullptr, *d_actions = nullptr;
     uint8_t* d_flags = nullptr;
     unsigned long long* d_metrics = nullptr;
+    unsigned long long* d_mslots = nullptr;   // [MSLOTS][RSX_METRICS] partial episode counters (metric_slot)
     unsigned long long* d_check = nullptr;   // rsx_check_finite counter
     hipStream_t cap_stream = nullptr;   // utility stream (serve stop)
     std::vector<float> h_f32;
@@ -126,10 +127,20 @@ __global__ void count_nonfinite_kernel(const float* __restrict__ p, size_t n, un
     if (bad) atomicAdd(out, bad);
 }
 
+// adds the per-block-group partial episode counters into metrics[1..7] and clears them (see metric_slot);
+// stream-ordered after the step launches whose counts it collects.  One wave; lane = counter.
+__global__ void fold_metrics_kernel(unsigned long long* __restrict__ metrics, unsigned long long* __restrict__ slots) {
+    const int i = threadIdx.x;
+    if (i < 1 || i >= RSX_METRICS) return;   // metrics[0] (env-steps) is kept by the step kernels directly
+    unsigned long long sum = 0;
+    for (int s = 0; s < MSLOTS; ++s) { sum += slots[(size_t)s * RSX_METRICS + i]; slots[(size_t)s * RSX_METRICS + i] = 0ull; }
+    metrics[i] += sum;
+}
+
 Buffers buffers_of(const rsx_sim* h, const float* actions) {
     Buffers b;
     b.state = h->d_state; b.aux = h->d_aux; b.obs = h->d_obs; b.final_obs = h->d_final_obs;
-    b.flags = h->d_flags; b.cmds = h->d_cmds; b.actions = actions; b.metrics = h->d_metrics;
+    b.flags = h->d_flags; b.cmds = h->d_cmds; b.actions = actions; b.metrics = h->d_metrics; b.mslots = h->d_mslots;
     b.serve_seq = h->sig_seq; b.serve_done = h->sig_done; b.serve_base = 0; b.serve_timeout = 0;
 #ifdef RSX_TIMING
     b.dbg = g_dbg;
@@ -207,7 +218,7 @@ void launch_task_m(const rsx_sim* h, const float* actions, int n_steps, hipStrea
         return;
     }
     if (TASK == RSX_TASK_SSL_STATIC_DEFENDERS && (MODE == MODE_STEP || MODE == MODE_ROLLOUT) && h->epl && h->NR == 7 && h->L == 8) {
-        launch_ssl_sd_epl(MODE == MODE_ROLLOUT, h->P, b, n_steps, s);
+        launch_ssl_epl(TASK, MODE == MODE_ROLLOUT, h->P, b, n_steps, s);
         return;
     }
     const dim3 grid = grid_for(h);
@@ -245,6 +256,7 @@ template <int TASK, int NRS, int MODE>
 void launch_fixed_m(const rsx_sim* h, const float* actions, int n_steps, hipStream_t s) {
     const dim3 grid = grid_for(h);
     const Buffers b = buffers_of(h, actions);
+    if ((MODE == MODE_STEP || MODE == MODE_ROLLOUT) && h->epl) { launch_ssl_epl(TASK, MODE == MODE_ROLLOUT, h->P, b, n_steps, s); return; }
     RSX_LAUNCH((task_step_kernel<RSX_KIND_SSL, 8, TASK, NRS, MODE>), h->P, b, n_steps);
 }
 template <int TASK, int NRS>
@@ -636,7 +648,8 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
     const size_t n_flags = align_up(2 * B);
     const size_t n_act = align_up(B * h->M.act_dim * sizeof(float));
     const size_t n_met = align_up(RSX_METRICS * sizeof(unsigned long long));
-    const size_t total = n_aux + 2 * n_obs + n_flags + n_act + n_met;
+    const size_t n_slots = align_up((size_t)MSLOTS * RSX_METRICS * sizeof(unsigned long long));
+    const size_t total = n_aux + 2 * n_obs + n_flags + n_act + n_met + n_slots;
     HIP_TRY(hipMalloc((void**)&h->arena_task, total));
     HIP_TRY(hipMemset(h->arena_task, 0, total));
     char* p = h->arena_task;
@@ -645,14 +658,16 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
     h->d_final_obs = (float*)p; p += n_obs;
     h->d_flags = (uint8_t*)p; p += n_flags;
     h->d_actions = (float*)p; p += n_act;
-    h->d_metrics = (unsigned long long*)p;
+    h->d_metrics = (unsigned long long*)p; p += n_met;
+    h->d_mslots = (unsigned long long*)p;
     // episode ids start at 0xFFFFFFFF so that the first reset() opens episode 0
     HIP_TRY(hipMemset(h->d_aux + (size_t)ROW_EPISODE * B, 0xFF, B * sizeof(uint32_t)));
     h->P = P;
     // VSS-v0 3v3: which tile layout steps the envs.  Both give identical results; the one-lane-
     // per-env kernel needs enough envs to fill the chip with its long waves.
     h->epl = false;
-    if ((task == RSX_TASK_VSS_V0 && h->NR == 6 && h->L == 8) || (task == RSX_TASK_SSL_STATIC_DEFENDERS && h->NR == 7 && h->L == 8)) {
+    const bool fixed_ssl = task == RSX_TASK_SSL_DRIBBLING || task == RSX_TASK_SSL_CONTESTED || task == RSX_TASK_SSL_PASS_ENDURANCE;   // team sizes checked above
+    if ((task == RSX_TASK_VSS_V0 && h->NR == 6 && h->L == 8) || (task == RSX_TASK_SSL_STATIC_DEFENDERS && h->NR == 7 && h->L == 8) || fixed_ssl) {
         const char* lay = std::getenv("RSX_LAYOUT");
         if (lay && std::strcmp(lay, "epl") == 0) h->epl = true;
         else if (lay && std::strcmp(lay, "lanes") == 0) h->epl = false;
@@ -820,10 +835,19 @@ int rsx_check_finite(rsx_sim* h, int64_t* n_bad, void* stream) {
     return check_finite_impl(h, n_bad, (hipStream_t)stream);
 }
 
+int rsx_metrics_fold(rsx_sim* h, void* stream) {
+    RSX_ENTER_TASK(h);
+    hipLaunchKernelGGL(fold_metrics_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, h->d_metrics, h->d_mslots);
+    HIP_TRY(hipGetLastError());
+    return RSX_OK;
+}
+
 int rsx_read_metrics(rsx_sim* h, int64_t out[RSX_METRICS], void* stream) {
     RSX_ENTER_TASK(h);
     if (!out) return fail(RSX_ERR_ARG, "out is null");
     hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(fold_metrics_kernel, dim3(1), dim3(64), 0, s, h->d_metrics, h->d_mslots);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, h->d_metrics, RSX_METRICS * sizeof(int64_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return RSX_OK;

@@ -1,4 +1,4 @@
-// rsx_epl.hip — the one-lane-per-env kernels (VSS-v0, SSLStaticDefenders) in their own translation unit:
+// rsx_epl.hip — the one-lane-per-env kernels (VSS-v0 and the four SSL tasks) in their own translation unit:
 // built with the compiler's default machine scheduler and explicit occupancy targets per entry point, while
 // rsx_api.hip is built with -amdgpu-sched-strategy=max-ilp, which suits the short 8-lanes-per-env kernels at
 // small batches but costs these a wave of occupancy.
@@ -20,15 +20,25 @@ void launch_vss_epl(bool rollout, const Params& P, const Buffers& b, int n_steps
                            P.num_envs, P.state_dim, (int)(grid.x >> 3), n_steps, P, b);
 }
 
-void launch_ssl_sd_epl(bool rollout, const Params& P, const Buffers& b, int n_steps, hipStream_t s) {
+template <int TASK>
+static void launch_ssl_epl_t(bool rollout, const Params& P, const Buffers& b, int n_steps, hipStream_t s) {
     const int tiles = (P.num_envs + 63) / 64;
     const dim3 grid((unsigned)(((tiles + 7) / 8) * 8));
     if (rollout)
-        hipLaunchKernelGGL((ssl_sd_epl_kernel<MODE_ROLLOUT>), grid, dim3(64), 0, s, b.state, b.aux, b.actions, b.flags,
+        hipLaunchKernelGGL((ssl_epl_kernel<TASK, MODE_ROLLOUT>), grid, dim3(64), 0, s, b.state, b.aux, b.actions, b.flags,
                            P.num_envs, P.state_dim, (int)(grid.x >> 3), n_steps, P, b);
     else
-        hipLaunchKernelGGL((ssl_sd_epl_kernel<MODE_STEP>), grid, dim3(64), 0, s, b.state, b.aux, b.actions, b.flags,
+        hipLaunchKernelGGL((ssl_epl_kernel<TASK, MODE_STEP>), grid, dim3(64), 0, s, b.state, b.aux, b.actions, b.flags,
                            P.num_envs, P.state_dim, (int)(grid.x >> 3), n_steps, P, b);
+}
+
+void launch_ssl_epl(int task, bool rollout, const Params& P, const Buffers& b, int n_steps, hipStream_t s) {
+    switch (task) {
+        case RSX_TASK_SSL_STATIC_DEFENDERS: launch_ssl_epl_t<RSX_TASK_SSL_STATIC_DEFENDERS>(rollout, P, b, n_steps, s); break;
+        case RSX_TASK_SSL_DRIBBLING: launch_ssl_epl_t<RSX_TASK_SSL_DRIBBLING>(rollout, P, b, n_steps, s); break;
+        case RSX_TASK_SSL_CONTESTED: launch_ssl_epl_t<RSX_TASK_SSL_CONTESTED>(rollout, P, b, n_steps, s); break;
+        default: launch_ssl_epl_t<RSX_TASK_SSL_PASS_ENDURANCE>(rollout, P, b, n_steps, s); break;
+    }
 }
 
 }  // namespace rsx

@@ -411,12 +411,13 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
             if (ended) {
                 epl_store_row(bufs.final_obs + (size_t)e * EPL_OD, ob);   // terminal observation
                 episode += 1; new_episode = true;
-                atomicAdd(&bufs.metrics[1], 1ull);
-                if (info[4] > 0.0f) atomicAdd(&bufs.metrics[2], 1ull);
-                if (info[5] > 0.0f) atomicAdd(&bufs.metrics[3], 1ull);
-                atomicAdd(&bufs.metrics[4], (unsigned long long)__float2ll_rn(vss_episode_return(info) * 1048576.0f));
-                atomicAdd(&bufs.metrics[5], (unsigned long long)steps);
-                if (trunc && !term) atomicAdd(&bufs.metrics[6], 1ull);
+                unsigned long long* const ms = metric_slot(bufs);
+                atomicAdd(&ms[1], 1ull);
+                if (info[4] > 0.0f) atomicAdd(&ms[2], 1ull);
+                if (info[5] > 0.0f) atomicAdd(&ms[3], 1ull);
+                atomicAdd(&ms[4], (unsigned long long)__float2ll_rn(vss_episode_return(info) * 1048576.0f));
+                atomicAdd(&ms[5], (unsigned long long)steps);
+                if (trunc && !term) atomicAdd(&ms[6], 1ull);
                 // placement: the reference's sequential rejection sampling (vss_gym.py:194-233)
                 uint32_t n = 0;
                 auto draw = [&]() -> float2 {

@@ -1,18 +1,21 @@
-// rsx_epl_ssl.hpp — SSLStaticDefenders-v0 (1 blue + 6 yellow) fused step, "one lane per env" layout for
-// LARGE batches: the SSL counterpart of rsx_epl.hpp.
+// rsx_epl_ssl.hpp — the four registered SSL tasks (SSLStaticDefenders-v0 1v6, SSLDribbling-v0 1v4,
+// SSLContestedPossession-v0 1v1, SSLPassEndurance-v0 2v0) as fused steps in the "one lane per env" layout
+// for LARGE batches: the SSL counterpart of rsx_epl.hpp.
 //
-// Same path, same buffers, same arithmetic as task_step_kernel<SSL, 8, STATIC_DEFENDERS, 7, ...>
-// (reference: ssl/ssl_hw_challenge/static_defenders.py:90-322 around robosim.SSL.step, rsim.py:155,158),
-// other mapping: lane = env, a wave owns 64 envs and walks the 8 bodies of each one after the other.  The
+// Same path, same buffers, same arithmetic as task_step_kernel<SSL, 8, TASK, N, ...>
+// (reference: ssl/ssl_hw_challenge/{static_defenders,dribbling,contested_possession,pass_endurance}.py
+// around robosim.SSL.step, rsim.py:155,158); the task arithmetic itself (agent commands, observation,
+// reward / termination, placement) is the SAME code: ssl_agent_commands, write_obs_nb, task_reward and
+// place_env of rsx_kernels.hpp.  Other mapping: lane = env, a wave owns 64 envs and walks the 8 bodies of each one after the other.  The
 // 8-lane layout has no idle lane here, but its ball lane and robot lanes run different code one after
 // the other and every robot pair is tested from both sides; at scale that kernel is VALU-bound
 // (DESIGN.md 5).  Results are bit-identical: every body sums its partners in index order (robot-robot
 // pairs first, then the ball), the ball sums the robots' records in robot order, each side of a pair
 // evaluates its own response with the same expressions, draws use the same Philox counters
-// (tests/test_gpu_parity.py::test_ssl_env_per_lane_layout_is_bit_identical).
+// (tests/test_gpu_parity.py::test_env_per_lane_layout_is_bit_identical).
 //
-// What differs from the VSS kernel: holonomic actuation (only blue 0 is commanded: the six defenders
-// hold still unless they are hit), the kicker mouth / infrared / kick / dribbler of the robot-ball
+// What differs from the VSS kernel: holonomic actuation (only blue 0 is driven by the agent: the other
+// robots hold still unless they are hit; pass endurance keeps the receiver's dribbler on), the kicker mouth / infrared / kick / dribbler of the robot-ball
 // contact (evaluated only for robots whose centre is within 13 cm of the ball: a mouth or infrared
 // contact needs < 12.6 cm), the ball's flight, SSL walls, eleven state rows per robot (infrared and
 // four wheel speeds are outputs: written every step, read only when the step has no physics).
@@ -21,64 +24,79 @@
 
 namespace rsx {
 
-constexpr int SEPL_NR = 7;            // 1 blue + 6 yellow (static_defenders.py:47-48)
-constexpr int SEPL_NB = SEPL_NR + 1;  // + ball (body index SEPL_NR)
-constexpr int SEPL_OD = 24;
-constexpr int SEPL_PAIRS = SEPL_NR * (SEPL_NR - 1) / 2;   // 21 robot-robot pairs
-
+template <int N>
 struct SeplShared {
-    // contact sums (column = lane); also scratch for the poses of a reset placement.  Observations stay in
-    // registers and go out as six 16-byte stores per lane (see rsx_epl.hpp).
-    struct { float acc[4][SEPL_NB][64]; float accw[64]; } c;
+    // contact sums (column = lane); the same bytes are the pose scratch A[body][lane] of a reset placement
+    // (place_env).  Observations stay in registers and go out as vector stores (see rsx_epl.hpp).
+    union {
+        struct { float acc[4][N + 1][64]; float accw[64]; } c;
+        float4 A[(N + 1) * 64];
+    };
 };
 
-// SSLStaticDefenders observation of a 1v6 env into registers (static_defenders.py:90-112): the values of
-// write_obs<SSL, STATIC_DEFENDERS> with the team sizes known at compile time
-__device__ __forceinline__ void sepl_obs_ball(const Params& P, float* ob, float x, float y, float vx, float vy) {
-    using T = TC<RSX_TASK_SSL_STATIC_DEFENDERS>;
-    ob[0] = clampf(x * P.inv_max_pos, -1.2f, 1.2f); ob[1] = clampf(y * P.inv_max_pos, -1.2f, 1.2f);
-    ob[2] = clampf(vx * T::inv_max_v, -1.2f, 1.2f); ob[3] = clampf(vy * T::inv_max_v, -1.2f, 1.2f);
-}
-__device__ __forceinline__ void sepl_obs_robot(const Params& P, float* ob, const int k /* constant after unrolling */, float x,
-                                               float y, float vx, float vy, float sn, float cs, float om_deg, int ir) {
-    using T = TC<RSX_TASK_SSL_STATIC_DEFENDERS>;
-    if (k == 0) {   // the agent: 8 values
-        float* r = ob + 4;
-        r[0] = clampf(x * P.inv_max_pos, -1.2f, 1.2f); r[1] = clampf(y * P.inv_max_pos, -1.2f, 1.2f);
-        r[2] = sn; r[3] = cs;
-        r[4] = clampf(vx * T::inv_max_v, -1.2f, 1.2f); r[5] = clampf(vy * T::inv_max_v, -1.2f, 1.2f);
-        r[6] = clampf(om_deg * T::inv_max_w, -1.2f, 1.2f);
-        r[7] = ir ? 1.0f : 0.0f;
-    } else {        // a defender: position only
-        float* r = ob + 12 + 2 * (k - 1);
-        r[0] = clampf(x * P.inv_max_pos, -1.2f, 1.2f); r[1] = clampf(y * P.inv_max_pos, -1.2f, 1.2f);
+template <int TASK> struct SeplTask;   // robots, blue robots, observation width, robots that carry kicker / dribbler commands
+template <> struct SeplTask<RSX_TASK_SSL_STATIC_DEFENDERS> { static constexpr int N = 7, NBLUE = 1, OD = 24, NCMD = 1; };   // static_defenders.py:47-48
+template <> struct SeplTask<RSX_TASK_SSL_DRIBBLING> { static constexpr int N = 5, NBLUE = 1, OD = 21, NCMD = 1; };          // dribbling.py:45-46
+template <> struct SeplTask<RSX_TASK_SSL_CONTESTED> { static constexpr int N = 2, NBLUE = 1, OD = 14, NCMD = 1; };          // contested_possession.py:46-47
+template <> struct SeplTask<RSX_TASK_SSL_PASS_ENDURANCE> { static constexpr int N = 2, NBLUE = 2, OD = 16, NCMD = 2; };     // pass_endurance.py:45-46
+
+// one observation row from registers: the widest stores the row's alignment allows (rows are OD floats apart)
+template <int OD>
+__device__ __forceinline__ void sepl_store_row(float* dst, const float* ob) {
+    if (OD % 4 == 0) {
+        float4* d4 = reinterpret_cast<float4*>(dst);
+#pragma unroll
+        for (int i = 0; i < OD / 4; ++i) d4[i] = make_float4(ob[4 * i], ob[4 * i + 1], ob[4 * i + 2], ob[4 * i + 3]);
+    } else if (OD % 2 == 0) {
+        float2* d2 = reinterpret_cast<float2*>(dst);
+#pragma unroll
+        for (int i = 0; i < OD / 2; ++i) d2[i] = make_float2(ob[2 * i], ob[2 * i + 1]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < OD; ++i) dst[i] = ob[i];
     }
 }
-__device__ __forceinline__ void sepl_store_row(float* dst, const float* ob) {   // 24 floats = six 16-byte stores
-    float4* d4 = reinterpret_cast<float4*>(dst);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) d4[i] = make_float4(ob[4 * i], ob[4 * i + 1], ob[4 * i + 2], ob[4 * i + 3]);
-}
 
-// pair p -> (i, j), i < j < 7, lexicographic: rows of the upper triangle start at 0, 6, 11, 15, 18, 20
+// pair p -> (i, j), i < j < N, lexicographic: row r of the upper triangle starts at r*N - r*(r+1)/2
+template <int N>
 __device__ __forceinline__ void sepl_pair(int p, int& i, int& j) {
-    i = p >= 20 ? 5 : p >= 18 ? 4 : p >= 15 ? 3 : p >= 11 ? 2 : p >= 6 ? 1 : 0;
-    const int start = i == 0 ? 0 : i == 1 ? 6 : i == 2 ? 11 : i == 3 ? 15 : i == 4 ? 18 : 20;
+    i = 0;
+    int start = 0;
+#pragma unroll
+    for (int r = 1; r < N - 1; ++r) {
+        const int rs = r * N - r * (r + 1) / 2;
+        if (p >= rs) { i = r; start = rs; }
+    }
     j = i + 1 + (p - start);
 }
+// bits of the pair set that involve robot k
+template <int N>
+__host__ __device__ constexpr unsigned sepl_pair_mask(int k) {
+    unsigned m = 0;
+    int p = 0;
+    for (int i = 0; i < N; ++i)
+        for (int j = i + 1; j < N; ++j, ++p)
+            if (i == k || j == k) m |= 1u << p;
+    return m;
+}
+static_assert(sepl_pair_mask<7>(0) == 0x00003Fu && sepl_pair_mask<7>(3) == 0x038884u && sepl_pair_mask<7>(6) == 0x1A4420u, "pair masks");
 
-template <int MODE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 4)))
-void ssl_sd_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
-    constexpr int KIND = RSX_KIND_SSL, TASK = RSX_TASK_SSL_STATIC_DEFENDERS, N = SEPL_NR, RS = 11;
+// occupancy target: the 1v6 kernel holds 7 robots in registers (3-4 waves per SIMD measured best); the
+// smaller tasks fit the default budget
+template <int TASK, int MODE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TASK == RSX_TASK_SSL_STATIC_DEFENDERS ? 3 : 4, TASK == RSX_TASK_SSL_STATIC_DEFENDERS ? 4 : 8)))
+void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
+    constexpr int KIND = RSX_KIND_SSL, N = SeplTask<TASK>::N, NBLUE = SeplTask<TASK>::NBLUE, OD = SeplTask<TASK>::OD,
+                  NCMD = SeplTask<TASK>::NCMD, RS = 11, NB1 = N + 1;
+    constexpr bool HAS_TS = TASK == RSX_TASK_SSL_DRIBBLING || TASK == RSX_TASK_SSL_PASS_ENDURANCE;   // checkpoints_count / stopped_steps
     using K = KC<KIND>;
     using T = TC<TASK>;
-    constexpr int ID = T::info_dim;
+    constexpr int ID = T::info_dim, AD = T::act_dim;
     constexpr bool STEP = MODE == MODE_STEP;
     Params P = P_; P.num_envs = hp_num_envs; P.state_dim = hp_state_dim;
     Buffers bufs = bufs_; bufs.state = hp_state; bufs.aux = hp_aux; bufs.actions = hp_in; bufs.flags = hp_flags;
     const int n_steps = MODE == MODE_ROLLOUT ? hp_n_steps : 1;
-    __shared__ SeplShared sh;
+    __shared__ SeplShared<N> sh;
     const int lane = threadIdx.x;
     const int tile = tile_of_block(hp_per_xcd);
     const int e = tile * 64 + lane;
@@ -92,8 +110,8 @@ void ssl_sd_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
     Body r[N];
     Body ball = Body{};
     float wdeg[N], wheels[N][4];
-    float info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    float ep_ret = 0.0f;
+    float info[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float ep_ret = 0.0f, prev_pot = 0.0f;
     int steps = 0; uint32_t episode = 0;
     float raw[N][6], rawb[7] = {0, 0, 0, 0, 0, 0, 0};
     int ir_in[N];
@@ -117,6 +135,7 @@ void ssl_sd_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
 #pragma unroll
         for (int i = 0; i < ID; ++i) info[i] = auxe[(size_t)(ROW_INFO + i) * B];
         ep_ret = auxe[(size_t)ROW_EP_RET * B];
+        if (HAS_TS) prev_pot = auxe[(size_t)ROW_PREV_POT * B];
     }
     const bool counts_steps = blockIdx.x == 0 && lane == 0;   // metrics[0]: see task_step_kernel
     unsigned long long steps_before = 0;
@@ -125,7 +144,7 @@ void ssl_sd_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
     float act[5] = {0, 0, 0, 0, 0};
     if (fed && live) {
 #pragma unroll
-        for (int i = 0; i < 5; ++i) act[i] = bufs.actions[(size_t)e * 5 + i];
+        for (int i = 0; i < AD; ++i) act[i] = bufs.actions[(size_t)e * AD + i];
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): all loads land once, before the step loop
 #pragma unroll
@@ -148,32 +167,28 @@ void ssl_sd_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
         const uint32_t t = P.tick_base + (uint32_t)it;   // see task_step_kernel
         if (first_step) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) info[i] = 0.0f;
+            for (int i = 0; i < 10; ++i) info[i] = 0.0f;
             ep_ret = 0.0f;
         }
         const float last_bx = ball.x, last_by = ball.y;        // the reference's last_frame (pre-step)
         const float last_rx = r[0].x, last_ry = r[0].y;
+        const float obs_ts = prev_pot;   // the task scalar as this step's observation sees it
 
-        // ---- action -> commands: only blue 0 is driven (static_defenders.py:114-148) ----
+        // ---- action -> commands: only blue 0 is driven by the agent ----
         {
-            float a[5];
+            float a[5] = {0, 0, 0, 0, 0};
             const StepDraw dr = draw_for_step<KIND, TASK>(P, env_id, t, 0, true, fed);
 #pragma unroll
-            for (int i = 0; i < 5; ++i) a[i] = fed ? act[i] : dr.v[i];
+            for (int i = 0; i < AD; ++i) a[i] = fed ? act[i] : dr.v[i];
             float q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            float sn, cs;
-            sincos_f32(r[0].th * K::deg2rad, sn, cs);
-            float gx = a[0] * T::max_v, gy = a[1] * T::max_v, vth = a[2] * 10.0f;
-            float lx = gx * cs + gy * sn, ly = gy * cs - gx * sn;
-            float nrm = sqrtf(lx * lx + ly * ly);
-            if (!(nrm < T::max_v)) { float sc = T::max_v / nrm; lx = lx * sc; ly = ly * sc; }
-            q[1] = lx; q[2] = ly; q[3] = vth;
-            q[5] = a[3] > 0.0f ? 5.0f : 0.0f;
-            q[7] = a[4] > 0.0f ? 1.0f : 0.0f;
+            ssl_agent_commands<TASK>(a, r[0].th, q);
             robot_targets<KIND>(P, r[0], q);
-            const float zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int k = 1; k < N; ++k) robot_targets<KIND>(P, r[k], zero);
+            for (int k = 1; k < N; ++k) {
+                float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (TASK == RSX_TASK_SSL_PASS_ENDURANCE && k == 1) z[7] = 1.0f;   // receiver: dribbler on
+                robot_targets<KIND>(P, r[k], z);
+            }
         }
 
         // ---- physics: n_sub sub-steps, the whole env in registers ----
@@ -261,7 +276,7 @@ void ssl_sd_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
                 if (!__any((touching | near) != 0)) break;
                 const bool first = sweep == 0;
 #pragma unroll
-                for (int k = 0; k < SEPL_NB; ++k) {
+                for (int k = 0; k < NB1; ++k) {
                     sh.c.acc[0][k][lane] = 0.0f; sh.c.acc[1][k][lane] = 0.0f;
                     sh.c.acc[2][k][lane] = 0.0f; sh.c.acc[3][k][lane] = 0.0f;
                 }
@@ -274,7 +289,7 @@ void ssl_sd_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
                     const int p = __builtin_ctz(todo);
                     todo &= todo - 1;
                     int i, j;
-                    sepl_pair(p, i, j);
+                    sepl_pair<N>(p, i, j);
                     Body bi = Body{}, bj = Body{};
                     float wi = 0.0f, wj = 0.0f;
 #pragma unroll
@@ -310,7 +325,9 @@ void ssl_sd_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
 #pragma unroll
                     for (int q = 0; q < N; ++q)
                         if (k == q) { o.x = r[q].x; o.y = r[q].y; o.vx = r[q].vx; o.vy = r[q].vy; o.om = r[q].om; o.c = r[q].c; o.s = r[q].s; }
-                    if (k == 0) { kick_x = r[0].kick_x; kick_z = r[0].kick_z; drib = r[0].drib; }   // the defenders get zero commands
+#pragma unroll
+                    for (int q = 0; q < NCMD; ++q)   // the other robots get zero commands
+                        if (k == q) { kick_x = r[q].kick_x; kick_z = r[q].kick_z; drib = r[q].drib; }
                     float dx = ball.x - o.x, dy = ball.y - o.y;
                     float nx = 0.0f, ny = 0.0f, pen = -1.0f;
                     bool mouth = false, touch = false;
@@ -377,12 +394,10 @@ void ssl_sd_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
                     }
                 }
                 wave_sync();
-                // bits of `touching` that involve robot k (pairs in lexicographic order, see sepl_pair)
-                constexpr unsigned PM[SEPL_NR] = {0x00003Fu, 0x0007C1u, 0x007842u, 0x038884u, 0x0C9108u, 0x152210u, 0x1A4420u};
                 // only a body that touched something is updated (the others keep their bits)
 #pragma unroll
                 for (int k = 0; k < N; ++k) {
-                    if ((touching & PM[k]) | (rb_touch & (1u << k))) {
+                    if ((touching & sepl_pair_mask<N>(k)) | (rb_touch & (1u << k))) {   // pair bits that involve robot k
                         r[k].vx = r[k].vx + sh.c.acc[0][k][lane]; r[k].vy = r[k].vy + sh.c.acc[1][k][lane];
                         r[k].x = r[k].x + sh.c.acc[2][k][lane]; r[k].y = r[k].y + sh.c.acc[3][k][lane];
                     }
@@ -413,7 +428,7 @@ void ssl_sd_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
         }
 
         // ---- wire-format values, observation, reward ----
-        float ob[SEPL_OD];   // this env's observation, in registers
+        float ob[OD];   // this env's observation, in registers
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             const float wd = r[k].om * K::rad2deg;
@@ -421,32 +436,25 @@ void ssl_sd_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
             wheel_speeds<KIND>(P, r[k], wheels[k]);   // from the carried (c, s) and the unrounded rate, like the other layout
             r[k].om = wd * K::deg2rad;
             sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
-            sepl_obs_robot(P, ob, k, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, wd, r[k].ir);
+            write_obs_nb<KIND, TASK>(P, ob, k, NBLUE, true, false, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, wd, r[k].ir, obs_ts);
         }
         ball.z = (K::r_ball + ball.z) - K::r_ball;
-        sepl_obs_ball(P, ob, ball.x, ball.y, ball.vx, ball.vy);
-        bool success = false;
-        {   // static_defenders.py:150-212,256-322
-            reward = 0.0f; term = 0;
-            const float bx = ball.x, by = ball.y, rx = r[0].x, ry = r[0].y;
-            if (rx < -0.2f || fabsf(ry) > P.half_wid) { term = 1; info[4] += 1.0f; }
-            else if (rx > P.pen_x && fabsf(ry) < P.half_pen_wid) { term = 1; info[1] += 1.0f; }
-            else if (bx < 0.0f || fabsf(by) > P.half_wid) { term = 1; info[2] += 1.0f; }
-            else if (bx > P.half_len) {
-                term = 1;
-                if (fabsf(by) < P.ghw) { reward = 5.0f; info[0] += 1.0f; }
-                else info[3] += 1.0f;
-            } else {
-                float ldx = last_rx - last_bx, ldy = last_ry - last_by;
-                float cdx = rx - bx, cdy = ry - by;
-                float bd = clampf(sqrtf(ldx * ldx + ldy * ldy) - sqrtf(cdx * cdx + cdy * cdy), -1.0f, 1.0f) * P.inv_bd_scale;
-                float lgx = P.half_len - last_bx, cgx = P.half_len - bx;
-                float bg = clampf(sqrtf(lgx * lgx + last_by * last_by) - sqrtf(cgx * cgx + by * by), -1.0f, 1.0f) * P.inv_bg_scale;
-                float en = -(((fabsf(wheels[0][0]) + fabsf(wheels[0][1])) + fabsf(wheels[0][2])) + fabsf(wheels[0][3])) * T::inv_en_scale;
-                info[5] += bd; info[6] += bg; info[7] += en;
-                reward = (bd + bg) + en;
+        write_obs_nb<KIND, TASK>(P, ob, N, NBLUE, false, true, ball.x, ball.y, ball.vx, ball.vy, 0.0f, 0.0f, 0.0f, 0, obs_ts);
+        bool success = false, against = false;
+        {   // what the reward needs from the robots, in the slots task_step_kernel uses
+            float xr[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            xr[0] = r[0].x; xr[1] = r[0].y;
+            if (TASK == RSX_TASK_SSL_STATIC_DEFENDERS || TASK == RSX_TASK_SSL_CONTESTED) {
+                xr[6] = last_rx; xr[7] = last_ry;
+                xr[8] = wheels[0][0]; xr[9] = wheels[0][1]; xr[10] = wheels[0][2]; xr[11] = wheels[0][3];
             }
-            success = info[0] > 0.0f;
+#pragma unroll
+            for (int k = 1; k < N; ++k) {
+                if (TASK == RSX_TASK_SSL_DRIBBLING) xr[1 + k] = (fabsf(r[k].vx) > 0.05f || fabsf(r[k].vy) > 0.05f) ? 1.0f : 0.0f;
+                if (TASK == RSX_TASK_SSL_CONTESTED && k == 1) xr[2] = (fabsf(r[k].vx) > 0.1f || fabsf(r[k].vy) > 0.1f) ? 1.0f : 0.0f;
+                if (TASK == RSX_TASK_SSL_PASS_ENDURANCE && k == 1) { xr[2] = r[k].x; xr[3] = r[k].y; xr[4] = r[k].ir ? 1.0f : 0.0f; }
+            }
+            task_reward<KIND, TASK>(P, xr, ball.x, ball.y, last_bx, last_by, first_step, prev_pot, info, reward, term, success, against);
             ep_ret = ep_ret + reward;
         }
         steps += 1;
@@ -462,68 +470,41 @@ void ssl_sd_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
         // ---- episode end: same-step auto-reset, one lane = one env ----
         if (__any(ended)) {
             if (ended) {
-                sepl_store_row(bufs.final_obs + (size_t)e * SEPL_OD, ob);   // terminal observation
+                sepl_store_row<OD>(bufs.final_obs + (size_t)e * OD, ob);   // terminal observation
                 episode += 1;
-                atomicAdd(&bufs.metrics[1], 1ull);
-                if (success) atomicAdd(&bufs.metrics[2], 1ull);
-                atomicAdd(&bufs.metrics[4], (unsigned long long)__float2ll_rn(ep_ret * 1048576.0f));
-                atomicAdd(&bufs.metrics[5], (unsigned long long)steps);
-                if (trunc && !term) atomicAdd(&bufs.metrics[6], 1ull);
-                // placement: static_defenders.py:214-254 (sequential rejection sampling, Philox draws)
-                uint32_t n = 0;
-                auto draw = [&]() -> float2 {
-                    const u32x4 u = philox4x32(env_id, episode, n++, DOM_PLACE, P.key0, P.key1);
-                    return make_float2(u01(u.x), u01(u.y));
-                };
-                float bx = 0.0f, by = 0.0f;
-                for (int tt = 0; tt < 64; ++tt) {
-                    const float2 u = draw();
-                    bx = P.pl_xlo + P.pl_xspan * u.x;
-                    by = P.pl_ylo + P.pl_yspan * u.y;
-                    if (!(bx > P.pen_x && fabsf(by) < P.half_pen_wid)) break;
-                }
-                // scratch for the poses placed so far: this lane's column of the (now idle) contact sums
-                float* const px = &sh.c.acc[0][0][lane], * const py = &sh.c.acc[1][0][lane], * const pth = &sh.c.acc[2][0][lane];
-                px[0] = 0.0f; py[0] = 0.0f; pth[0] = 0.0f;   // blue 0 at the origin
-                for (int k = 1; k < N; ++k) {
-                    float x = 0.0f, y = 0.0f;
-                    for (int tt = 0; tt < 64; ++tt) {
-                        const float2 u = draw();
-                        x = P.pl_xlo + P.pl_xspan * u.x;
-                        y = P.pl_ylo + P.pl_yspan * u.y;
-                        bool ok = true;
-                        { float dx = x - bx, dy = y - by; if (dx * dx + dy * dy < P.pl_min_d2) ok = false; }
-                        for (int q = 0; q < k; ++q) {
-                            float dx = x - px[q * 64], dy = y - py[q * 64];
-                            if (dx * dx + dy * dy < P.pl_min_d2) ok = false;
-                        }
-                        if (ok) break;
-                    }
-                    const float2 u = draw();
-                    px[k * 64] = x; py[k * 64] = y; pth[k * 64] = 360.0f * u.x;
-                }
+                unsigned long long* const ms = metric_slot(bufs);
+                atomicAdd(&ms[1], 1ull);
+                if (success) atomicAdd(&ms[2], 1ull);
+                atomicAdd(&ms[4], (unsigned long long)__float2ll_rn(ep_ret * 1048576.0f));
+                atomicAdd(&ms[5], (unsigned long long)steps);
+                if (trunc && !term) atomicAdd(&ms[6], 1ull);
+                // placement: the task's reset (place_env: sequential, Philox draws), poses through this lane's
+                // column of the (now idle) contact sums
+                place_env<TASK, 1, false>(P, N, env_id, episode, lane, sh.A, nullptr);
                 steps = 0;
-                float nx[N], ny[N], nth[N];
+                if (HAS_TS) prev_pot = 0.0f;
+                float4 np[NB1];
 #pragma unroll
-                for (int k = 0; k < N; ++k) { nx[k] = px[k * 64]; ny[k] = py[k * 64]; nth[k] = pth[k * 64]; }
+                for (int k = 0; k < NB1; ++k) np[k] = sh.A[k * 64 + lane];
+                wave_sync();   // the scratch is the contact sums again from here on
 #pragma unroll
                 for (int k = 0; k < N; ++k) {
                     r[k] = Body{};
-                    r[k].x = nx[k]; r[k].y = ny[k];
-                    r[k].th = nth[k];
+                    r[k].x = np[k].x; r[k].y = np[k].y;
+                    r[k].th = np[k].z;
                     wdeg[k] = 0.0f;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) wheels[k][i] = 0.0f;
                     sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
-                    sepl_obs_robot(P, ob, k, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, 0.0f, 0);
+                    write_obs_nb<KIND, TASK>(P, ob, k, NBLUE, true, false, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, 0.0f, 0, 0.0f);
                 }
                 ball = Body{};
-                ball.x = bx; ball.y = by;
-                sepl_obs_ball(P, ob, ball.x, ball.y, ball.vx, ball.vy);
+                ball.x = np[N].x; ball.y = np[N].y;
+                write_obs_nb<KIND, TASK>(P, ob, N, NBLUE, false, true, ball.x, ball.y, ball.vx, ball.vy, 0.0f, 0.0f, 0.0f, 0, 0.0f);
             }
         }
-        // ---- observation out: this lane's row, six 16-byte stores ----
-        if (live) sepl_store_row(bufs.obs + (size_t)e * SEPL_OD, ob);
+        // ---- observation out: this lane's row ----
+        if (live) sepl_store_row<OD>(bufs.obs + (size_t)e * OD, ob);
     }
 
     // ---- store (wire format: degrees, deg/s, infrared, wheel speeds) ----
@@ -542,6 +523,7 @@ void ssl_sd_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
         auxe[(size_t)ROW_STEPS * B] = __int_as_float(steps);
         auxe[(size_t)ROW_EPISODE * B] = __uint_as_float(episode);
         auxe[(size_t)ROW_EP_RET * B] = ep_ret;
+        if (HAS_TS) auxe[(size_t)ROW_PREV_POT * B] = prev_pot;
     }
     if (counts_steps) bufs.metrics[0] = steps_before + (unsigned long long)P.num_envs * (unsigned long long)n_steps;
 }

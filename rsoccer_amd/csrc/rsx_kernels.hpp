@@ -60,6 +60,7 @@ struct Buffers {
     const float* cmds;     // [N*C][B]        (raw simulator path)
     const float* actions;  // [B][act_dim] or nullptr = random
     unsigned long long* metrics;  // [RSX_METRICS]
+    unsigned long long* mslots;   // [MSLOTS][RSX_METRICS]: per-block-group partial sums of the episode counters (see metric_slot)
     // MODE_SERVE (persistent kernel): doorbell written by the caller's stream, completion counter read by it
     unsigned long long* serve_seq;   // step number requested so far; bit 63 = stop
     unsigned long long* serve_done;  // += 1 per wave and step served
@@ -818,14 +819,26 @@ __global__ __launch_bounds__(64) void sim_step_kernel(RSX_HOT_ARGS, const Params
 // fused task step
 // =============================================================================================
 
+// Episode counters (metrics[1..6]) are summed with atomics.  Device-scope atomics on ONE cache line
+// serialise at about 8 ns each, whatever wave issues them: with a reset in most waves of a 10^6-env launch
+// (pass endurance, contested possession) that was the whole step time (605 us instead of 82 us).  The step
+// kernels therefore add into one of MSLOTS 64-byte lines, picked by block id, and fold_metrics_kernel
+// (rsx_read_metrics / rsx_metrics_fold) adds the lines into metrics[] and clears them.
+constexpr int MSLOTS = 256;
+__device__ __forceinline__ unsigned long long* metric_slot(const Buffers& b) {
+    return b.mslots + (size_t)(blockIdx.x & (MSLOTS - 1)) * RSX_METRICS;
+}
+
 // observation entries owned by this lane -> staging row of its env; values are the WIRE-format
 // state.  Layouts: vss_gym.py:93-117, static_defenders.py:90-112, dribbling.py:76-104,
 // contested_possession.py:78-104, pass_endurance.py:77-91.
+// nb = blue robots (run-time for the lanes kernels, a constant for the one-lane-per-env kernels, whose
+// "row" is a register array)
 template <int KIND, int TASK>
-__device__ __forceinline__ void write_obs(const Params& P, float* __restrict__ row, int b,
-                                          bool is_robot, bool is_ball, float x, float y, float vx,
-                                          float vy, float sn, float cs, float om_deg, int ir,
-                                          float tscalar) {
+__device__ __forceinline__ void write_obs_nb(const Params& P, float* __restrict__ row, int b, const int nb,
+                                             bool is_robot, bool is_ball, float x, float y, float vx,
+                                             float vy, float sn, float cs, float om_deg, int ir,
+                                             float tscalar) {
     // sn / cs = sin / cos of (theta_deg * deg2rad), i.e. of the wire-format heading
     using T = TC<TASK>;
     const float lo = -1.2f, hi = 1.2f;
@@ -847,7 +860,7 @@ __device__ __forceinline__ void write_obs(const Params& P, float* __restrict__ r
         row[OFF + 2] = clampf(vx * T::inv_max_v, lo, hi);
         row[OFF + 3] = clampf(vy * T::inv_max_v, lo, hi);
     } else if (is_robot) {
-        if (b < P.n_blue) {
+        if (b < nb) {
             float* r = row + OFF + 4 + WB * b;
             r[0] = clampf(x * P.inv_max_pos, lo, hi);
             r[1] = clampf(y * P.inv_max_pos, lo, hi);
@@ -863,7 +876,7 @@ __device__ __forceinline__ void write_obs(const Params& P, float* __restrict__ r
                 else if (TASK != RSX_TASK_VSS_V0) r[7] = ir ? 1.0f : 0.0f;
             }
         } else {
-            float* r = row + OFF + 4 + WB * P.n_blue + WY * (b - P.n_blue);
+            float* r = row + OFF + 4 + WB * nb + WY * (b - nb);
             r[0] = clampf(x * P.inv_max_pos, lo, hi);
             r[1] = clampf(y * P.inv_max_pos, lo, hi);
             if (TASK == RSX_TASK_VSS_V0) {
@@ -873,6 +886,14 @@ __device__ __forceinline__ void write_obs(const Params& P, float* __restrict__ r
             }
         }
     }
+}
+
+template <int KIND, int TASK>
+__device__ __forceinline__ void write_obs(const Params& P, float* __restrict__ row, int b,
+                                          bool is_robot, bool is_ball, float x, float y, float vx,
+                                          float vy, float sn, float cs, float om_deg, int ir,
+                                          float tscalar) {
+    write_obs_nb<KIND, TASK>(P, row, b, P.n_blue, is_robot, is_ball, x, y, vx, vy, sn, cs, om_deg, ir, tscalar);
 }
 
 // Return of a finished VSS-v0 episode, from its cumulative reward terms (vss_gym.py:151-158,186-190):
@@ -889,6 +910,139 @@ __device__ __forceinline__ float vss_wheel(float a) {
     v = clampf(v, -T::max_v, T::max_v);
     if (-T::deadzone < v && v < T::deadzone) v = 0.0f;
     return v * K::inv_rw;
+}
+
+// Action of the agent (blue 0) of an SSL task -> its robot command q (robosim order: wheel speeds flag,
+// v_x, v_y, v_theta, kick_x, kick_z is q[5]..., dribbler q[7]); od = the robot's heading in degrees.
+template <int TASK>
+__device__ __forceinline__ void ssl_agent_commands(const float* a, float od, float* q) {
+    using K = KC<RSX_KIND_SSL>;
+    using T = TC<TASK>;
+    if (TASK == RSX_TASK_SSL_PASS_ENDURANCE) {  // pass_endurance.py:106-130
+        float k = fabsf(a[1]) > 0.5f ? a[1] : 0.0f;
+        q[3] = a[0] * 10.0f;
+        q[5] = k * 5.0f;
+        q[7] = a[2] > 0.0f ? 1.0f : 0.0f;
+    } else {  // static_defenders.py:114-148, dribbling.py:106-135, contested_possession.py:106-137
+        float sn, cs;
+        sincos_f32(od * K::deg2rad, sn, cs);
+        float gx = a[0] * T::max_v, gy = a[1] * T::max_v, vth = a[2] * 10.0f;
+        float lx = gx * cs + gy * sn, ly = gy * cs - gx * sn;
+        float nrm = sqrtf(lx * lx + ly * ly);
+        if (!(nrm < T::max_v)) { float sc = T::max_v / nrm; lx = lx * sc; ly = ly * sc; }
+        q[1] = lx; q[2] = ly; q[3] = vth;
+        if (TASK == RSX_TASK_SSL_DRIBBLING) {
+            q[7] = a[3] > 0.0f ? 1.0f : 0.0f;
+        } else {
+            q[5] = a[3] > 0.0f ? 5.0f : 0.0f;
+            q[7] = a[4] > 0.0f ? 1.0f : 0.0f;
+        }
+    }
+}
+
+// Reward, termination and info terms of one env step, from the post-step ball position (bx, by), the
+// pre-step one (lastx, lasty) and xr[] = what the task needs from the robots (filled by the caller: see
+// task_step_kernel).  One body for both tile layouts, so their arithmetic cannot drift apart.
+template <int KIND, int TASK>
+__device__ __forceinline__ void task_reward(const Params& P, const float* xr, const float bx, const float by,
+                                            const float lastx, const float lasty, const bool first_step,
+                                            float& prev_pot, float* info, float& reward, int& term,
+                                            bool& success, bool& against) {
+    using T = TC<TASK>;
+    reward = 0.0f; term = 0;
+    if (TASK == RSX_TASK_VSS_V0) {  // vss_gym.py:144-192,256-311
+        if (bx > P.half_len) { info[0] += 1.0f; info[4] += 1.0f; reward = 10.0f; term = 1; }
+        else if (bx < -P.half_len) { info[0] -= 1.0f; info[5] += 1.0f; reward = -10.0f; term = 1; }
+        else {
+            float dx_d = (P.hl_goal + bx) * 100.0f, dx_a = (P.hl_goal - bx) * 100.0f, dy = by * 100.0f;
+            float dy2 = 2.0f * (dy * dy);
+            float dist_1 = -sqrtf(dx_a * dx_a + dy2), dist_2 = sqrtf(dx_d * dx_d + dy2);
+            float pot = ((dist_1 + dist_2) * P.inv_len_cm - 1.0f) * 0.5f;
+            float grad = 0.0f;
+            if (!first_step) grad = clampf((pot - prev_pot) * 3.0f * P.inv_dt, -5.0f, 5.0f);
+            prev_pot = pot;
+            float rbx = bx - xr[0], rby = by - xr[1];
+            float nrm = sqrtf(rbx * rbx + rby * rby);
+            float mv = nrm > 0.0f ? (rbx / nrm) * xr[2] + (rby / nrm) * xr[3] : 0.0f;   // unguarded in vss_gym.py:298
+            float move = clampf(mv * 2.5f, -5.0f, 5.0f);
+            float energy = -(fabsf(xr[4]) + fabsf(xr[5]));
+            float t_move = 0.2f * move, t_grad = 0.8f * grad, t_en = 2e-4f * energy;
+            reward = (t_move + t_grad) + t_en;
+            info[1] += t_move; info[2] += t_grad; info[3] += t_en;
+        }
+    } else if (TASK == RSX_TASK_SSL_SCRIMMAGE) {  // README.md:96-102 style: a goal ends the episode
+        if (bx > P.half_len && fabsf(by) < P.ghw) { reward = 1.0f; term = 1; info[0] += 1.0f; }
+        else if (bx < -P.half_len && fabsf(by) < P.ghw) { reward = -1.0f; term = 1; info[1] += 1.0f; }
+        success = info[0] > 0.0f; against = info[1] > 0.0f;
+    } else if (TASK == RSX_TASK_SSL_DRIBBLING) {  // dribbling.py:137-185; prev_pot = checkpoints_count
+        const float rx = xr[0], ry = xr[1];
+        if (xr[2] != 0.0f || xr[3] != 0.0f || xr[4] != 0.0f || xr[5] != 0.0f) term = 1;  // an obstacle was hit
+        if (rx < -3.0f || rx > 1.0f || fabsf(ry) > 1.0f) term = 1;                         // left the course
+        else {
+            const int n = (int)prev_pot;
+            const bool down = lasty >= 0.0f && by < 0.0f, up = lasty < 0.0f && by >= 0.0f;
+            bool passed;
+            if (n == 0) passed = bx < -0.5f && bx > -1.0f && down;
+            else if (n == 1) passed = bx < -1.0f && bx > -1.5f && up;
+            else if (n % 2 == 0) {
+                const bool inside = bx < -1.5f && bx > -2.0f;
+                passed = inside && down;
+                if (inside && !down && up) term = 1;   // reversed the last checkpoint
+            } else passed = bx > -3.0f && bx < -2.0f && up;
+            if (passed) {
+                reward = 1.0f;
+                prev_pot = (float)(n + 1);
+                if (n >= 2 && n % 2 == 0 && n + 1 == 7) term = 1;   // course completed
+            }
+        }
+        info[0] = prev_pot;
+        success = prev_pot >= 7.0f;
+    } else if (TASK == RSX_TASK_SSL_PASS_ENDURANCE) {  // pass_endurance.py:132-154,187-233; prev_pot = stopped_steps
+        const float shx = xr[0], shy = xr[1], rcx = xr[2], rcy = xr[3];
+        const bool rc_ir = xr[4] != 0.0f;
+        float ddx = rcx - bx, ddy = rcy - by, ldx = rcx - lastx, ldy = rcy - lasty;
+        float dist = sqrtf(ddx * ddx + ddy * ddy), last_dist = sqrtf(ldx * ldx + ldy * ldy);
+        if (rc_ir) { reward = 1.0f; term = 1; }
+        else {
+            float gr = P.inv_bg_scale * clampf(last_dist - dist, -1.0f, 1.0f);
+            reward = gr; info[1] += gr;
+        }
+        // "wrong ball": outside the shooter-receiver box on a centimetre grid, or stalled
+        const int cbx = (int)(bx * 100.0f), cby = (int)(by * 100.0f);
+        const int csx = (int)(shx * 100.0f), csy = (int)(shy * 100.0f);
+        const int crx = (int)(rcx * 100.0f), cry = (int)(rcy * 100.0f);
+        const bool in_x = min(crx, csx) <= cbx && cbx <= max(crx, csx);
+        const bool in_y = min(cry, csy) <= cby && cby <= max(cry, csy);
+        if (fabsf(last_dist - dist) < 0.01f) prev_pot = prev_pot + 1.0f; else prev_pot = 0.0f;
+        if (prev_pot > 20.0f || !(in_x && in_y)) { reward = reward - 1.0f; term = 1; }
+        if (term) {
+            float rdx = rcx - shx, rdy = rcy - shy;
+            float dist_robs = sqrtf(rdx * rdx + rdy * rdy);
+            info[0] = dist_robs > 0.0f ? (dist_robs - dist) / dist_robs : 0.0f;
+        }
+        success = term && rc_ir;
+    } else {  // static_defenders.py:150-212,256-322; contested_possession.py:139-201
+        const float rx = xr[0], ry = xr[1];
+        if (TASK == RSX_TASK_SSL_CONTESTED && xr[2] != 0.0f) { info[8] += 1.0f; term = 1; }  // opponent moved
+        if (rx < -0.2f || fabsf(ry) > P.half_wid) { term = 1; info[4] += 1.0f; }
+        else if (rx > P.pen_x && fabsf(ry) < P.half_pen_wid) { term = 1; info[1] += 1.0f; }
+        else if (bx < 0.0f || fabsf(by) > P.half_wid) { term = 1; info[2] += 1.0f; }
+        else if (bx > P.half_len) {
+            term = 1;
+            if (fabsf(by) < P.ghw) { reward = 5.0f; info[0] += 1.0f; }
+            else info[3] += 1.0f;
+        } else {
+            float ldx = xr[6] - lastx, ldy = xr[7] - lasty;
+            float cdx = rx - bx, cdy = ry - by;
+            float bd = clampf(sqrtf(ldx * ldx + ldy * ldy) - sqrtf(cdx * cdx + cdy * cdy), -1.0f, 1.0f) * P.inv_bd_scale;
+            float lgx = P.half_len - lastx, cgx = P.half_len - bx;
+            float bg = clampf(sqrtf(lgx * lgx + lasty * lasty) - sqrtf(cgx * cgx + by * by), -1.0f, 1.0f) * P.inv_bg_scale;
+            float en = -(((fabsf(xr[8]) + fabsf(xr[9])) + fabsf(xr[10])) + fabsf(xr[11])) * T::inv_en_scale;
+            info[5] += bd; info[6] += bg; info[7] += en;
+            reward = (bd + bg) + en;
+        }
+        success = info[0] > 0.0f;
+    }
 }
 
 // Random placement of one env (vss_gym.py:194-233 / static_defenders.py:214-254 with Philox
@@ -918,11 +1072,11 @@ __device__ __forceinline__ void place_predraw(const Params& P, uint32_t env_id, 
     }
 }
 
-template <int TASK, int L>
+template <int TASK, int L, bool PRE = true>
 __device__ __forceinline__ void place_env(const Params& P, const int N, uint32_t env_id,
                                           uint32_t episode, int g, float4* A, const float2* draws) {
     constexpr int G = 64 / L;
-    constexpr int NPRE = predraw_count<TASK, L>();
+    constexpr int NPRE = PRE ? predraw_count<TASK, L>() : 0;   // !PRE: every draw is computed where it is used
     uint32_t n = 0;
     auto draw = [&]() -> float2 {
         const uint32_t i = n++;
@@ -1371,26 +1525,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
                     float a[5] = {0, 0, 0, 0, 0};
 #pragma unroll
                     for (int i = 0; i < AD; ++i) a[i] = fed ? act[i] : dr.v[i];
-                    if (TASK == RSX_TASK_SSL_PASS_ENDURANCE) {  // pass_endurance.py:106-130
-                        float k = fabsf(a[1]) > 0.5f ? a[1] : 0.0f;
-                        q[3] = a[0] * 10.0f;
-                        q[5] = k * 5.0f;
-                        q[7] = a[2] > 0.0f ? 1.0f : 0.0f;
-                    } else {  // static_defenders.py:114-148, dribbling.py:106-135, contested_possession.py:106-137
-                        float sn, cs;
-                        sincos_f32(od * K::deg2rad, sn, cs);
-                        float gx = a[0] * T::max_v, gy = a[1] * T::max_v, vth = a[2] * 10.0f;
-                        float lx = gx * cs + gy * sn, ly = gy * cs - gx * sn;
-                        float nrm = sqrtf(lx * lx + ly * ly);
-                        if (!(nrm < T::max_v)) { float sc = T::max_v / nrm; lx = lx * sc; ly = ly * sc; }
-                        q[1] = lx; q[2] = ly; q[3] = vth;
-                        if (TASK == RSX_TASK_SSL_DRIBBLING) {
-                            q[7] = a[3] > 0.0f ? 1.0f : 0.0f;
-                        } else {
-                            q[5] = a[3] > 0.0f ? 5.0f : 0.0f;
-                            q[7] = a[4] > 0.0f ? 1.0f : 0.0f;
-                        }
-                    }
+                    ssl_agent_commands<TASK>(a, od, q);
                 }
                 if (TASK == RSX_TASK_SSL_PASS_ENDURANCE && is_robot && b == 1) q[7] = 1.0f;  // receiver: dribbler on
             }
@@ -1433,101 +1568,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
             wave_sync();
             if (is_ball) {
                 const float* xr = sh.x0[g];
-                reward = 0.0f; term = 0;
-                const float bx = o.x, by = o.y;
-                if (TASK == RSX_TASK_VSS_V0) {  // vss_gym.py:144-192,256-311
-                    if (bx > P.half_len) { info[0] += 1.0f; info[4] += 1.0f; reward = 10.0f; term = 1; }
-                    else if (bx < -P.half_len) { info[0] -= 1.0f; info[5] += 1.0f; reward = -10.0f; term = 1; }
-                    else {
-                        float dx_d = (P.hl_goal + bx) * 100.0f, dx_a = (P.hl_goal - bx) * 100.0f, dy = by * 100.0f;
-                        float dy2 = 2.0f * (dy * dy);
-                        float dist_1 = -sqrtf(dx_a * dx_a + dy2), dist_2 = sqrtf(dx_d * dx_d + dy2);
-                        float pot = ((dist_1 + dist_2) * P.inv_len_cm - 1.0f) * 0.5f;
-                        float grad = 0.0f;
-                        if (!first_step) grad = clampf((pot - prev_pot) * 3.0f * P.inv_dt, -5.0f, 5.0f);
-                        prev_pot = pot;
-                        float rbx = bx - xr[0], rby = by - xr[1];
-                        float nrm = sqrtf(rbx * rbx + rby * rby);
-                        float mv = nrm > 0.0f ? (rbx / nrm) * xr[2] + (rby / nrm) * xr[3] : 0.0f;   // unguarded in vss_gym.py:298
-                        float move = clampf(mv * 2.5f, -5.0f, 5.0f);
-                        float energy = -(fabsf(xr[4]) + fabsf(xr[5]));
-                        float t_move = 0.2f * move, t_grad = 0.8f * grad, t_en = 2e-4f * energy;
-                        reward = (t_move + t_grad) + t_en;
-                        info[1] += t_move; info[2] += t_grad; info[3] += t_en;
-                    }
-                } else if (TASK == RSX_TASK_SSL_SCRIMMAGE) {  // README.md:96-102 style: a goal ends the episode
-                    if (bx > P.half_len && fabsf(by) < P.ghw) { reward = 1.0f; term = 1; info[0] += 1.0f; }
-                    else if (bx < -P.half_len && fabsf(by) < P.ghw) { reward = -1.0f; term = 1; info[1] += 1.0f; }
-                    success = info[0] > 0.0f; against = info[1] > 0.0f;
-                } else if (TASK == RSX_TASK_SSL_DRIBBLING) {  // dribbling.py:137-185; prev_pot = checkpoints_count
-                    const float rx = xr[0], ry = xr[1];
-                    if (xr[2] != 0.0f || xr[3] != 0.0f || xr[4] != 0.0f || xr[5] != 0.0f) term = 1;  // an obstacle was hit
-                    if (rx < -3.0f || rx > 1.0f || fabsf(ry) > 1.0f) term = 1;                         // left the course
-                    else {
-                        const int n = (int)prev_pot;
-                        const bool down = lasty >= 0.0f && by < 0.0f, up = lasty < 0.0f && by >= 0.0f;
-                        bool passed;
-                        if (n == 0) passed = bx < -0.5f && bx > -1.0f && down;
-                        else if (n == 1) passed = bx < -1.0f && bx > -1.5f && up;
-                        else if (n % 2 == 0) {
-                            const bool inside = bx < -1.5f && bx > -2.0f;
-                            passed = inside && down;
-                            if (inside && !down && up) term = 1;   // reversed the last checkpoint
-                        } else passed = bx > -3.0f && bx < -2.0f && up;
-                        if (passed) {
-                            reward = 1.0f;
-                            prev_pot = (float)(n + 1);
-                            if (n >= 2 && n % 2 == 0 && n + 1 == 7) term = 1;   // course completed
-                        }
-                    }
-                    info[0] = prev_pot;
-                    success = prev_pot >= 7.0f;
-                } else if (TASK == RSX_TASK_SSL_PASS_ENDURANCE) {  // pass_endurance.py:132-154,187-233; prev_pot = stopped_steps
-                    const float shx = xr[0], shy = xr[1], rcx = xr[2], rcy = xr[3];
-                    const bool rc_ir = xr[4] != 0.0f;
-                    float ddx = rcx - bx, ddy = rcy - by, ldx = rcx - lastx, ldy = rcy - lasty;
-                    float dist = sqrtf(ddx * ddx + ddy * ddy), last_dist = sqrtf(ldx * ldx + ldy * ldy);
-                    if (rc_ir) { reward = 1.0f; term = 1; }
-                    else {
-                        float gr = P.inv_bg_scale * clampf(last_dist - dist, -1.0f, 1.0f);
-                        reward = gr; info[1] += gr;
-                    }
-                    // "wrong ball": outside the shooter-receiver box on a centimetre grid, or stalled
-                    const int cbx = (int)(bx * 100.0f), cby = (int)(by * 100.0f);
-                    const int csx = (int)(shx * 100.0f), csy = (int)(shy * 100.0f);
-                    const int crx = (int)(rcx * 100.0f), cry = (int)(rcy * 100.0f);
-                    const bool in_x = min(crx, csx) <= cbx && cbx <= max(crx, csx);
-                    const bool in_y = min(cry, csy) <= cby && cby <= max(cry, csy);
-                    if (fabsf(last_dist - dist) < 0.01f) prev_pot = prev_pot + 1.0f; else prev_pot = 0.0f;
-                    if (prev_pot > 20.0f || !(in_x && in_y)) { reward = reward - 1.0f; term = 1; }
-                    if (term) {
-                        float rdx = rcx - shx, rdy = rcy - shy;
-                        float dist_robs = sqrtf(rdx * rdx + rdy * rdy);
-                        info[0] = dist_robs > 0.0f ? (dist_robs - dist) / dist_robs : 0.0f;
-                    }
-                    success = term && rc_ir;
-                } else {  // static_defenders.py:150-212,256-322; contested_possession.py:139-201
-                    const float rx = xr[0], ry = xr[1];
-                    if (TASK == RSX_TASK_SSL_CONTESTED && xr[2] != 0.0f) { info[8] += 1.0f; term = 1; }  // opponent moved
-                    if (rx < -0.2f || fabsf(ry) > P.half_wid) { term = 1; info[4] += 1.0f; }
-                    else if (rx > P.pen_x && fabsf(ry) < P.half_pen_wid) { term = 1; info[1] += 1.0f; }
-                    else if (bx < 0.0f || fabsf(by) > P.half_wid) { term = 1; info[2] += 1.0f; }
-                    else if (bx > P.half_len) {
-                        term = 1;
-                        if (fabsf(by) < P.ghw) { reward = 5.0f; info[0] += 1.0f; }
-                        else info[3] += 1.0f;
-                    } else {
-                        float ldx = xr[6] - lastx, ldy = xr[7] - lasty;
-                        float cdx = rx - bx, cdy = ry - by;
-                        float bd = clampf(sqrtf(ldx * ldx + ldy * ldy) - sqrtf(cdx * cdx + cdy * cdy), -1.0f, 1.0f) * P.inv_bd_scale;
-                        float lgx = P.half_len - lastx, cgx = P.half_len - bx;
-                        float bg = clampf(sqrtf(lgx * lgx + lasty * lasty) - sqrtf(cgx * cgx + by * by), -1.0f, 1.0f) * P.inv_bg_scale;
-                        float en = -(((fabsf(xr[8]) + fabsf(xr[9])) + fabsf(xr[10])) + fabsf(xr[11])) * T::inv_en_scale;
-                        info[5] += bd; info[6] += bg; info[7] += en;
-                        reward = (bd + bg) + en;
-                    }
-                    success = info[0] > 0.0f;
-                }
+                task_reward<KIND, TASK>(P, xr, o.x, o.y, lastx, lasty, first_step, prev_pot, info, reward, term, success, against);
                 ep_ret = ep_ret + reward;
             }
             steps += 1;
@@ -1557,12 +1598,13 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
             if (ended && mode == 0) episode += 1;   // every lane of the env: the new episode's id
             if (KIND == RSX_KIND_VSS) {
                 if (ended && is_ball && mode == 0) {
-                    atomicAdd(&bufs.metrics[1], 1ull);
-                    if (info[4] > 0.0f) atomicAdd(&bufs.metrics[2], 1ull);
-                    if (info[5] > 0.0f) atomicAdd(&bufs.metrics[3], 1ull);
-                    atomicAdd(&bufs.metrics[4], (unsigned long long)__float2ll_rn(vss_episode_return(info) * 1048576.0f));
-                    atomicAdd(&bufs.metrics[5], (unsigned long long)steps);
-                    if (trunc && !term) atomicAdd(&bufs.metrics[6], 1ull);
+                    unsigned long long* const ms = metric_slot(bufs);
+                    atomicAdd(&ms[1], 1ull);
+                    if (info[4] > 0.0f) atomicAdd(&ms[2], 1ull);
+                    if (info[5] > 0.0f) atomicAdd(&ms[3], 1ull);
+                    atomicAdd(&ms[4], (unsigned long long)__float2ll_rn(vss_episode_return(info) * 1048576.0f));
+                    atomicAdd(&ms[5], (unsigned long long)steps);
+                    if (trunc && !term) atomicAdd(&ms[6], 1ull);
                 }
             } else if (mode == 0) {
                 // SSL tasks (short episodes: several resetting waves in every launch): the ball lane
@@ -1586,7 +1628,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
                 wave_sync();
                 if (ended && b < 6) {
                     const unsigned long long v = (unsigned long long)mv[2 * b] | ((unsigned long long)mv[2 * b + 1] << 32);
-                    if (v) atomicAdd(&bufs.metrics[1 + b], v);
+                    if (v) atomicAdd(&metric_slot(bufs)[1 + b], v);
                 }
             }
             RSX_STAMP(15);

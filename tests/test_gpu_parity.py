@@ -502,9 +502,13 @@ def test_get_state_after_device_side_writes_is_not_served_from_the_step_copy():
     sim.close()
 
 
-@pytest.mark.parametrize("task,kind,ft,nb,ny,adim", [(1, 0, 0, 3, 3, 2), (2, 1, 2, 1, 6, 5)], ids=["vss-v0", "static-defenders"])
+EPL_TASKS = [(1, 0, 0, 3, 3, 2), (2, 1, 2, 1, 6, 5), (3, 1, 2, 1, 4, 4), (4, 1, 2, 1, 1, 5), (5, 1, 2, 2, 0, 3)]
+EPL_IDS = ["vss-v0", "static-defenders", "dribbling", "contested", "pass-endurance"]
+
+
+@pytest.mark.parametrize("task,kind,ft,nb,ny,adim", EPL_TASKS, ids=EPL_IDS)
 def test_env_per_lane_layout_is_bit_identical(oracle_mod, monkeypatch, task, kind, ft, nb, ny, adim):
-    """Large VSS-v0 and SSLStaticDefenders batches are stepped by second kernels (one lane per env,
+    """Large batches of the five registered tasks are stepped by second kernels (one lane per env,
     rsx_epl.hpp / rsx_epl_ssl.hpp).  Forced on a small ragged batch here: they must agree bit for bit
     with the CPU oracle and with the 8-lanes-per-env kernel — fed and random actions (kicks, dribbler),
     contacts, TimeLimit resets, single-step and multi-step launches, counters."""
@@ -593,19 +597,20 @@ def test_long_horizon_bitexact(oracle_mod, task, kind, ft, nb, ny, B, steps):
     sim.close()
 
 
-def test_static_defenders_env_per_lane_long_run_with_contacts(oracle_mod, monkeypatch):
-    """the SSL one-lane-per-env kernel over 1500 random-action steps x 96 envs (ball carried, kicked into the
-    defenders, robot-robot hits, every termination branch): still the oracle's bits"""
+@pytest.mark.parametrize("task,kind,ft,nb,ny,adim", EPL_TASKS[1:], ids=EPL_IDS[1:])
+def test_ssl_env_per_lane_long_run_with_contacts(oracle_mod, monkeypatch, task, kind, ft, nb, ny, adim):
+    """the SSL one-lane-per-env kernels over 1500 random-action steps x 96 envs (ball carried, kicked into the
+    other robots, robot-robot hits, every termination branch): still the oracle's bits"""
     L = _lib()
     monkeypatch.setenv("RSX_LAYOUT", "epl")
     B = 96
-    sim = L.Sim(1, 2, 1, 6, 25, B)
-    sim.task_attach(2, 99, 0, 0)
+    sim = L.Sim(kind, ft, nb, ny, 25, B)
+    sim.task_attach(task, 99, 0, 0)
     tens = sim.task_tensors()
     sim.task_reset()
-    refs = _mk_oracles(oracle_mod, 1, 2, 1, 6, B)
+    refs = _mk_oracles(oracle_mod, kind, ft, nb, ny, B)
     for e, r in enumerate(refs):
-        r.task_attach(2, 99, e, 0)
+        r.task_attach(task, 99, e, 0)
         r.task_reset()
     for chunk in range(6):
         sim.task_step_n(249)
@@ -617,8 +622,8 @@ def test_static_defenders_env_per_lane_long_run_with_contacts(oracle_mod, monkey
     sim.close()
 
 
-@pytest.mark.parametrize("task,kind,ft,nb,ny", [(1, 0, 0, 3, 3), (2, 1, 2, 1, 6)], ids=["vss-v0", "static-defenders"])
-def test_large_batch_switches_layout_and_agrees(monkeypatch, task, kind, ft, nb, ny):
+@pytest.mark.parametrize("task,kind,ft,nb,ny,adim", EPL_TASKS, ids=EPL_IDS)
+def test_large_batch_switches_layout_and_agrees(monkeypatch, task, kind, ft, nb, ny, adim):
     """At 131 072 envs the library picks the one-lane-per-env kernel by itself; forcing the 8-lane
     kernel on the same seeds must give the same buffers (full size, a few hundred resets)."""
     import torch
@@ -729,13 +734,20 @@ def test_metrics_env_steps_are_counted_on_the_device():
     launches, C-side step loops and one-launch rollouts alike."""
     L = _lib()
     sim = L.Sim(0, 0, 3, 3, 25, 100)
-    sim.task_attach(1, 1, 0, 0)
+    sim.task_attach(1, 1, 0, 5)
     sim.task_reset()
     sim.task_step(None); sim.task_step_n(4); sim.task_rollout(7)
     import torch
     torch.cuda.synchronize()
     dev = sim.task_tensors()["metrics"].cpu().numpy()
-    assert dev[0] == 100 * 12 and np.array_equal(dev, sim.read_metrics())
+    assert dev[0] == 100 * 12
+    # the episode counters are per-block partial sums until they are folded (rsx_metrics_fold)
+    sim.metrics_fold()
+    torch.cuda.synchronize()
+    dev = sim.task_tensors()["metrics"].cpu().numpy()
+    assert dev[1] == 200 and dev[5] == 1000 and dev[6] == 200 and np.array_equal(dev, sim.read_metrics())
+    sim.task_rollout(5)
+    assert sim.read_metrics()[1] == 300 and sim.read_metrics()[1] == 300   # folding twice adds nothing
     sim.close()
 
 
