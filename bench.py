@@ -405,11 +405,16 @@ def sweep(L, torch, dev, timed, n=100, warm=30):
 def other_configs(L, torch, dev, timed):
     """The other single-GPU configurations of BASELINE.json, fused, one launch per step, device-side random
     actions; algorithmic bytes per env-step from SURVEY.md 8(d): state r/w + commands + obs + reward + done."""
-    SD = 2 * 4 * (5 + 11 * 7) + 4 * 8 * 7 + 4 * 24 + 5          # 981
-    SC = 2 * 4 * (5 + 11 * 22) + 4 * 8 * 22 + 4 * 46 + 5        # 2869
+    def ssl_bytes(n_robots, obs_dim):
+        return 2 * 4 * (5 + 11 * n_robots) + 4 * 8 * n_robots + 4 * obs_dim + 5
+    SD = ssl_bytes(7, 24)      # 981
+    SC = ssl_bytes(22, 46)     # 2869
     cases = (("configs[2] SSLStaticDefenders-v0 1v6", 1, 2, 1, 6, L.TASK_SSL_STATIC_DEFENDERS, 2048, SD, 2000, 200),
              ("SSLStaticDefenders-v0 1v6, 262 144 envs (one-lane-per-env kernel)", 1, 2, 1, 6, L.TASK_SSL_STATIC_DEFENDERS, 262144, SD, 100, 30),
              ("SSLStaticDefenders-v0 1v6, 1 048 576 envs (one-lane-per-env kernel)", 1, 2, 1, 6, L.TASK_SSL_STATIC_DEFENDERS, 1048576, SD, 60, 20),
+             ("SSLDribbling-v0 1v4, 1 048 576 envs (one-lane-per-env kernel)", 1, 2, 1, 4, L.TASK_SSL_DRIBBLING, 1048576, ssl_bytes(5, 21), 60, 20),
+             ("SSLContestedPossession-v0 1v1, 1 048 576 envs (one-lane-per-env kernel)", 1, 2, 1, 1, L.TASK_SSL_CONTESTED, 1048576, ssl_bytes(2, 14), 60, 20),
+             ("SSLPassEndurance-v0 2v0, 1 048 576 envs (one-lane-per-env kernel)", 1, 2, 2, 0, L.TASK_SSL_PASS_ENDURANCE, 1048576, ssl_bytes(2, 16), 60, 20),
              ("configs[3] SSL 11v11 division-A, scrimmage task, spread line-up", 1, 1, 11, 11, L.TASK_SSL_SCRIMMAGE, 1024, SC, 1000, 100),
              ("configs[3] SSL 11v11 division-A, scrimmage task, crowded line-up (worst-case contacts)", 1, 1, 11, 11,
               L.TASK_SSL_SCRIMMAGE_CROWDED, 1024, SC, 1000, 100),

@@ -38,9 +38,14 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 }  // namespace
 
-// smallest batch stepped by the one-lane-per-env VSS-v0 kernel (measured crossover, profiles/)
+// smallest batch stepped by the one-lane-per-env kernels (measured crossovers, profiles/): VSS-v0 at
+// 131 072 envs; the SSL tasks at 65 536 (single-step launches break even there, multi-step launches
+// are already 1.3-2.5x faster)
 #ifndef RSX_EPL_MIN_ENVS
 #define RSX_EPL_MIN_ENVS 131072
+#endif
+#ifndef RSX_EPL_MIN_ENVS_SSL
+#define RSX_EPL_MIN_ENVS_SSL 65536
 #endif
 
 struct rsx_sim {
@@ -663,7 +668,7 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
     // episode ids start at 0xFFFFFFFF so that the first reset() opens episode 0
     HIP_TRY(hipMemset(h->d_aux + (size_t)ROW_EPISODE * B, 0xFF, B * sizeof(uint32_t)));
     h->P = P;
-    // VSS-v0 3v3: which tile layout steps the envs.  Both give identical results; the one-lane-
+    // The five registered tasks: which tile layout steps the envs.  Both give identical results; the one-lane-
     // per-env kernel needs enough envs to fill the chip with its long waves.
     h->epl = false;
     const bool fixed_ssl = task == RSX_TASK_SSL_DRIBBLING || task == RSX_TASK_SSL_CONTESTED || task == RSX_TASK_SSL_PASS_ENDURANCE;   // team sizes checked above
@@ -671,7 +676,7 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
         const char* lay = std::getenv("RSX_LAYOUT");
         if (lay && std::strcmp(lay, "epl") == 0) h->epl = true;
         else if (lay && std::strcmp(lay, "lanes") == 0) h->epl = false;
-        else h->epl = P.num_envs >= RSX_EPL_MIN_ENVS;
+        else h->epl = P.num_envs >= (task == RSX_TASK_VSS_V0 ? RSX_EPL_MIN_ENVS : RSX_EPL_MIN_ENVS_SSL);
     }
     h->task_ready = false;
     HIP_TRY(hipDeviceSynchronize());   // null-stream memsets done before any caller stream steps

@@ -35,10 +35,10 @@ struct SeplShared {
 };
 
 template <int TASK> struct SeplTask;   // robots, blue robots, observation width, robots that carry kicker / dribbler commands
-template <> struct SeplTask<RSX_TASK_SSL_STATIC_DEFENDERS> { static constexpr int N = 7, NBLUE = 1, OD = 24, NCMD = 1; };   // static_defenders.py:47-48
-template <> struct SeplTask<RSX_TASK_SSL_DRIBBLING> { static constexpr int N = 5, NBLUE = 1, OD = 21, NCMD = 1; };          // dribbling.py:45-46
-template <> struct SeplTask<RSX_TASK_SSL_CONTESTED> { static constexpr int N = 2, NBLUE = 1, OD = 14, NCMD = 1; };          // contested_possession.py:46-47
-template <> struct SeplTask<RSX_TASK_SSL_PASS_ENDURANCE> { static constexpr int N = 2, NBLUE = 2, OD = 16, NCMD = 2; };     // pass_endurance.py:45-46
+template <> struct SeplTask<RSX_TASK_SSL_STATIC_DEFENDERS> { static constexpr int N = 7, NBLUE = 1, OD = 24, NCMD = 1, WMIN = 3, WMAX = 4; };   // static_defenders.py:47-48
+template <> struct SeplTask<RSX_TASK_SSL_DRIBBLING> { static constexpr int N = 5, NBLUE = 1, OD = 21, NCMD = 1, WMIN = 4, WMAX = 8; };          // dribbling.py:45-46
+template <> struct SeplTask<RSX_TASK_SSL_CONTESTED> { static constexpr int N = 2, NBLUE = 1, OD = 14, NCMD = 1, WMIN = 4, WMAX = 8; };          // contested_possession.py:46-47
+template <> struct SeplTask<RSX_TASK_SSL_PASS_ENDURANCE> { static constexpr int N = 2, NBLUE = 2, OD = 16, NCMD = 2, WMIN = 4, WMAX = 8; };     // pass_endurance.py:45-46
 
 // one observation row from registers: the widest stores the row's alignment allows (rows are OD floats apart)
 template <int OD>
@@ -81,10 +81,10 @@ __host__ __device__ constexpr unsigned sepl_pair_mask(int k) {
 }
 static_assert(sepl_pair_mask<7>(0) == 0x00003Fu && sepl_pair_mask<7>(3) == 0x038884u && sepl_pair_mask<7>(6) == 0x1A4420u, "pair masks");
 
-// occupancy target: the 1v6 kernel holds 7 robots in registers (3-4 waves per SIMD measured best); the
-// smaller tasks fit the default budget
+// occupancy target (waves per SIMD): the 1v6 kernel holds 7 robots in registers (3-4 measured best); the smaller
+// tasks fit 128 VGPRs (4 waves) without spilling — 6 and 8 waves spill and measured 1.4x / 2.3x slower, 3 the same
 template <int TASK, int MODE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TASK == RSX_TASK_SSL_STATIC_DEFENDERS ? 3 : 4, TASK == RSX_TASK_SSL_STATIC_DEFENDERS ? 4 : 8)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SeplTask<TASK>::WMIN, SeplTask<TASK>::WMAX)))
 void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
     constexpr int KIND = RSX_KIND_SSL, N = SeplTask<TASK>::N, NBLUE = SeplTask<TASK>::NBLUE, OD = SeplTask<TASK>::OD,
                   NCMD = SeplTask<TASK>::NCMD, RS = 11, NB1 = N + 1;
