@@ -106,6 +106,7 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
     float* const st = bufs.state + e;
     float* const auxe = bufs.aux + e;
 
+    RSX_STAMP(0);
     // ---- load ----
     Body r[N];
     Body ball = Body{};
@@ -147,6 +148,7 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
         for (int i = 0; i < AD; ++i) act[i] = bufs.actions[(size_t)e * AD + i];
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): all loads land once, before the step loop
+    RSX_STAMP(1);
 #pragma unroll
     for (int k = 0; k < N; ++k) {   // interpret_body, robot
         r[k] = Body{};
@@ -161,6 +163,7 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
     ball.z = rawb[2] - K::r_ball; ball.vz = rawb[5]; ball.om = rawb[6];
 
     float reward = 0.0f; int term = 0, trunc = 0;
+    RSX_STAMP(2);   // development builds (-DRSX_TIMING, tools/exp_timeline_epl.py): cycle stamps of wave 0's lane 0 per block
 
     for (int it = 0; it < n_steps; ++it) {
         const bool first_step = steps == 0;
@@ -191,6 +194,7 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
             }
         }
 
+        RSX_STAMP(3);
         // ---- physics: n_sub sub-steps, the whole env in registers ----
         if (P.n_sub && !(ball.z > 0.0f || ball.vz > 0.0f)) {   // rolling resistance + spin decay, once per step()
             float sp2 = fma_(ball.vx, ball.vx, ball.vy * ball.vy);
@@ -236,6 +240,7 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
             ball.x = fma_(ball.vx, P.h, ball.x);
             ball.y = fma_(ball.vy, P.h, ball.y);
 
+            if (sub == 0) RSX_STAMP(4);
             // B: contacts.  One bit per touching robot pair (exact integer form of 0 < d2 < thr, see
             // rsx_kernels.hpp), one bit per robot whose centre is near enough to the ball for a mouth,
             // circle or infrared contact; a second sweep over the corrected snapshot where a pair was deep.
@@ -273,6 +278,7 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
                 const bool mine = sweep == 0 || deep;   // second: envs with a deep pair only
                 const unsigned touching = mine ? find_pairs() : 0u;
                 const unsigned near = mine ? find_near() : 0u;
+                if (sub == 0 && sweep == 0) RSX_STAMP(5);
                 if (!__any((touching | near) != 0)) break;
                 const bool first = sweep == 0;
 #pragma unroll
@@ -409,6 +415,7 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
                 }
                 wave_sync();
             }
+            if (sub == 0) RSX_STAMP(6);
             if (bo.ovr) {   // kicker / dribbler: decided in the first sweep, applied after the impulses
                 ball.vx = bo.ovx; ball.vy = bo.ovy; ball.om = 0.0f;
                 if (bo.okick && bo.ovz > 0.0f) ball.vz = bo.ovz;
@@ -425,7 +432,9 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
                 walls<KIND>(P, K::r_ball, K::e_wb, ball.x, ball.y, ball.vx, ball.vy, hit);
                 if (hit) ball_wall_spin<KIND>(hit, vx0, vy0, ball.vx, ball.vy, ball.om);
             }
+            if (sub == 0) RSX_STAMP(7);
         }
+        RSX_STAMP(8);
 
         // ---- wire-format values, observation, reward ----
         float ob[OD];   // this env's observation, in registers
@@ -438,6 +447,7 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
             sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
             write_obs_nb<KIND, TASK>(P, ob, k, NBLUE, true, false, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, wd, r[k].ir, obs_ts);
         }
+        RSX_STAMP(9);
         ball.z = (K::r_ball + ball.z) - K::r_ball;
         write_obs_nb<KIND, TASK>(P, ob, N, NBLUE, false, true, ball.x, ball.y, ball.vx, ball.vy, 0.0f, 0.0f, 0.0f, 0, obs_ts);
         bool success = false, against = false;
@@ -467,6 +477,7 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
             bufs.flags[e] = (uint8_t)term; bufs.flags[B + e] = (uint8_t)trunc;
         }
 
+        RSX_STAMP(10);
         // ---- episode end: same-step auto-reset, one lane = one env ----
         if (__any(ended)) {
             if (ended) {
@@ -507,6 +518,7 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
         if (live) sepl_store_row<OD>(bufs.obs + (size_t)e * OD, ob);
     }
 
+    RSX_STAMP(11);
     // ---- store (wire format: degrees, deg/s, infrared, wheel speeds) ----
     if (live) {
 #pragma unroll
@@ -526,6 +538,11 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
         if (HAS_TS) auxe[(size_t)ROW_PREV_POT * B] = prev_pot;
     }
     if (counts_steps) bufs.metrics[0] = steps_before + (unsigned long long)P.num_envs * (unsigned long long)n_steps;
+    RSX_STAMP(12);
+#ifdef RSX_TIMING
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    RSX_STAMP(13);
+#endif
 }
 
 }  // namespace rsx

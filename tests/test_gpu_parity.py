@@ -533,7 +533,8 @@ def test_env_per_lane_layout_is_bit_identical(oracle_mod, monkeypatch, task, kin
         rng = np.random.default_rng(5)
         for t in range(120):
             if t % 3 == 0:
-                a = rng.uniform(-1, 1, (B, adim)).astype(np.float32)
+                a = rng.uniform(-1, 1, tuple(tens["actions"].shape)).astype(np.float32)
+                assert a[0].size == adim
                 tens["actions"].copy_(torch.from_numpy(a))
                 sim.task_step(tens["actions"].data_ptr())
                 if layout == "epl":
@@ -618,7 +619,7 @@ def test_ssl_env_per_lane_long_run_with_contacts(oracle_mod, monkeypatch, task, 
         oracle_mod.vec_task_step(refs, 250)
         _cmp_task(sim, refs, tens, chunk)
     m = sim.read_metrics()
-    assert np.array_equal(m, sum(r.task_out()["metrics"] for r in refs)) and m[1] > B
+    assert np.array_equal(m, sum(r.task_out()["metrics"] for r in refs)) and m[1] >= B
     sim.close()
 
 
@@ -636,7 +637,7 @@ def test_large_batch_switches_layout_and_agrees(monkeypatch, task, kind, ft, nb,
         else:
             monkeypatch.delenv("RSX_LAYOUT", raising=False)
         sim = L.Sim(kind, ft, nb, ny, 25, B)
-        sim.task_attach(task, 2025, 0, 0)
+        sim.task_attach(task, 2025, 0, 30 if task >= 6 else 0)   # (scrimmage episodes are long: end them by the step limit)
         tens = sim.task_tensors()
         sim.task_reset()
         sim.task_step_n(25)
