@@ -93,8 +93,12 @@ raw_ssl("configs[3] SSL 11v11 raw sim, spread", 1, 11, 11, 1024, False, 2680)
 raw_ssl("configs[3] SSL 11v11 raw sim, crowded (worst-case contacts)", 1, 11, 11, 1024, True, 2680)
 for B in (256, 1024, 16384, 65536, 262144, 1048576, 4194304):
     fused("sweep VSS-v0 fused", 0, 0, 3, 3, 1, B, 541, K=2000 if B <= 65536 else 200)
-for B in (16384, 262144):
-    fused("sweep SSLStaticDefenders-v0 fused", 1, 2, 1, 6, 2, B, 981, K=500 if B <= 65536 else 100)
+for B in (16384, 262144, 1048576):
+    fused("sweep SSLStaticDefenders-v0 fused", 1, 2, 1, 6, 2, B, 981, K=500 if B <= 65536 else 100 if B <= 262144 else 60)
+for B in (262144, 1048576):   # the other registered SSL tasks at scale (one lane per env from 65 536 envs)
+    fused("sweep SSLDribbling-v0 fused", 1, 2, 1, 4, 3, B, 2 * 4 * 60 + 4 * 40 + 4 * 21 + 5, K=60)
+    fused("sweep SSLContestedPossession-v0 fused", 1, 2, 1, 1, 4, B, 2 * 4 * 27 + 4 * 16 + 4 * 14 + 5, K=60)
+    fused("sweep SSLPassEndurance-v0 fused", 1, 2, 2, 0, 5, B, 2 * 4 * 27 + 4 * 16 + 4 * 16 + 5, K=60)
 
 # The robosim-shaped host path (rsx_step + rsx_get_state): float64 host arrays in and out, i.e.
 # the PCIe-inclusive rate of the boundary when a caller keeps its data on the host.

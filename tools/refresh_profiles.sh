@@ -29,15 +29,23 @@ python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_flags.json 2> $OUT/ben
 # one-lane-per-env kernel at 1 M envs: SQ + HBM counters
 tools/prof_epl.sh $OUT/epl > $OUT/epl.log 2>&1
 cat $OUT/epl/*.txt > $OUT/epl_counters_1M.txt
-# SSLStaticDefenders at 1 M envs (one-lane-per-env kernel): kernel stats
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sd_stats -- python -c "
+# the four registered SSL tasks at 1 M envs (one-lane-per-env kernels): kernel stats, SQ + HBM counters of the 1v6 one
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ssl_stats -- python -c "
 import sys; sys.path.insert(0, '.')
 import torch
 from rsoccer_amd import _lib as L
-s = L.Sim(1, 2, 1, 6, 25, 1 << 20); s.task_attach(2, 0, 0, 0); s.task_reset(); s.task_step_n(60); torch.cuda.synchronize()
-" > $OUT/sd_stats.log 2>&1
-find $OUT/sd_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/sd_1M_kernel_stats.csv
-head -3 $OUT/sd_1M_kernel_stats.csv
+for task, nb, ny in ((2, 1, 6), (3, 1, 4), (4, 1, 1), (5, 2, 0)):
+    s = L.Sim(1, 2, nb, ny, 25, 1 << 20); s.task_attach(task, 0, 0, 0); s.task_reset(); s.task_step_n(60); torch.cuda.synchronize(); s.close()
+" > $OUT/ssl_stats.log 2>&1
+find $OUT/ssl_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/ssl_tasks_1M_kernel_stats.csv
+head -6 $OUT/ssl_tasks_1M_kernel_stats.csv
+tools/prof_kernel.sh $OUT/sd_epl 1048576 2 "ssl_epl_kernel" > $OUT/sd_epl.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c -d $OUT/sd_epl/$c -- python tools/prof_target.py 1048576 step 12 2 > $OUT/sd_epl/$c.log 2>&1
+  python tools/rocpd_summary.py $(find $OUT/sd_epl/$c -name "*.db" | head -1) 2>&1 | grep -E "ssl_epl_kernel" | grep -v "^rsx" > $OUT/sd_epl/$c.txt
+done
+cat $OUT/sd_epl/*.txt > $OUT/static_defenders_epl_counters_1M.txt
+cut -c1-130 $OUT/static_defenders_epl_counters_1M.txt
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
 # batched hooks: no host <-> device copy inside step()
 rocprofv3 --memory-copy-trace --kernel-trace --stats --output-format csv -d $OUT/hooks -- python tools/hooks_nocopy.py > $OUT/hooks.log 2>&1
@@ -48,3 +56,5 @@ cat $OUT/hooks_memcopy.txt
 # in-kernel timeline of the headline kernel
 tools/build_timing.sh > /dev/null 2>&1 && RSX_LIB=tools/_dev/librsx_hip_timing.so python tools/exp_timeline2.py > $OUT/timeline.txt 2>&1
 head -40 $OUT/timeline.txt
+for t in 2 3 5; do echo "== task $t, 1 048 576 envs, one lane per env"; RSX_LIB=tools/_dev/librsx_hip_timing.so B=1048576 TASK=$t python tools/exp_timeline_epl.py 2>&1 | grep -v amdgpu; done > $OUT/timeline_ssl_epl_1M.txt
+cat $OUT/timeline_ssl_epl_1M.txt

@@ -7,7 +7,8 @@ from rsoccer_amd import _lib as L
 SCALE = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0   # fraction of the full soak
 CASES = [("vss", 0, 0, 3, 3, 1, 4096, 1_000_000), ("vss-epl", 0, 0, 3, 3, 1, 131072, 60_000), ("sd", 1, 2, 1, 6, 2, 2048, 400_000),
          ("sd-epl", 1, 2, 1, 6, 2, 131072, 40_000), ("drib", 1, 2, 1, 4, 3, 2048, 300_000), ("cont", 1, 2, 1, 1, 4, 2048, 300_000),
-         ("pass", 1, 2, 2, 0, 5, 2048, 300_000), ("vss5v5", 0, 1, 5, 5, 1, 1024, 200_000),
+         ("pass", 1, 2, 2, 0, 5, 2048, 300_000), ("drib-epl", 1, 2, 1, 4, 3, 131072, 40_000), ("cont-epl", 1, 2, 1, 1, 4, 131072, 40_000),
+         ("pass-epl", 1, 2, 2, 0, 5, 131072, 40_000), ("vss5v5", 0, 1, 5, 5, 1, 1024, 200_000),
          ("scrim", 1, 1, 11, 11, 6, 1024, 100_000), ("scrim-crowded", 1, 1, 11, 11, 7, 1024, 100_000)]
 CASES = [c[:7] + (max(1000, int(c[7] * SCALE)),) for c in CASES]
 for name, kind, ft, nb, ny, task, B, steps in CASES:
