@@ -254,17 +254,21 @@ def main():
         mbuf.copy_(tens["metrics"], non_blocking=backend == "nccl")
         dist.all_reduce(mbuf)
 
+    stepped = [0]   # per-step launches of `sim` so far: the all-reduce falls on every ALLREDUCE_EVERY-th of them
+
     def run(s, n, timed_mode):
         if timed_mode == "rollout":
             s.task_rollout(n, stream)
             return
         done = 0
         while done < n:
-            m = min(ALLREDUCE_EVERY, n - done)
+            m = min(ALLREDUCE_EVERY - stepped[0] % ALLREDUCE_EVERY if s is sim else ALLREDUCE_EVERY, n - done)
             s.task_step_n(m, stream)   # m launches, one per env.step()
             done += m
-            if distributed and s is sim and not os.environ.get("RSX_BENCH_NO_ALLREDUCE"):
-                allreduce_metrics()
+            if s is sim:
+                stepped[0] += m
+                if distributed and stepped[0] % ALLREDUCE_EVERY == 0 and not os.environ.get("RSX_BENCH_NO_ALLREDUCE"):
+                    allreduce_metrics()
 
     def barrier():
         if distributed:
@@ -273,7 +277,10 @@ def main():
 
     def timed(s, n, warm, mode):
         """warm untimed steps, then EXACTLY n steps bracketed by barrier + synchronize; returns the
-        max wall time over ranks and this rank's HIP-event time of the same region (ms)."""
+        max wall time over ranks and this rank's HIP-event time of the same region (ms).  Every rank starts its
+        clock when the opening barrier releases it and stops it when ITS n steps are complete on the device; the
+        maximum over ranks is then the time until the last rank was done — the closing barrier itself (an RCCL
+        collective of ~50-100 us, comparable to a short timed region) is not part of any rank's n steps."""
         run(s, warm, mode) if warm else None
         barrier()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -282,8 +289,8 @@ def main():
         run(s, n, mode)
         ev1.record()
         torch.cuda.synchronize()
-        barrier()
         wall = time.perf_counter() - t0
+        barrier()
         dev_ms = ev0.elapsed_time(ev1)
         if distributed:
             t = torch.tensor([wall], dtype=torch.float64, device=mbuf.device)
@@ -341,6 +348,7 @@ def main():
         if distributed:
             line["collective"] = {"backend": "rccl" if backend == "nccl" else "gloo (shared device, test mode)",
                                   "ranks": world, "payload_bytes": 8 * L.N_METRICS, "every_steps": ALLREDUCE_EVERY,
+                                  "allreduces_in_timed_region": (W + K) // ALLREDUCE_EVERY - W // ALLREDUCE_EVERY,
                                   "per_rank_ms_per_step": per_rank_ms}
         if steady is not None:
             sw, sd = steady
