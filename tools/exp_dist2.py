@@ -14,7 +14,7 @@ def v_none(): pass
 def v_copy_side():
     ev = torch.cuda.Event(); ev.record(main)
     with torch.cuda.stream(side):
-        side.wait_event(ev); mbuf.copy_(tens["metrics"], non_blocking=True)
+        side.wait_event(ev); sim.metrics_fold(torch.cuda.current_stream().cuda_stream); mbuf.copy_(tens["metrics"], non_blocking=True)
 def v_ar_side():
     ev = torch.cuda.Event(); ev.record(main)
     with torch.cuda.stream(side):

@@ -15,11 +15,11 @@ mbuf = torch.zeros(8, dtype=torch.int64, device="cuda")
 ev = torch.cuda.Event(enable_timing=False)
 def none(): pass
 def inline():
-    mbuf.copy_(tens["metrics"], non_blocking=True); dist.all_reduce(mbuf)
+    sim.metrics_fold(torch.cuda.current_stream().cuda_stream); mbuf.copy_(tens["metrics"], non_blocking=True); dist.all_reduce(mbuf)
 def sidestream():
     ev.record(main); side.wait_event(ev)
     with torch.cuda.stream(side):
-        mbuf.copy_(tens["metrics"], non_blocking=True); dist.all_reduce(mbuf)
+        sim.metrics_fold(torch.cuda.current_stream().cuda_stream); mbuf.copy_(tens["metrics"], non_blocking=True); dist.all_reduce(mbuf)
 for name, fn in (("no all-reduce", none), ("on the compute stream", inline), ("side stream + event", sidestream), ("no all-reduce", none)):
     for _ in range(5):
         sim.task_step_n(100, main.cuda_stream); fn()
