@@ -247,6 +247,19 @@ int rsx_check_finite(rsx_sim* h, int64_t* n_bad, void* stream);
  * all-reduce): 0 env_steps, 1 episodes, 2 goals_for (blue), 3 goals_against (yellow),
  * 4 sum of episode returns in 2^-20 fixed point, 5 sum of episode lengths,
  * 6 truncated episodes, 7 reserved.  Synchronises `stream`. */
+/* ---- checkpoint / resume of a fused run ----------------------------------------------------
+ * (the reference cannot: robosim exposes no way to restore velocities, rsim.py:52-75, and its tasks keep their
+ * episode state — OU noise, step counters, cumulative reward terms — in Python attributes.)
+ * The blob holds every per-env buffer of the handle (state incl. the two internal rows, step / episode counters,
+ * OU noise, cumulative info terms, last observation / reward / flags), the handle's step counter (the key of the
+ * per-step random draws) and the metrics.  Loading it into a handle created with the same simulator kind, team
+ * sizes, batch size and attached with the same task, seed and env_id_base makes every following step bit-identical
+ * to what the saving handle would have produced — across kernel layouts (RSX_LAYOUT) and processes.  Host blob,
+ * both calls synchronise `stream`. */
+int rsx_task_checkpoint_size(rsx_sim* h, size_t* bytes);
+int rsx_task_checkpoint_save(rsx_sim* h, void* blob, size_t bytes, void* stream);
+int rsx_task_checkpoint_load(rsx_sim* h, const void* blob, size_t bytes, void* stream);
+
 int rsx_read_metrics(rsx_sim* h, int64_t out[RSX_METRICS], void* stream);
 /* Device-side readers of rsx_task_view.metrics (e.g. an RCCL all-reduce of the 64 bytes) call this
  * first: one tiny launch on `stream` that adds the step kernels' partial episode counters into

@@ -35,6 +35,7 @@ SYMBOLS = (
     "rsx_reset_dev", "rsx_task_attach",
     "rsx_task_view_get", "rsx_task_reset", "rsx_task_reset_to", "rsx_task_step",
     "rsx_task_step_n", "rsx_task_rollout", "rsx_read_metrics", "rsx_metrics_fold", "rsx_check_finite",
+    "rsx_task_checkpoint_size", "rsx_task_checkpoint_save", "rsx_task_checkpoint_load",
     "rsx_serve_start", "rsx_serve_step", "rsx_serve_stop",
 )
 
@@ -100,6 +101,9 @@ def load():
     lib.rsx_task_rollout.argtypes = [vp, ip, vp]
     lib.rsx_read_metrics.argtypes = [vp, vp, vp]
     lib.rsx_metrics_fold.argtypes = [vp, vp]
+    lib.rsx_task_checkpoint_size.argtypes = [vp, C.POINTER(C.c_size_t)]
+    lib.rsx_task_checkpoint_save.argtypes = [vp, vp, C.c_size_t, vp]
+    lib.rsx_task_checkpoint_load.argtypes = [vp, vp, C.c_size_t, vp]
     lib.rsx_check_finite.argtypes = [vp, C.POINTER(C.c_int64), vp]
     lib.rsx_serve_start.argtypes = [vp, ip]
     lib.rsx_serve_step.argtypes = [vp, vp, vp]
@@ -343,6 +347,20 @@ class Sim:
         n = C.c_int64(0)
         _chk(self._lib.rsx_check_finite(self._h, C.byref(n), self._stream(stream)))
         return int(n.value)
+
+    def task_checkpoint(self, stream=None):
+        """bytes of a checkpoint of the fused run (rsx_task_checkpoint_save): state, episode bookkeeping, noise
+        state, step counter, metrics — see include/rsx.h"""
+        n = C.c_size_t(0)
+        _chk(self._lib.rsx_task_checkpoint_size(self._h, C.byref(n)))
+        blob = np.empty(n.value, dtype=np.uint8)
+        _chk(self._lib.rsx_task_checkpoint_save(self._h, blob.ctypes.data_as(C.c_void_p), n.value, self._stream(stream)))
+        return blob
+
+    def task_restore(self, blob, stream=None):
+        """continue from ``task_checkpoint()`` (same simulator, batch, task, seed and env_id_base)"""
+        blob = np.ascontiguousarray(np.frombuffer(blob, dtype=np.uint8) if isinstance(blob, (bytes, bytearray)) else blob, dtype=np.uint8)
+        _chk(self._lib.rsx_task_checkpoint_load(self._h, blob.ctypes.data_as(C.c_void_p), blob.size, self._stream(stream)))
 
     def metrics_fold(self, stream=None):
         """make the device copy of the episode counters (``task_tensors()["metrics"]``) exact, on ``stream``"""

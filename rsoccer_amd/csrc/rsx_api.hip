@@ -840,6 +840,95 @@ int rsx_check_finite(rsx_sim* h, int64_t* n_bad, void* stream) {
     return check_finite_impl(h, n_bad, (hipStream_t)stream);
 }
 
+}  // extern "C" (reopened below)
+
+// ---- task checkpoint: everything a fused run needs to continue bit-identically ----
+namespace {
+struct CkptHeader {
+    uint64_t magic;            // "RSXCKPT1"
+    int32_t abi, kind, field_rows, task, n_blue, n_yellow, num_envs, state_rows, aux_rows, obs_dim;
+    uint32_t key0, key1, env_id_base, tick;
+    uint64_t state_bytes, aux_bytes, obs_bytes, flag_bytes;
+    int64_t metrics[RSX_METRICS];
+};
+constexpr uint64_t CKPT_MAGIC = 0x3154504B43585352ull;   // "RSXCKPT1", little endian
+CkptHeader ckpt_header(const rsx_sim* h) {
+    CkptHeader k{};
+    const size_t B = (size_t)h->P.num_envs;
+    k.magic = CKPT_MAGIC; k.abi = RSX_ABI_VERSION; k.kind = h->P.kind; k.field_rows = h->M.rs; k.task = h->P.task;
+    k.n_blue = h->P.n_blue; k.n_yellow = h->P.n_yellow; k.num_envs = h->P.num_envs;
+    k.state_rows = h->P.state_dim + X_ROWS; k.aux_rows = aux_rows(h->P.n_robots); k.obs_dim = h->P.obs_dim;
+    k.key0 = h->P.key0; k.key1 = h->P.key1; k.env_id_base = h->P.env_id_base; k.tick = h->tick;
+    k.state_bytes = (uint64_t)k.state_rows * B * sizeof(float);
+    k.aux_bytes = (uint64_t)k.aux_rows * B * sizeof(float);
+    k.obs_bytes = (uint64_t)B * k.obs_dim * sizeof(float);
+    k.flag_bytes = 2 * B;
+    return k;
+}
+size_t ckpt_size(const CkptHeader& k) { return sizeof(CkptHeader) + k.state_bytes + k.aux_bytes + 2 * k.obs_bytes + k.flag_bytes; }
+}  // namespace
+
+extern "C" {
+
+int rsx_task_checkpoint_size(rsx_sim* h, size_t* bytes) {
+    if (!h || !bytes) return fail(RSX_ERR_ARG, "null argument");
+    if (h->P.task == RSX_TASK_NONE) return fail(RSX_ERR_STATE, "no task attached (rsx_task_attach)");
+    *bytes = ckpt_size(ckpt_header(h));
+    return RSX_OK;
+}
+
+int rsx_task_checkpoint_save(rsx_sim* h, void* blob, size_t bytes, void* stream) {
+    RSX_ENTER_TASK(h);
+    if (!blob) return fail(RSX_ERR_ARG, "blob is null");
+    CkptHeader k = ckpt_header(h);
+    if (bytes < ckpt_size(k)) return fail(RSX_ERR_ARG, "blob is smaller than rsx_task_checkpoint_size");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(fold_metrics_kernel, dim3(1), dim3(64), 0, s, h->d_metrics, h->d_mslots);
+    HIP_TRY(hipGetLastError());
+    char* p = (char*)blob + sizeof(CkptHeader);
+    HIP_TRY(hipMemcpyAsync(p, h->d_state, k.state_bytes, hipMemcpyDeviceToHost, s)); p += k.state_bytes;
+    HIP_TRY(hipMemcpyAsync(p, h->d_aux, k.aux_bytes, hipMemcpyDeviceToHost, s)); p += k.aux_bytes;
+    HIP_TRY(hipMemcpyAsync(p, h->d_obs, k.obs_bytes, hipMemcpyDeviceToHost, s)); p += k.obs_bytes;
+    HIP_TRY(hipMemcpyAsync(p, h->d_final_obs, k.obs_bytes, hipMemcpyDeviceToHost, s)); p += k.obs_bytes;
+    HIP_TRY(hipMemcpyAsync(p, h->d_flags, k.flag_bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(k.metrics, h->d_metrics, sizeof(k.metrics), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::memcpy(blob, &k, sizeof(k));
+    return RSX_OK;
+}
+
+int rsx_task_checkpoint_load(rsx_sim* h, const void* blob, size_t bytes, void* stream) {
+    RSX_ENTER_TASK(h);
+    if (!blob || bytes < sizeof(CkptHeader)) return fail(RSX_ERR_ARG, "blob is null or truncated");
+    CkptHeader k;
+    std::memcpy(&k, blob, sizeof(k));
+    CkptHeader want = ckpt_header(h);
+    if (k.magic != CKPT_MAGIC || k.abi != want.abi) return fail(RSX_ERR_ARG, "not a checkpoint of this library version");
+    if (k.kind != want.kind || k.task != want.task || k.n_blue != want.n_blue || k.n_yellow != want.n_yellow ||
+        k.num_envs != want.num_envs || k.state_rows != want.state_rows || k.aux_rows != want.aux_rows || k.obs_dim != want.obs_dim)
+        return fail(RSX_ERR_ARG, "the checkpoint was taken from a different configuration (simulator kind, team sizes, batch or task)");
+    if (k.key0 != want.key0 || k.key1 != want.key1 || k.env_id_base != want.env_id_base)
+        return fail(RSX_ERR_ARG, "the checkpoint was taken with another seed or env_id_base: attach the task with the same ones");
+    if (bytes < ckpt_size(k)) return fail(RSX_ERR_ARG, "blob is truncated");
+    hipStream_t s = (hipStream_t)stream;
+    const char* p = (const char*)blob + sizeof(CkptHeader);
+    h->host_state_valid = false;
+    HIP_TRY(hipMemcpyAsync(h->d_state, p, k.state_bytes, hipMemcpyHostToDevice, s)); p += k.state_bytes;
+    HIP_TRY(hipMemcpyAsync(h->d_aux, p, k.aux_bytes, hipMemcpyHostToDevice, s)); p += k.aux_bytes;
+    HIP_TRY(hipMemcpyAsync(h->d_obs, p, k.obs_bytes, hipMemcpyHostToDevice, s)); p += k.obs_bytes;
+    HIP_TRY(hipMemcpyAsync(h->d_final_obs, p, k.obs_bytes, hipMemcpyHostToDevice, s)); p += k.obs_bytes;
+    HIP_TRY(hipMemcpyAsync(h->d_flags, p, k.flag_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(h->d_mslots, 0, (size_t)MSLOTS * RSX_METRICS * sizeof(unsigned long long), s));
+    HIP_TRY(hipMemcpyAsync(h->d_metrics, k.metrics, sizeof(k.metrics), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    h->tick = k.tick;
+    h->task_ready = true;
+    return RSX_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
 int rsx_metrics_fold(rsx_sim* h, void* stream) {
     RSX_ENTER_TASK(h);
     hipLaunchKernelGGL(fold_metrics_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, h->d_metrics, h->d_mslots);

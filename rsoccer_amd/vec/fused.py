@@ -147,6 +147,18 @@ class VecFusedEnv:
         t = self._t
         return t["obs"], t["reward"], t["terminated"], t["truncated"], self._info()
 
+    def checkpoint(self):
+        """Everything needed to continue this run bit-identically (numpy uint8 blob, ``rsx_task_checkpoint_save``):
+        simulator state, episode bookkeeping, noise state, the random streams' step counter, metrics.  Restore
+        with ``restore()`` on an env of the same class, size, seed and ``env_id_base`` — in another process or on
+        another GPU."""
+        return self.sim.task_checkpoint(self._stream())
+
+    def restore(self, blob):
+        self.sim.task_restore(blob, self._stream())
+        t = self._t
+        return t["obs"], self._info()
+
     def metrics(self):
         """Counters accumulated on device since construction (synchronises the stream)."""
         m = self.sim.read_metrics(self._stream())

@@ -460,4 +460,29 @@ def test_plain_c_host_drives_the_library(tmp_path):
                            os.path.join(root, "examples", "rsx_c_host.c"), "-o", str(exe), "-ldl"])
     res = subprocess.run([str(exe), os.path.join(root, "rsoccer_amd", "librsx_hip.so")], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stdout + res.stderr
-    assert "ok" in res.stdout
+    assert "ok" in res.stdout@pytest.mark.gpu
+def test_vec_env_checkpoint_restore_continues_the_same_run():
+    """VecVSSEnv.checkpoint() / restore(): a second env object (same seed) picks the run up mid-episode — policy
+    actions, OU noise, auto-resets and counters continue as if nothing had happened"""
+    import torch
+    from rsoccer_amd.vec import VecVSSEnv
+    a = VecVSSEnv(48, seed=9, max_episode_steps=25)
+    a.reset()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    acts = [torch.rand(48, 2, generator=g) * 2 - 1 for _ in range(60)]
+    for t in range(20):
+        a.step(acts[t].cuda())
+    blob = a.checkpoint()
+    outs = [tuple(x.clone() for x in a.step(acts[t].cuda())[:4]) for t in range(20, 60)]
+    ma = a.metrics()
+    b = VecVSSEnv(48, seed=9, max_episode_steps=25)
+    obs, _ = b.restore(blob.tobytes())          # bytes work as well as the numpy blob
+    for t in range(20, 60):
+        got = b.step(acts[t].cuda())[:4]
+        for x, y in zip(got, outs[t - 20]):
+            assert torch.equal(x, y), t
+    assert b.metrics() == ma and ma["episodes"] >= 48 * 2
+    a.close(); b.close()
+
+
+

@@ -773,3 +773,58 @@ def test_other_time_steps_bitexact(oracle_mod, ts_ms):
                 r.task_step(None)
         _cmp_task(sim, refs, tens, f"ts={ts_ms}")
         sim.close()
+
+
+@pytest.mark.parametrize("task,kind,ft,nb,ny,adim", EPL_TASKS, ids=EPL_IDS)
+def test_checkpoint_resume_is_bit_identical_across_handles_and_layouts(monkeypatch, task, kind, ft, nb, ny, adim):
+    """rsx_task_checkpoint_save / _load: a run interrupted after 70 steps continues in a NEW handle (stepped by the
+    other kernel layout) exactly as the uninterrupted one: state, observations, rewards, flags, episode bookkeeping,
+    random streams and metrics."""
+    import torch
+    L = _lib()
+    B, seed, base = 200, 4242, 31
+
+    def snapshot(sim, tens):
+        torch.cuda.synchronize()
+        return np.concatenate([sim.get_state_full().ravel()] + [tens[k].cpu().numpy().astype(np.float64).ravel()
+                              for k in ("obs", "reward", "terminated", "truncated", "info", "final_obs", "steps")]
+                              + [sim.read_metrics().astype(np.float64)])
+
+    def make(layout):
+        monkeypatch.setenv("RSX_LAYOUT", layout)
+        sim = L.Sim(kind, ft, nb, ny, 25, B)
+        sim.task_attach(task, seed, base, 40)
+        return sim, sim.task_tensors()
+
+    a, ta = make("lanes")
+    a.task_reset()
+    a.task_step_n(50); a.task_rollout(20)
+    blob = a.task_checkpoint()
+    assert blob.dtype == np.uint8 and blob.size > B * 4 * (5 + 6 * (nb + ny))
+    a.task_step_n(30); a.task_rollout(25); a.task_step(None)
+    want = snapshot(a, ta)
+    a.close()
+
+    b, tb = make("epl")                       # another handle, the other layout, never reset
+    with pytest.raises(L.RsxError, match="must come before the first step"):
+        b.task_step(None)
+    b.task_restore(blob)
+    b.task_step_n(30); b.task_rollout(25); b.task_step(None)
+    got = snapshot(b, tb)
+    assert np.array_equal(got, want, equal_nan=True)
+    b.close()
+
+    c, _ = make("lanes")                      # a damaged blob is refused
+    with pytest.raises(L.RsxError, match="truncated"):
+        c.task_restore(blob[: blob.size // 2])
+    c.close()
+    d = L.Sim(kind, ft, nb, ny, 25, B)        # so is another seed ...
+    d.task_attach(task, seed + 1, base, 40)
+    with pytest.raises(L.RsxError, match="another seed"):
+        d.task_restore(blob)
+    d.close()
+    e = L.Sim(kind, ft, nb, ny, 25, B + 1)   # ... and another batch size
+    e.task_attach(task, seed, base, 40)
+    with pytest.raises(L.RsxError, match="different configuration"):
+        e.task_restore(blob)
+    e.close()
