@@ -460,7 +460,9 @@ def test_plain_c_host_drives_the_library(tmp_path):
                            os.path.join(root, "examples", "rsx_c_host.c"), "-o", str(exe), "-ldl"])
     res = subprocess.run([str(exe), os.path.join(root, "rsoccer_amd", "librsx_hip.so")], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stdout + res.stderr
-    assert "ok" in res.stdout@pytest.mark.gpu
+    assert "ok" in res.stdout
+
+
 def test_vec_env_checkpoint_restore_continues_the_same_run():
     """VecVSSEnv.checkpoint() / restore(): a second env object (same seed) picks the run up mid-episode — policy
     actions, OU noise, auto-resets and counters continue as if nothing had happened"""
@@ -483,6 +485,3 @@ def test_vec_env_checkpoint_restore_continues_the_same_run():
             assert torch.equal(x, y), t
     assert b.metrics() == ma and ma["episodes"] >= 48 * 2
     a.close(); b.close()
-
-
-
