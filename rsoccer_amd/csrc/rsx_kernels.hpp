@@ -87,6 +87,9 @@ struct Body {
 #ifndef RSX_DIRECT_OBS
 #define RSX_DIRECT_OBS 1
 #endif
+#ifndef RSX_PK_SWEEP
+#define RSX_PK_SWEEP 1
+#endif
 #define RSX_DIRECT_OBS_STAGE(L) (RSX_DIRECT_OBS ? 1 : (64 / (L)) * 64)
 
 template <int L>
@@ -96,6 +99,9 @@ struct Shared {
     float4 Cq[64];  // SSL robot -> ball record 1: flags, ovx, ovy, ovz
     float Dq[64];   // SSL robot -> ball record 2: spin change of the ball
     float W[64];    // robots: yaw rate, ball: spin (rad/s) — read on the contact path only
+#if RSX_PK_SWEEP
+    alignas(16) float X[64], Y[64];   // positions once more, [env slot][body]: four partners per 16-byte read for the packed overlap test
+#endif
     float zb[64 / L];          // ball height per env
     float x0[64 / L][12];      // robot 0 -> reward lane exchange
     float stage[RSX_DIRECT_OBS_STAGE(L)];  // obs staging, [env][obs_dim], obs_dim <= 64 (only without RSX_DIRECT_OBS)
@@ -315,6 +321,38 @@ __device__ __forceinline__ bool vss_sweep_loop(Body& o, const int N, const int g
 }
 
 // What the kicker / dribbler of some robot decided for the ball in the first sweep of a sub-step
+// u[j] = bits(|p_j - p_o|^2) - 1 for the SLOTS bodies of the lane's env, two partners per packed-FP32 instruction
+// (v_pk_add / v_pk_mul / v_pk_fma are IEEE per component: the same bits as the scalar form), positions from the
+// [env][body] copies in LDS (one 16-byte read = four partners).
+#if RSX_PK_SWEEP
+template <int SLOTS, int L>
+__device__ __forceinline__ void overlap_keys_packed(const Shared<L>& sh, const int g, const float ox, const float oy, uint32_t* u) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    constexpr int Q = (SLOTS + 3) / 4;
+    const f4* X4 = reinterpret_cast<const f4*>(&sh.X[g * L]);
+    const f4* Y4 = reinterpret_cast<const f4*>(&sh.Y[g * L]);
+    f4 xs[Q], ys[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { xs[q] = X4[q]; ys[q] = Y4[q]; }
+    const f2 ox2 = {ox, ox}, oy2 = {oy, oy};
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            const int j = 4 * q + 2 * hlf;
+            if (j >= SLOTS) continue;
+            const f2 px = hlf ? xs[q].zw : xs[q].xy, py = hlf ? ys[q].zw : ys[q].xy;
+            const f2 dx = px - ox2, dy = py - oy2;
+            const f2 t = dy * dy;
+            const f2 d2 = __builtin_elementwise_fma(dx, dx, t);
+            u[j] = __float_as_uint(d2.x) - 1u;
+            if (j + 1 < SLOTS) u[j + 1] = __float_as_uint(d2.y) - 1u;
+        }
+    }
+}
+#endif
+
 struct BallOverride { bool ovr, okick; float ovx, ovy, ovz; };
 
 // SSL contact sweep.  Robot lanes: robot-robot pairs (circles), then the robot's own robot-ball
@@ -337,15 +375,19 @@ __device__ __forceinline__ bool ssl_sweep(const Params& P, Body& o, const int N,
     if (is_robot) {
         unsigned todo = 0;
         if (NRX) {
+            uint32_t u[NRX ? NRX : 1];   // exact integer form of 0 < d2 < rs_rr^2, see the VSS sweep
+#if RSX_PK_SWEEP
+            overlap_keys_packed<(NRX ? NRX : 1), L>(sh, g, o.x, o.y, u);
+#else
             float4 oth[NRX ? NRX : 1];  // all reads in flight together, one wait
 #pragma unroll
             for (int j = 0; j < NRX; ++j) oth[j] = sh.A[j * G + g];
-            uint32_t u[NRX ? NRX : 1];   // exact integer form of 0 < d2 < rs_rr^2, see the VSS sweep
 #pragma unroll
             for (int j = 0; j < NRX; ++j) {
                 float dx = oth[j].x - o.x, dy = oth[j].y - o.y;
                 u[j] = __float_as_uint(fma_(dx, dx, dy * dy)) - 1u;
             }
+#endif
             uint32_t um = u[0];
 #pragma unroll
             for (int j = 1; j < NRX; ++j) um = min(um, u[j]);
@@ -542,6 +584,9 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
             if (active) {
                 sh.A[lane] = make_float4(o.x, o.y, o.vx, o.vy);
                 sh.W[lane] = o.om;   // yaw rate / spin: read on the contact path only
+#if RSX_PK_SWEEP
+                sh.X[g * L + b] = o.x; sh.Y[g * L + b] = o.y;
+#endif
             }
             wave_sync();
             if (sweep == 0) ball_low = sh.zb[g] < K::robot_h;
@@ -551,9 +596,11 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                 // every pair is circle-circle; only the constants depend on the pair type
                 if (active) {
                     if (NR) {
+#if !RSX_PK_SWEEP
                         float4 oth[NR + 1];  // all reads in flight together, one wait
 #pragma unroll
                         for (int j = 0; j <= NR; ++j) oth[j] = sh.A[j * G + g];
+#endif
                         // Overlap test of the whole sweep, exact and with ONE compare per partner class:
                         // d2 is a sum of squares (>= +0), and non-negative floats order like their bit
                         // patterns, so with u = bits(d2) - 1 (d2 == 0, the lane's own slot, wraps to
@@ -563,11 +610,15 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                         constexpr uint32_t T_RR = __builtin_bit_cast(uint32_t, K::rs_rr2) - 1u;
                         constexpr uint32_t T_RB = __builtin_bit_cast(uint32_t, K::rs_rb2) - 1u;
                         uint32_t u[NR + 1];
+#if RSX_PK_SWEEP
+                        overlap_keys_packed<NR + 1, L>(sh, g, o.x, o.y, u);
+#else
 #pragma unroll
                         for (int j = 0; j <= NR; ++j) {
                             float dx = oth[j].x - o.x, dy = oth[j].y - o.y;
                             u[j] = __float_as_uint(fma_(dx, dx, dy * dy)) - 1u;
                         }
+#endif
                         uint32_t um = u[0];
 #pragma unroll
                         for (int j = 1; j < NR; ++j) um = min(um, u[j]);
