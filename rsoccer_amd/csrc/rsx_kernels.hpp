@@ -552,25 +552,24 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
             }
             o.vx = fma_(vf, o.c, -(vl * o.s));
             o.vy = fma_(vf, o.s, vl * o.c);
-            o.x = fma_(o.vx, P.h, o.x);
-            o.y = fma_(o.vy, P.h, o.y);
             o.th = fma_(o.om, P.h_deg, o.th);
             if (o.th > 180.0f) o.th = o.th - 360.0f;
             else if (o.th < -180.0f) o.th = o.th + 360.0f;
             rotate_heading(o.om * P.h, o.c, o.s);
-        } else if (is_ball) {
-            if (RSX_RARE_B(KIND, 1, o.z > 0.0f || o.vz > 0.0f)) {
-                o.vz = o.vz - P.g_h;
-                o.z = fma_(o.vz, P.h, o.z);
-                if (o.z <= 0.0f) {
-                    o.z = 0.0f;
-                    o.vz = -o.vz * K::e_ground;
-                    if (o.vz < K::vz_min) o.vz = 0.0f;
-                }
-            }
-            o.x = fma_(o.vx, P.h, o.x);
-            o.y = fma_(o.vy, P.h, o.y);
         }
+        if (RSX_RARE_B(KIND, 1, is_ball && (o.z > 0.0f || o.vz > 0.0f))) {   // the ball in flight
+            o.vz = o.vz - P.g_h;
+            o.z = fma_(o.vz, P.h, o.z);
+            if (o.z <= 0.0f) {
+                o.z = 0.0f;
+                o.vz = -o.vz * K::e_ground;
+                if (o.vz < K::vz_min) o.vz = 0.0f;
+            }
+        }
+        // the position advance is the same instruction pair for robots and the ball, outside the role branches
+        // (every role branch of a lane group costs a save / branch / restore of the exec mask; idle lanes hold zeros)
+        o.x = fma_(o.vx, P.h, o.x);
+        o.y = fma_(o.vy, P.h, o.y);
 
         // ---- B: contacts — one Jacobi sweep over the post-integration snapshot, and a second one
         // over the corrected snapshot for the envs in which some pair overlapped by more than pen2
@@ -691,7 +690,9 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
         }
 
         // ---- C: walls ----
-        if (is_robot || is_ball) {
+        // SSL: every lane, no role branch (idle lanes hold zeros: inside every wall) — measured 1-3 % on the SSL tasks;
+        // the VSS-v0 3v3 single-step kernel measured 1.5 % slower that way and keeps the branch
+        if (KIND == RSX_KIND_SSL || is_robot || is_ball) {
             const float vx0 = o.vx, vy0 = o.vy;
             int hit = 0;
             walls<KIND>(P, is_ball ? K::r_ball : K::r_robot, is_ball ? K::e_wb : K::e_wr, o.x, o.y, o.vx, o.vy, hit);
