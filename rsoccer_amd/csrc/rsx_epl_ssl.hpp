@@ -6,19 +6,18 @@
 // (reference: ssl/ssl_hw_challenge/{static_defenders,dribbling,contested_possession,pass_endurance}.py
 // around robosim.SSL.step, rsim.py:155,158); the task arithmetic itself (agent commands, observation,
 // reward / termination, placement) is the SAME code: ssl_agent_commands, write_obs_nb, task_reward and
-// place_env of rsx_kernels.hpp.  Other mapping: lane = env, a wave owns 64 envs and walks the 8 bodies of each one after the other.  The
-// 8-lane layout has no idle lane here, but its ball lane and robot lanes run different code one after
-// the other and every robot pair is tested from both sides; at scale that kernel is VALU-bound
-// (DESIGN.md 5).  Results are bit-identical: every body sums its partners in index order (robot-robot
-// pairs first, then the ball), the ball sums the robots' records in robot order, each side of a pair
-// evaluates its own response with the same expressions, draws use the same Philox counters
-// (tests/test_gpu_parity.py::test_env_per_lane_layout_is_bit_identical).
+// place_env of rsx_kernels.hpp.  Other mapping: lane = env, a wave owns 64 envs and walks the bodies of each
+// one after the other.  The 8-lane layout runs its ball lane and its robot lanes one after the other and tests
+// every robot pair from both sides; at scale that kernel is VALU-bound.  Results are bit-identical:
+// every body sums its partners in index order (robot-robot pairs first, then the ball), the ball sums the robots'
+// records in robot order, each side of a pair evaluates its own response with the same expressions, draws use
+// the same Philox counters (tests/test_gpu_parity.py::test_env_per_lane_layout_is_bit_identical).
 //
-// What differs from the VSS kernel: holonomic actuation (only blue 0 is driven by the agent: the other
-// robots hold still unless they are hit; pass endurance keeps the receiver's dribbler on), the kicker mouth / infrared / kick / dribbler of the robot-ball
-// contact (evaluated only for robots whose centre is within 13 cm of the ball: a mouth or infrared
-// contact needs < 12.6 cm), the ball's flight, SSL walls, eleven state rows per robot (infrared and
-// four wheel speeds are outputs: written every step, read only when the step has no physics).
+// What differs from the VSS kernel: holonomic actuation (only blue 0 is driven by the agent: the other robots
+// hold still unless they are hit; pass endurance keeps the receiver's dribbler on), the kicker mouth / infrared /
+// kick / dribbler of the robot-ball contact (evaluated only for robots whose centre is within 13 cm of the ball:
+// a mouth or infrared contact needs < 12.6 cm), the ball's flight, SSL walls, eleven state rows per robot
+// (infrared and four wheel speeds are outputs: written every step, read only when the step has no physics).
 #pragma once
 #include "rsx_kernels.hpp"
 
