@@ -223,8 +223,7 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
                 o.x = fma_(o.vx, P.h, o.x);
                 o.y = fma_(o.vy, P.h, o.y);
                 o.th = fma_(o.om, P.h_deg, o.th);
-                if (o.th > 180.0f) o.th = o.th - 360.0f;
-                else if (o.th < -180.0f) o.th = o.th + 360.0f;
+                o.th = wrap_deg(o.th);
                 rotate_heading(o.om * P.h, o.c, o.s);
             }
             if (ball.z > 0.0f || ball.vz > 0.0f) {

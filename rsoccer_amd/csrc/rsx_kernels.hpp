@@ -553,8 +553,7 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
             o.vx = fma_(vf, o.c, -(vl * o.s));
             o.vy = fma_(vf, o.s, vl * o.c);
             o.th = fma_(o.om, P.h_deg, o.th);
-            if (o.th > 180.0f) o.th = o.th - 360.0f;
-            else if (o.th < -180.0f) o.th = o.th + 360.0f;
+            o.th = wrap_deg(o.th);
             rotate_heading(o.om * P.h, o.c, o.s);
         }
         if (RSX_RARE_B(KIND, 1, is_ball && (o.z > 0.0f || o.vz > 0.0f))) {   // the ball in flight

@@ -56,6 +56,14 @@ __device__ __forceinline__ void sincos_f32(float a, float& s, float& c) {
     c = (q == 1 || q == 2) ? -cc : cc;
 }
 
+// heading in degrees back into (-180, 180] after one sub-step's turn: "if (th > 180) th -= 360; else if (th < -180)
+// th += 360" as two selects — the same values (both candidates are computed, one is picked), but no branch: the
+// compiler turned the if / else-if into two save / restore sequences of the exec mask per robot and sub-step
+__device__ __forceinline__ float wrap_deg(float th) {
+    const float lo = th - 360.0f, hi = th + 360.0f;
+    return th > 180.0f ? lo : (th < -180.0f ? hi : th);
+}
+
 // heading after a small turn d (rad): rotate (c, s) by sin / cos of d (|d| < 0.5; odd / even
 // Taylor polynomials, error < 1e-8) — one exact sincos per step(), cheap rotations per sub-step
 __device__ __forceinline__ void rotate_heading(float d, float& c, float& s) {
