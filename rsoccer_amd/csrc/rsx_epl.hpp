@@ -284,8 +284,8 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
                     float wi = 0.0f, wj = 0.0f;
 #pragma unroll
                     for (int k = 0; k < N; ++k) {   // i < N always; j may be the ball
-                        if (i == k) { bi.x = r[k].x; bi.y = r[k].y; bi.vx = r[k].vx; bi.vy = r[k].vy; wi = r[k].om; }
-                        if (j == k) { bj.x = r[k].x; bj.y = r[k].y; bj.vx = r[k].vx; bj.vy = r[k].vy; wj = r[k].om; }
+                        { const bool m = i == k; bi.x = m ? r[k].x : bi.x; bi.y = m ? r[k].y : bi.y; bi.vx = m ? r[k].vx : bi.vx; bi.vy = m ? r[k].vy : bi.vy; wi = m ? r[k].om : wi; }   // selects, not branches
+                        { const bool m = j == k; bj.x = m ? r[k].x : bj.x; bj.y = m ? r[k].y : bj.y; bj.vx = m ? r[k].vx : bj.vx; bj.vy = m ? r[k].vy : bj.vy; wj = m ? r[k].om : wj; }
                     }
                     if (j == N) { bj.x = ball.x; bj.y = ball.y; bj.vx = ball.vx; bj.vy = ball.vy; wj = ball.om; }
                     const float rs = rb ? K::rs_rb : K::rs_rr, ope = rb ? K::ope_rb : K::ope_rr;

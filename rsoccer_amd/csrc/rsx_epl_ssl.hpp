@@ -298,8 +298,8 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
                     float wi = 0.0f, wj = 0.0f;
 #pragma unroll
                     for (int k = 0; k < N; ++k) {
-                        if (i == k) { bi.x = r[k].x; bi.y = r[k].y; bi.vx = r[k].vx; bi.vy = r[k].vy; wi = r[k].om; }
-                        if (j == k) { bj.x = r[k].x; bj.y = r[k].y; bj.vx = r[k].vx; bj.vy = r[k].vy; wj = r[k].om; }
+                        { const bool m = i == k; bi.x = m ? r[k].x : bi.x; bi.y = m ? r[k].y : bi.y; bi.vx = m ? r[k].vx : bi.vx; bi.vy = m ? r[k].vy : bi.vy; wi = m ? r[k].om : wi; }   // selects, not branches
+                        { const bool m = j == k; bj.x = m ? r[k].x : bj.x; bj.y = m ? r[k].y : bj.y; bj.vx = m ? r[k].vx : bj.vx; bj.vy = m ? r[k].vy : bj.vy; wj = m ? r[k].om : wj; }
                     }
                     float unused = 0.0f;
                     {
@@ -328,7 +328,7 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
                     float kick_x = 0.0f, kick_z = 0.0f; int drib = 0;
 #pragma unroll
                     for (int q = 0; q < N; ++q)
-                        if (k == q) { o.x = r[q].x; o.y = r[q].y; o.vx = r[q].vx; o.vy = r[q].vy; o.om = r[q].om; o.c = r[q].c; o.s = r[q].s; }
+                        { const bool m = k == q; o.x = m ? r[q].x : o.x; o.y = m ? r[q].y : o.y; o.vx = m ? r[q].vx : o.vx; o.vy = m ? r[q].vy : o.vy; o.om = m ? r[q].om : o.om; o.c = m ? r[q].c : o.c; o.s = m ? r[q].s : o.s; }
 #pragma unroll
                     for (int q = 0; q < NCMD; ++q)   // the other robots get zero commands
                         if (k == q) { kick_x = r[q].kick_x; kick_z = r[q].kick_z; drib = r[q].drib; }
