@@ -64,8 +64,9 @@ __device__ __forceinline__ void epl_store_row(float* dst, const float* ob) {   /
 // pair p -> (i, j), i < j, lexicographic: every body then receives its partners in index order
 __device__ __forceinline__ void epl_pair(int p, int& i, int& j) {
     // rows of the upper triangle of a 7 x 7 matrix start at 0, 6, 11, 15, 18, 20
-    i = p >= 20 ? 5 : p >= 18 ? 4 : p >= 15 ? 3 : p >= 11 ? 2 : p >= 6 ? 1 : 0;
-    const int start = i == 0 ? 0 : i == 1 ? 6 : i == 2 ? 11 : i == 3 ? 15 : i == 4 ? 18 : 20;
+    // (sums of comparisons and the closed form of the row start: the nested ?: chains compiled to exec-mask branches)
+    i = (int)(p >= 6) + (int)(p >= 11) + (int)(p >= 15) + (int)(p >= 18) + (int)(p >= 20);
+    const int start = i * 7 - ((i * (i + 1)) >> 1);
     j = i + 1 + (p - start);
 }
 

@@ -60,12 +60,9 @@ __device__ __forceinline__ void sepl_store_row(float* dst, const float* ob) {
 template <int N>
 __device__ __forceinline__ void sepl_pair(int p, int& i, int& j) {
     i = 0;
-    int start = 0;
 #pragma unroll
-    for (int r = 1; r < N - 1; ++r) {
-        const int rs = r * N - r * (r + 1) / 2;
-        if (p >= rs) { i = r; start = rs; }
-    }
+    for (int r = 1; r < N - 1; ++r) i += (int)(p >= r * N - r * (r + 1) / 2);   // sums of comparisons: no branches
+    const int start = i * N - ((i * (i + 1)) >> 1);
     j = i + 1 + (p - start);
 }
 // bits of the pair set that involve robot k
