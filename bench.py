@@ -165,28 +165,63 @@ def roofline_of(envs, launch_us, units_per_launch, mode, traffic=None, traffic_s
     return r
 
 
+def rank_logger(rank, world, tag=""):
+    """per-rank diagnostics go to stderr with a prefix (stdout carries rank 0's JSON line only)"""
+    def log(msg):
+        print(f"[bench rank {rank}/{world}{' ' + tag if tag else ''}] {msg}", file=sys.stderr, flush=True)
+    return log
+
+
+def efficiency_vs_n1(value, world):
+    """value / (N x the N=1 value) when the N=1 figure is known: RSX_BENCH_N1_VALUE, else the newest profiles/r*_bench.json"""
+    n1, src = None, None
+    if os.environ.get("RSX_BENCH_N1_VALUE"):
+        try:
+            n1, src = float(os.environ["RSX_BENCH_N1_VALUE"]), "RSX_BENCH_N1_VALUE"
+        except ValueError:
+            pass
+    if n1 is None:
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_driver_flags.json")), reverse=True):
+            try:
+                d = json.load(open(path))
+                if d.get("n_gpus") == 1 and d.get("value"):
+                    n1, src = float(d["value"]), os.path.relpath(path, ROOT)
+                    break
+            except Exception:
+                continue
+    if not n1 or world < 1:
+        return None
+    return {"efficiency_vs_n1": value / (world * n1), "n1_value": n1, "n1_source": src}
+
+
 def dry_run(args, rank, world):
-    """Launcher / collective plumbing without a GPU (CPU test of `--gpus N`): gloo ranks shard the env
-    ids, all-reduce a metrics vector and rank 0 prints the line."""
+    """Launcher / collective plumbing without a GPU (CPU test of `--gpus N`): the ranks shard the env ids, set up
+    the metrics collective exactly like a real run (RCCL cannot come up without a device, so this exercises the
+    degraded mode: gloo carries the 64 bytes and the line says why), all-reduce a metrics vector and rank 0 prints
+    the line."""
     import torch
-    import torch.distributed as dist
     from rsoccer_amd import dist as rdist
+    log = rank_logger(rank, world, "dry-run")
+    coll = None
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        coll = rdist.MetricsCollective(rank, world, device=None, prefer="nccl", timeout_s=args.rccl_timeout,
+                                       simulate_failure=args.simulate_rccl_failure, log=log)
     base, count = rdist.shard(world * args.envs, rank, world)
     m = torch.zeros(8, dtype=torch.int64)
     m[0] = count * args.steps
     m[7] = base
-    if world > 1:
-        dist.all_reduce(m)
-        dist.barrier()
+    if coll:
+        coll.all_reduce(m)
+        coll.barrier()
     if rank == 0:
-        print(json.dumps({"metric": METRIC, "dry_run": True, "n_gpus": world, "steps": args.steps,
-                          "warmup": args.warmup, "env_steps_counted": int(m[0]),
-                          "env_id_bases_sum": int(m[7])}), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+        line = {"metric": METRIC, "dry_run": True, "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "env_steps_counted": int(m[0]), "env_id_bases_sum": int(m[7])}
+        if coll:
+            line["collective"] = {"backend": coll.describe(), "ranks": world, "rccl_ranks": coll.rccl_ranks}
+        print(json.dumps(line), flush=True)
+    if coll:
+        coll.close()
 
 
 def main():
@@ -200,6 +235,9 @@ def main():
     ap.add_argument("--no-rollout", action="store_true", help="skip the extra one-launch rollout leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the steady / sweep / python_layer legs")
     ap.add_argument("--dry-run", action="store_true", help="launcher + collective plumbing only (no GPU)")
+    ap.add_argument("--simulate-rccl-failure", default=None, metavar="all|RANK",
+                    help="make the RCCL probe fail (on every rank, or on one): tests the degraded mode (metrics over gloo)")
+    ap.add_argument("--rccl-timeout", type=float, default=60.0, help="seconds the RCCL probe may take before gloo takes over")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -215,8 +253,9 @@ def main():
     ensure_built(local_rank)
 
     import torch
-    import torch.distributed as dist
     from rsoccer_amd import _lib as L
+    from rsoccer_amd import dist as rdist
+    log = rank_logger(rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the step engine has no CPU path")
     ndev = torch.cuda.device_count()
@@ -227,14 +266,16 @@ def main():
         raise SystemExit(f"--gpus {world} but only {ndev} device(s) visible")
     dev = local_rank % ndev
     torch.cuda.set_device(dev)
+    dev_tag = rdist.device_tag(dev)
     # RSX_BENCH_FORCE_DIST=1 runs the RCCL path even with one rank (used to test it on a 1-GPU box)
     distributed = world > 1 or os.environ.get("RSX_BENCH_FORCE_DIST") == "1"
-    backend = "gloo" if share else "nccl"
+    coll = None
     if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        kw = {"device_id": torch.device("cuda", dev)} if backend == "nccl" else {}
-        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        log(f"{dev_tag}; {ndev} device(s) visible; HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}")
+        coll = rdist.MetricsCollective(rank, world, device=dev, prefer="gloo" if share else "nccl",
+                                       timeout_s=args.rccl_timeout, simulate_failure=args.simulate_rccl_failure, log=log)
+        log(f"metrics collective: {coll.describe()} ({coll.rccl_ranks}/{world} ranks on RCCL)")
+    on_rccl = coll is not None and coll.backend == "rccl"
 
     B, K, W = args.envs, args.steps, args.warmup
     sim = L.Sim(L.KIND_VSS, 0, 3, 3, 25, B, dev)
@@ -242,7 +283,7 @@ def main():
     tens = sim.task_tensors()
     stream = torch.cuda.current_stream().cuda_stream
     sim.task_reset(stream)
-    mbuf = torch.zeros(L.N_METRICS, dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+    mbuf = torch.zeros(L.N_METRICS, dtype=torch.int64, device=coll.buffer_device() if coll else "cpu")
 
     def allreduce_metrics():
         """The only inter-GPU exchange: sum of the 8-entry int64 metrics vector (64 bytes), all eight
@@ -251,8 +292,8 @@ def main():
         costs ~200 us of stream time, so the async_op=True / side-stream forms of torch.distributed
         (which record events) are 3 orders of magnitude more expensive than the ~20 us collective."""
         sim.metrics_fold(stream)
-        mbuf.copy_(tens["metrics"], non_blocking=backend == "nccl")
-        dist.all_reduce(mbuf)
+        mbuf.copy_(tens["metrics"], non_blocking=on_rccl)   # degraded mode (gloo): a synchronous 64-byte read-back
+        coll.all_reduce(mbuf)
 
     stepped = [0]   # per-step launches of `sim` so far: the all-reduce falls on every ALLREDUCE_EVERY-th of them
 
@@ -272,7 +313,7 @@ def main():
 
     def barrier():
         if distributed:
-            dist.barrier()
+            coll.barrier()
         torch.cuda.synchronize()
 
     def timed(s, n, warm, mode):
@@ -294,7 +335,7 @@ def main():
         dev_ms = ev0.elapsed_time(ev1)
         if distributed:
             t = torch.tensor([wall], dtype=torch.float64, device=mbuf.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            coll.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             wall = float(t.item())
         return wall, dev_ms
 
@@ -303,8 +344,10 @@ def main():
     if distributed:
         g = torch.zeros(world, dtype=torch.float64, device=mbuf.device)
         g[rank] = dev_ms / K
-        dist.all_reduce(g)
+        coll.all_reduce(g)
         per_rank_ms = [float(x) for x in g.cpu()]
+        tags = [None] * world
+        torch.distributed.all_gather_object(tags, dev_tag, group=coll.ctl)
     extra = not args.no_extra and args.mode == "step"
     steady = None
     if extra and (K < STEADY_STEPS or W < STEADY_WARMUP):
@@ -314,7 +357,7 @@ def main():
     metrics = sim.read_metrics()
     if distributed:
         mt = torch.from_numpy(metrics).to(mbuf.device)
-        dist.all_reduce(mt)
+        coll.all_reduce(mt)
         metrics = mt.cpu().numpy()
 
     line = None
@@ -346,10 +389,14 @@ def main():
             "episodes": int(metrics[1]), "env_steps_counted": int(metrics[0]),
         }
         if distributed:
-            line["collective"] = {"backend": "rccl" if backend == "nccl" else "gloo (shared device, test mode)",
-                                  "ranks": world, "payload_bytes": 8 * L.N_METRICS, "every_steps": ALLREDUCE_EVERY,
+            line["collective"] = {"backend": "gloo (shared device, test mode)" if share else coll.describe(),
+                                  "ranks": world, "rccl_ranks": coll.rccl_ranks, "devices": tags,
+                                  "payload_bytes": 8 * L.N_METRICS, "every_steps": ALLREDUCE_EVERY,
                                   "allreduces_in_timed_region": (W + K) // ALLREDUCE_EVERY - W // ALLREDUCE_EVERY,
                                   "per_rank_ms_per_step": per_rank_ms}
+            eff = efficiency_vs_n1(value, world)
+            if eff:
+                line.update(eff)
         if steady is not None:
             sw, sd = steady
             line["steady"] = {"value": world * B * STEADY_STEPS / sw, "unit": "env-steps/s", "steps": STEADY_STEPS,
@@ -377,8 +424,11 @@ def main():
     if rank == 0:
         print(json.dumps(line), flush=True)
     if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+        coll.close()
+        if coll.reason is not None and not share:
+            # degraded mode: a wedged RCCL communicator may hang the interpreter's teardown — everything is printed
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(0)
 
 
 def sweep(L, torch, dev, timed, n=100, warm=30):

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define RSX_ABI_VERSION 2
+#define RSX_ABI_VERSION 3
 
 /* kind: which robosim class the handle stands for (rsim.py:116 robosim.VSS, :169 robosim.SSL) */
 #define RSX_KIND_VSS 0
@@ -220,22 +220,6 @@ int rsx_task_step_n(rsx_sim* h, int n, void* stream);
  * steps; obs / reward / done buffers hold the values of the last step). */
 int rsx_task_rollout(rsx_sim* h, int n, void* stream);
 
-/* ---- serving: policy-in-the-loop stepping without a kernel boundary per step ----------------- *
- * rsx_serve_start launches ONE persistent kernel (on a stream of the handle's own) that keeps the
- * state in registers and waits for doorbells.  rsx_serve_step(actions_dev, stream) is stream-ordered
- * on the CALLER's stream: (copy the actions into the handle's action buffer unless they already are
- * task_view.actions,) ring the doorbell, wait for the step's completion counter — two one-thread
- * kernels, no host synchronisation, no state reload, no grid launch.  Work enqueued on
- * `stream` afterwards sees the observations / rewards / flags of that step in the task view.  Results
- * are bit-identical to rsx_task_step with the same actions.  While serving, every other call on the
- * handle returns RSX_ERR_STATE; rsx_serve_stop stores the state back and ends the kernel.  The kernel
- * also ends by itself when no doorbell arrives for timeout_ms (<= 0: 2000): a lost caller must not
- * keep the GPU busy; the next rsx_serve_step then reports RSX_ERR_STATE.
- * Supported: VSS-v0 3v3 and SSLStaticDefenders 1v6, at most 32768 envs per handle. */
-int rsx_serve_start(rsx_sim* h, int timeout_ms);
-int rsx_serve_step(rsx_sim* h, const float* actions_dev, void* stream);
-int rsx_serve_stop(rsx_sim* h);
-
 /* Debugging aid: number of non-finite floats in the state rows and, with a task attached, in the
  * observations, rewards and info rows.  Synchronises `stream`.  With RSX_DEBUG_FINITE=1 in the
  * environment every stepping call (rsx_step_dev, rsx_task_step, rsx_task_step_n, rsx_task_rollout)
@@ -243,10 +227,6 @@ int rsx_serve_stop(rsx_sim* h);
  * guard: e.g. rsoccer_gym/vss/env_vss/vss_gym.py:298 divides by a distance that can be zero). */
 int rsx_check_finite(rsx_sim* h, int64_t* n_bad, void* stream);
 
-/* metrics, int64[RSX_METRICS], accumulated on device since attach (payload of the multi-GPU
- * all-reduce): 0 env_steps, 1 episodes, 2 goals_for (blue), 3 goals_against (yellow),
- * 4 sum of episode returns in 2^-20 fixed point, 5 sum of episode lengths,
- * 6 truncated episodes, 7 reserved.  Synchronises `stream`. */
 /* ---- checkpoint / resume of a fused run ----------------------------------------------------
  * (the reference cannot: robosim exposes no way to restore velocities, rsim.py:52-75, and its tasks keep their
  * episode state — OU noise, step counters, cumulative reward terms — in Python attributes.)
@@ -260,6 +240,10 @@ int rsx_task_checkpoint_size(rsx_sim* h, size_t* bytes);
 int rsx_task_checkpoint_save(rsx_sim* h, void* blob, size_t bytes, void* stream);
 int rsx_task_checkpoint_load(rsx_sim* h, const void* blob, size_t bytes, void* stream);
 
+/* metrics, int64[RSX_METRICS], accumulated on device since attach (payload of the multi-GPU
+ * all-reduce): 0 env_steps, 1 episodes, 2 goals_for (blue), 3 goals_against (yellow),
+ * 4 sum of episode returns in 2^-20 fixed point, 5 sum of episode lengths,
+ * 6 truncated episodes, 7 reserved.  Synchronises `stream`. */
 int rsx_read_metrics(rsx_sim* h, int64_t out[RSX_METRICS], void* stream);
 /* Device-side readers of rsx_task_view.metrics (e.g. an RCCL all-reduce of the 64 bytes) call this
  * first: one tiny launch on `stream` that adds the step kernels' partial episode counters into

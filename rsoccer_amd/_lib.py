@@ -36,7 +36,6 @@ SYMBOLS = (
     "rsx_task_view_get", "rsx_task_reset", "rsx_task_reset_to", "rsx_task_step",
     "rsx_task_step_n", "rsx_task_rollout", "rsx_read_metrics", "rsx_metrics_fold", "rsx_check_finite",
     "rsx_task_checkpoint_size", "rsx_task_checkpoint_save", "rsx_task_checkpoint_load",
-    "rsx_serve_start", "rsx_serve_step", "rsx_serve_stop",
 )
 
 
@@ -105,10 +104,7 @@ def load():
     lib.rsx_task_checkpoint_save.argtypes = [vp, vp, C.c_size_t, vp]
     lib.rsx_task_checkpoint_load.argtypes = [vp, vp, C.c_size_t, vp]
     lib.rsx_check_finite.argtypes = [vp, C.POINTER(C.c_int64), vp]
-    lib.rsx_serve_start.argtypes = [vp, ip]
-    lib.rsx_serve_step.argtypes = [vp, vp, vp]
-    lib.rsx_serve_stop.argtypes = [vp]
-    if lib.rsx_abi_version() != 2:
+    if lib.rsx_abi_version() != 3:
         raise RsxError("librsx_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -329,18 +325,6 @@ class Sim:
 
     def task_rollout(self, n, stream=None):
         _chk(self._lib.rsx_task_rollout(self._h, int(n), self._stream(stream)))
-
-    def serve_start(self, timeout_ms=2000):
-        """persistent kernel: steps are requested with serve_step() (doorbell), no launch per step"""
-        _chk(self._lib.rsx_serve_start(self._h, int(timeout_ms)))
-
-    def serve_step(self, actions_ptr, stream=None):
-        rc = self._lib.rsx_serve_step(self._h, actions_ptr, stream)
-        if rc:
-            _chk(rc)
-
-    def serve_stop(self):
-        _chk(self._lib.rsx_serve_stop(self._h))
 
     def check_finite(self, stream=None):
         """Number of non-finite floats in state / obs / reward / info (debugging aid; synchronises)."""

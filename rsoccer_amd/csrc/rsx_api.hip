@@ -52,6 +52,7 @@ struct rsx_sim {
     Params P;
     HostModel M;
     int device = 0;
+    int field_type = 0, time_step_ms = 0;   // as given to rsx_create (checkpoint header)
     int L = 8;   // lanes per env
     int NR = 0;  // compile-time robot count of the selected kernel variant (0 = generic)
     bool epl = false;  // VSS-v0 3v3 / the registered SSL tasks: step and rollout launches use the one-lane-per-env kernels (large batches)
@@ -66,7 +67,6 @@ struct rsx_sim {
     unsigned long long* d_metrics = nullptr;
     unsigned long long* d_mslots = nullptr;   // [MSLOTS][RSX_METRICS] partial episode counters (metric_slot)
     unsigned long long* d_check = nullptr;   // rsx_check_finite counter
-    hipStream_t cap_stream = nullptr;   // utility stream (serve stop)
     std::vector<float> h_f32;
     // host-format path: pinned staging; rsx_step() brings the new state back with its own
     // synchronisation, so the rsx_get_state() that follows it (rsim.py:102 then :105) is a pure
@@ -77,14 +77,6 @@ struct rsx_sim {
     bool host_state_valid = false;
     bool host_state_cache = true;
     bool task_ready = false;   // a reset has opened the first episode
-    // persistent serving kernel (rsx_serve_*)
-    bool serving = false;
-    hipStream_t serve_stream = nullptr;
-    unsigned long long* sig_seq = nullptr;    // signal memory: doorbell
-    unsigned long long* sig_done = nullptr;   // signal memory: completion counter
-    unsigned long long serve_req = 0;         // steps requested so far
-    unsigned long long serve_waves = 0;       // waves of the serving grid
-    unsigned long long serve_timeout_ticks = 0;
     uint32_t tick = 0;                        // fused steps taken since attach (key of the per-step draws)
 };
 
@@ -110,20 +102,6 @@ dim3 grid_for(const rsx_sim* h) {
 unsigned long long* g_dbg = nullptr;  // development builds: s_memtime stamps
 #endif
 
-// Serving doorbell and completion wait as one-thread kernels on the caller's stream.  (The stream memory
-// operations hipStreamWriteValue64 / hipStreamWaitValue64 would be the natural tools, but each costs
-// ~1.1 ms on this ROCm stack — measured, tools/exp_serve2.py — against ~2.5 us for a launch.)
-__global__ void serve_ring_kernel(unsigned long long* seq, unsigned long long value) {
-    __hip_atomic_store(seq, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__global__ void serve_wait_kernel(const unsigned long long* done, unsigned long long target, unsigned long long timeout) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__hip_atomic_load(done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < target) {
-        if (__builtin_amdgcn_s_memrealtime() - t0 > timeout) break;   // the serving kernel is gone: do not hang the stream
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
-
 // debugging aid (rsx_check_finite / RSX_DEBUG_FINITE=1): counts the non-finite floats of a buffer
 __global__ void count_nonfinite_kernel(const float* __restrict__ p, size_t n, unsigned long long* out) {
     unsigned long long bad = 0;
@@ -146,7 +124,6 @@ Buffers buffers_of(const rsx_sim* h, const float* actions) {
     Buffers b;
     b.state = h->d_state; b.aux = h->d_aux; b.obs = h->d_obs; b.final_obs = h->d_final_obs;
     b.flags = h->d_flags; b.cmds = h->d_cmds; b.actions = actions; b.metrics = h->d_metrics; b.mslots = h->d_mslots;
-    b.serve_seq = h->sig_seq; b.serve_done = h->sig_done; b.serve_base = 0; b.serve_timeout = 0;
 #ifdef RSX_TIMING
     b.dbg = g_dbg;
 #endif
@@ -159,9 +136,9 @@ void pick_variant(rsx_sim* h) {
     const int N = h->P.n_robots;
     h->NR = 0;
     if (std::getenv("RSX_GENERIC_KERNELS")) return;
-    if (h->P.kind == RSX_KIND_VSS && N == 6 && h->L == 8 && h->P.n_blue == 3) h->NR = 6;
+    if (h->P.kind == RSX_KIND_VSS && N == 6 && (h->L == 8 || h->L == 16) && h->P.n_blue == 3) h->NR = 6;   // 16: RSX_LANES_PER_ENV=16 (four envs per wave)
     if (h->P.kind == RSX_KIND_VSS && N == 10 && h->L == 16 && h->P.n_blue == 5) h->NR = 10;   // 5v5 field
-    if (h->P.kind == RSX_KIND_SSL && N == 7 && h->L == 8) h->NR = 7;
+    if (h->P.kind == RSX_KIND_SSL && N == 7 && (h->L == 8 || h->L == 16)) h->NR = 7;
     if (h->P.kind == RSX_KIND_SSL && N == 12 && h->L == 16) h->NR = 12;   // 6v6 (field_type 0, ssl/README.md:4)
     if (h->P.kind == RSX_KIND_SSL && N == 22 && h->L == 32) h->NR = 22;
 }
@@ -176,9 +153,9 @@ template <int KIND>
 void launch_sim_k(const rsx_sim* h, const Params& P_, float* state_out, int rand_tick, hipStream_t s) {
     const dim3 grid = grid_for(h);
     const Buffers b = buffers_of(h, nullptr);
-    if (KIND == RSX_KIND_VSS && h->NR == 6) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 8, (KIND == RSX_KIND_VSS ? 6 : 0)>), P_, b); return; }
+    if (KIND == RSX_KIND_VSS && h->NR == 6 && h->L == 8) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 8, (KIND == RSX_KIND_VSS ? 6 : 0)>), P_, b); return; }
     if (KIND == RSX_KIND_VSS && h->NR == 10) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 16, (KIND == RSX_KIND_VSS ? 10 : 0)>), P_, b); return; }
-    if (KIND == RSX_KIND_SSL && h->NR == 7) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 8, (KIND == RSX_KIND_SSL ? 7 : 0)>), P_, b); return; }
+    if (KIND == RSX_KIND_SSL && h->NR == 7 && h->L == 8) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 8, (KIND == RSX_KIND_SSL ? 7 : 0)>), P_, b); return; }
     if (KIND == RSX_KIND_SSL && h->NR == 12) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 16, (KIND == RSX_KIND_SSL ? 12 : 0)>), P_, b); return; }
     if (KIND == RSX_KIND_SSL && h->NR == 22) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 32, (KIND == RSX_KIND_SSL ? 22 : 0)>), P_, b); return; }
     switch (h->L) {
@@ -228,6 +205,7 @@ void launch_task_m(const rsx_sim* h, const float* actions, int n_steps, hipStrea
     }
     const dim3 grid = grid_for(h);
     if (NRS <= 7 && h->NR == NRS && h->L == 8) { RSX_LAUNCH((task_step_kernel<KIND, 8, TASK, (NRS <= 7 ? NRS : 0), MODE>), h->P, b, n_steps); return; }
+    if (NRS <= 7 && h->NR == NRS && h->L == 16) { RSX_LAUNCH((task_step_kernel<KIND, 16, TASK, (NRS <= 7 ? NRS : 0), MODE>), h->P, b, n_steps); return; }
     if (TASK == RSX_TASK_SSL_SCRIMMAGE && h->NR == 22 && h->L == 32) {   // 11v11: robot count known at compile time
         RSX_LAUNCH((task_step_kernel<KIND, 32, TASK, (TASK == RSX_TASK_SSL_SCRIMMAGE ? 22 : 0), MODE>), h->P, b, n_steps);
         return;
@@ -307,12 +285,8 @@ struct DeviceGuard {
     DeviceGuard _guard;                                           \
     if (int _rc = _guard.enter((h)->device)) return _rc
 
-#define RSX_NOT_SERVING(h) \
-    if ((h)->serving) return fail(RSX_ERR_STATE, "the handle is serving (rsx_serve_start): only rsx_serve_step / rsx_serve_stop are valid until it stops")
-
 #define RSX_ENTER_TASK(h)                                                                        \
     RSX_ENTER(h);                                                                                \
-    RSX_NOT_SERVING(h);                                                                          \
     (h)->host_state_valid = false; /* every task call may change the state */                    \
     if ((h)->P.task == RSX_TASK_NONE) return fail(RSX_ERR_STATE, "no task attached (rsx_task_attach)")
 
@@ -357,14 +331,9 @@ void apply_reset(const rsx_sim* h, std::vector<float>& soa, const double* ball, 
 }
 
 void free_all(rsx_sim* h) {
-    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     if (h->pin_cmds) (void)hipHostFree(h->pin_cmds);
     if (h->pin_state) (void)hipHostFree(h->pin_state);
     h->pin_cmds = h->pin_state = nullptr;
-    if (h->serve_stream) (void)hipStreamDestroy(h->serve_stream);
-    if (h->sig_seq) (void)hipFree(h->sig_seq);
-    if (h->sig_done) (void)hipFree(h->sig_done);
-    h->serve_stream = nullptr; h->sig_seq = h->sig_done = nullptr;
     if (h->d_state_alt) (void)hipFree(h->d_state_alt);
     h->d_state_alt = nullptr;
     if (h->d_check) (void)hipFree(h->d_check);
@@ -411,8 +380,6 @@ static int debug_finite(rsx_sim* h, hipStream_t s, const char* where) {
     return RSX_OK;
 }
 
-static int serve_stop_impl(rsx_sim* h);
-
 extern "C" {
 
 #ifdef RSX_TIMING
@@ -442,6 +409,7 @@ int rsx_create(rsx_sim** out, int kind, int field_type, int n_blue, int n_yellow
         return fail(RSX_ERR_ARG, "bad simulator configuration (kind / field_type / robot counts / time step / num_envs)");
     }
     h->device = device_id;
+    h->field_type = field_type; h->time_step_ms = time_step_ms;
     h->L = pick_lanes(h->P.n_robots + 1);
     pick_variant(h);
     auto bail = [&](hipError_t e, const char* what) {
@@ -461,7 +429,6 @@ int rsx_create(rsx_sim** out, int kind, int field_type, int n_blue, int n_yellow
     if ((e = hipMemset(h->d_cmds, 0, cbytes)) != hipSuccess) return bail(e, "hipMemset(cmds)");
     if ((e = hipHostMalloc((void**)&h->pin_cmds, cbytes ? cbytes : 4, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc(cmds)");
     if ((e = hipHostMalloc((void**)&h->pin_state, sbytes, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc(state)");
-    if ((e = hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     // the adapter's dummy line-up, rsim.py:20-24
     std::vector<float> soa((size_t)(h->P.state_dim + X_ROWS) * B, 0.0f);
     for (size_t i = 0; i < B; ++i) {
@@ -483,7 +450,6 @@ int rsx_destroy(rsx_sim* h) {
     if (!h) return RSX_OK;
     DeviceGuard guard;
     (void)guard.enter(h->device);
-    (void)serve_stop_impl(h);
     free_all(h);
     delete h;
     return RSX_OK;
@@ -498,7 +464,6 @@ int rsx_get_field_params(const rsx_sim* h, double out[RSX_FIELD_PARAMS]) {
 int rsx_reset(rsx_sim* h, const double* ball, const double* blue, const double* yellow,
               const uint8_t* env_mask, void* stream) {
     RSX_ENTER(h);
-    RSX_NOT_SERVING(h);
     if (!ball || (h->P.n_blue && !blue) || (h->P.n_yellow && !yellow)) return fail(RSX_ERR_ARG, "null placement array");
     hipStream_t s = (hipStream_t)stream;
     std::vector<float> soa;
@@ -510,7 +475,6 @@ int rsx_reset(rsx_sim* h, const double* ball, const double* blue, const double* 
 
 int rsx_step(rsx_sim* h, const double* cmds, void* stream) {
     RSX_ENTER(h);
-    RSX_NOT_SERVING(h);
     if (!cmds) return fail(RSX_ERR_ARG, "cmds is null");
     hipStream_t s = (hipStream_t)stream;
     const Params& P = h->P;
@@ -543,21 +507,18 @@ static int get_state_impl(rsx_sim* h, double* out, int rows, hipStream_t s) {
 
 int rsx_get_state(rsx_sim* h, double* out, void* stream) {
     RSX_ENTER(h);
-    RSX_NOT_SERVING(h);
     if (!out) return fail(RSX_ERR_ARG, "out is null");
     return get_state_impl(h, out, h->P.state_dim, (hipStream_t)stream);
 }
 
 int rsx_get_state_full(rsx_sim* h, double* out, void* stream) {
     RSX_ENTER(h);
-    RSX_NOT_SERVING(h);
     if (!out) return fail(RSX_ERR_ARG, "out is null");
     return get_state_impl(h, out, h->P.state_dim + X_ROWS, (hipStream_t)stream);
 }
 
 int rsx_set_state(rsx_sim* h, const double* state, void* stream) {
     RSX_ENTER(h);
-    RSX_NOT_SERVING(h);
     if (!state) return fail(RSX_ERR_ARG, "state is null");
     const size_t B = (size_t)h->P.num_envs;
     const int rows = h->P.state_dim + X_ROWS;
@@ -578,7 +539,6 @@ int rsx_dev_view_get(rsx_sim* h, rsx_dev_view* out) {
 
 int rsx_step_dev(rsx_sim* h, void* stream) {
     RSX_ENTER(h);
-    RSX_NOT_SERVING(h);
     h->host_state_valid = false;
     launch_sim(h, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
@@ -605,7 +565,6 @@ int rsx_state_buffers(rsx_sim* h, float** current, float** other) {
 
 int rsx_step_dev_random(rsx_sim* h, int n, uint64_t seed, uint32_t first_tick, void* stream) {
     RSX_ENTER(h);
-    RSX_NOT_SERVING(h);
     if (n < 1) return fail(RSX_ERR_ARG, "n must be >= 1");
     if ((uint64_t)first_tick + (uint64_t)n > 0x7FFFFFFFull) return fail(RSX_ERR_ARG, "tick range exceeds 2^31");
     h->host_state_valid = false;
@@ -616,7 +575,6 @@ int rsx_step_dev_random(rsx_sim* h, int n, uint64_t seed, uint32_t first_tick, v
 
 int rsx_step_dev_flip(rsx_sim* h, void* stream) {
     RSX_ENTER(h);
-    RSX_NOT_SERVING(h);
     if (int rc = ensure_alt(h)) return rc;
     h->host_state_valid = false;
     launch_sim(h, (hipStream_t)stream, h->d_state_alt);
@@ -628,7 +586,6 @@ int rsx_step_dev_flip(rsx_sim* h, void* stream) {
 int rsx_reset_dev(rsx_sim* h, const float* ball_dev, const float* blue_dev, const float* yellow_dev,
                   const uint8_t* env_mask_dev, void* stream) {
     RSX_ENTER(h);
-    RSX_NOT_SERVING(h);
     if (!ball_dev || (h->P.n_blue && !blue_dev) || (h->P.n_yellow && !yellow_dev)) return fail(RSX_ERR_ARG, "null placement array");
     h->host_state_valid = false;
     const int B = h->P.num_envs;
@@ -750,90 +707,6 @@ int rsx_task_rollout(rsx_sim* h, int n, void* stream) {
     return debug_finite(h, (hipStream_t)stream, "rsx_task_rollout");
 }
 
-// ---- persistent serving kernel ----------------------------------------------------------------
-static int serve_stop_impl(rsx_sim* h) {
-    if (!h->serving) return RSX_OK;
-    // the stop request goes through a stream-ordered write like every doorbell; the kernel stores the
-    // state and leaves, then the serving stream drains
-    hipLaunchKernelGGL(serve_ring_kernel, dim3(1), dim3(1), 0, h->cap_stream, h->sig_seq, SERVE_STOP | h->serve_req);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(h->cap_stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->serve_stream);
-    h->serving = false;
-    h->tick += (uint32_t)h->serve_req;   // every requested step was served before the kernel left
-    if (e != hipSuccess) return fail(RSX_ERR_HIP, std::string("rsx_serve_stop: ") + hipGetErrorString(e));
-    return RSX_OK;
-}
-
-int rsx_serve_start(rsx_sim* h, int timeout_ms) {
-    RSX_ENTER_TASK(h);
-    RSX_NEED_RESET(h);
-    const Params& P = h->P;
-    const bool vss = P.task == RSX_TASK_VSS_V0 && h->NR == 6 && h->L == 8;
-    const bool sd = P.task == RSX_TASK_SSL_STATIC_DEFENDERS && h->NR == 7 && h->L == 8;
-    if (!vss && !sd) return fail(RSX_ERR_ARG, "serving supports VSS-v0 3v3 and SSLStaticDefenders 1v6 (8 lanes per env)");
-    const dim3 grid = grid_for(h);
-    if (grid.x > 4096) return fail(RSX_ERR_ARG, "serving needs every workgroup resident at once: at most 32768 envs");
-    if (timeout_ms <= 0) timeout_ms = 2000;
-    if (!h->sig_seq) {
-        HIP_TRY(hipExtMallocWithFlags((void**)&h->sig_seq, 8, hipMallocSignalMemory));
-        HIP_TRY(hipExtMallocWithFlags((void**)&h->sig_done, 8, hipMallocSignalMemory));
-    }
-    if (!h->serve_stream) {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // numerically lowest = highest priority
-        int prio = lo;                                     // the serving kernel: lowest priority by default
-        if (const char* p = std::getenv("RSX_SERVE_PRIO")) prio = std::atoi(p);
-        HIP_TRY(hipStreamCreateWithPriority(&h->serve_stream, hipStreamNonBlocking, prio));
-    }
-    HIP_TRY(hipDeviceSynchronize());   // everything issued so far (resets, steps) is in memory
-    const unsigned long long zero = 0;
-    HIP_TRY(hipMemcpy(h->sig_seq, &zero, 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->sig_done, &zero, 8, hipMemcpyHostToDevice));
-    h->serve_req = 0;
-    h->serve_waves = grid.x;
-    Buffers b = buffers_of(h, h->d_actions);
-    h->P.tick_base = h->tick;
-    b.serve_timeout = (unsigned long long)timeout_ms * 100000ull;   // s_memrealtime ticks at 100 MHz
-    h->serve_timeout_ticks = b.serve_timeout;
-    hipStream_t s = h->serve_stream;
-    if (vss) RSX_LAUNCH((task_step_kernel<RSX_KIND_VSS, 8, RSX_TASK_VSS_V0, 6, MODE_SERVE>), h->P, b, 0);
-    else RSX_LAUNCH((task_step_kernel<RSX_KIND_SSL, 8, RSX_TASK_SSL_STATIC_DEFENDERS, 7, MODE_SERVE>), h->P, b, 0);
-    HIP_TRY(hipGetLastError());
-    (void)hipStreamQuery(h->serve_stream);   // make sure the launch is submitted now, not with the caller's next call
-    h->serving = true;
-    return RSX_OK;
-}
-
-int rsx_serve_step(rsx_sim* h, const float* actions_dev, void* stream) {
-    RSX_ENTER(h);
-    if (!h->serving) return fail(RSX_ERR_STATE, "rsx_serve_start first");
-    if (hipStreamQuery(h->serve_stream) != hipErrorNotReady) {   // the kernel left on its own: no request within the timeout
-        h->serving = false;
-        h->tick += (uint32_t)h->serve_req;
-        return fail(RSX_ERR_STATE, "the serving kernel is no longer running (no request within its timeout): state saved, serving ended");
-    }
-    hipStream_t s = (hipStream_t)stream;
-    if (actions_dev && actions_dev != h->d_actions)
-        HIP_TRY(hipMemcpyAsync(h->d_actions, actions_dev, (size_t)h->P.num_envs * h->M.act_dim * sizeof(float), hipMemcpyDeviceToDevice, s));
-    h->serve_req += 1;
-    static const bool memops = std::getenv("RSX_SERVE_MEMOPS") != nullptr;   // development: the stream-memory-operation form (slow)
-    if (memops) {
-        HIP_TRY(hipStreamWriteValue64(s, h->sig_seq, h->serve_req, 0));
-        HIP_TRY(hipStreamWaitValue64(s, h->sig_done, h->serve_req * h->serve_waves, hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull));
-        return RSX_OK;
-    }
-    hipLaunchKernelGGL(serve_ring_kernel, dim3(1), dim3(1), 0, s, h->sig_seq, h->serve_req);
-    hipLaunchKernelGGL(serve_wait_kernel, dim3(1), dim3(1), 0, s, h->sig_done, h->serve_req * h->serve_waves, h->serve_timeout_ticks);
-    HIP_TRY(hipGetLastError());
-    return RSX_OK;
-}
-
-int rsx_serve_stop(rsx_sim* h) {
-    RSX_ENTER(h);
-    return serve_stop_impl(h);
-}
-
 int rsx_check_finite(rsx_sim* h, int64_t* n_bad, void* stream) {
     RSX_ENTER(h);
     if (!n_bad) return fail(RSX_ERR_ARG, "n_bad is null");
@@ -845,19 +718,21 @@ int rsx_check_finite(rsx_sim* h, int64_t* n_bad, void* stream) {
 // ---- task checkpoint: everything a fused run needs to continue bit-identically ----
 namespace {
 struct CkptHeader {
-    uint64_t magic;            // "RSXCKPT1"
+    uint64_t magic;            // "RSXCKPT2"
     int32_t abi, kind, field_rows, task, n_blue, n_yellow, num_envs, state_rows, aux_rows, obs_dim;
+    int32_t field_type, time_step_ms, max_steps, reserved;
     uint32_t key0, key1, env_id_base, tick;
     uint64_t state_bytes, aux_bytes, obs_bytes, flag_bytes;
     int64_t metrics[RSX_METRICS];
 };
-constexpr uint64_t CKPT_MAGIC = 0x3154504B43585352ull;   // "RSXCKPT1", little endian
+constexpr uint64_t CKPT_MAGIC = 0x3254504B43585352ull;   // "RSXCKPT2", little endian
 CkptHeader ckpt_header(const rsx_sim* h) {
     CkptHeader k{};
     const size_t B = (size_t)h->P.num_envs;
     k.magic = CKPT_MAGIC; k.abi = RSX_ABI_VERSION; k.kind = h->P.kind; k.field_rows = h->M.rs; k.task = h->P.task;
     k.n_blue = h->P.n_blue; k.n_yellow = h->P.n_yellow; k.num_envs = h->P.num_envs;
     k.state_rows = h->P.state_dim + X_ROWS; k.aux_rows = aux_rows(h->P.n_robots); k.obs_dim = h->P.obs_dim;
+    k.field_type = h->field_type; k.time_step_ms = h->time_step_ms; k.max_steps = h->P.max_steps; k.reserved = 0;
     k.key0 = h->P.key0; k.key1 = h->P.key1; k.env_id_base = h->P.env_id_base; k.tick = h->tick;
     k.state_bytes = (uint64_t)k.state_rows * B * sizeof(float);
     k.aux_bytes = (uint64_t)k.aux_rows * B * sizeof(float);
@@ -894,6 +769,22 @@ int rsx_task_checkpoint_save(rsx_sim* h, void* blob, size_t bytes, void* stream)
     HIP_TRY(hipMemcpyAsync(k.metrics, h->d_metrics, sizeof(k.metrics), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     std::memcpy(blob, &k, sizeof(k));
+    if (h->P.task == RSX_TASK_VSS_V0) {
+        // The task scalar of VSS-v0 (previous ball potential, vss_gym.py:256-283) is a function of the ball position
+        // the next step starts from; the one-lane-per-env kernel recomputes it instead of keeping the row up to date.
+        // The blob always carries the value, so that it restores into either kernel layout.  Same float expression
+        // as the kernels' (this file is built with -ffp-contract=off; sqrtf is correctly rounded on both sides).
+        const size_t B = (size_t)h->P.num_envs;
+        const float* st = reinterpret_cast<const float*>((const char*)blob + sizeof(CkptHeader));
+        float* aux = reinterpret_cast<float*>((char*)blob + sizeof(CkptHeader) + k.state_bytes);
+        for (size_t e = 0; e < B; ++e) {
+            const float bx = st[e], by = st[B + e];
+            const float dx_d = (h->P.hl_goal + bx) * 100.0f, dx_a = (h->P.hl_goal - bx) * 100.0f, dy = by * 100.0f;
+            const float dy2 = 2.0f * (dy * dy);
+            const float dist_1 = -std::sqrt(dx_a * dx_a + dy2), dist_2 = std::sqrt(dx_d * dx_d + dy2);
+            aux[(size_t)ROW_PREV_POT * B + e] = ((dist_1 + dist_2) * h->P.inv_len_cm - 1.0f) * 0.5f;
+        }
+    }
     return RSX_OK;
 }
 
@@ -907,6 +798,10 @@ int rsx_task_checkpoint_load(rsx_sim* h, const void* blob, size_t bytes, void* s
     if (k.kind != want.kind || k.task != want.task || k.n_blue != want.n_blue || k.n_yellow != want.n_yellow ||
         k.num_envs != want.num_envs || k.state_rows != want.state_rows || k.aux_rows != want.aux_rows || k.obs_dim != want.obs_dim)
         return fail(RSX_ERR_ARG, "the checkpoint was taken from a different configuration (simulator kind, team sizes, batch or task)");
+    if (k.field_type != want.field_type || k.time_step_ms != want.time_step_ms || k.field_rows != want.field_rows)
+        return fail(RSX_ERR_ARG, "the checkpoint was taken with another field type or time step");
+    if (k.max_steps != want.max_steps)
+        return fail(RSX_ERR_ARG, "the checkpoint was taken with another max_episode_steps (TimeLimit)");
     if (k.key0 != want.key0 || k.key1 != want.key1 || k.env_id_base != want.env_id_base)
         return fail(RSX_ERR_ARG, "the checkpoint was taken with another seed or env_id_base: attach the task with the same ones");
     if (bytes < ckpt_size(k)) return fail(RSX_ERR_ARG, "blob is truncated");

@@ -4,10 +4,19 @@
 // small batches but costs these a wave of occupancy.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "rsx_epl.hpp"
 #include "rsx_epl_ssl.hpp"
 
 namespace rsx {
+
+// development knob: RSX_EPL_LDS_PAD=<bytes> of dynamic LDS per workgroup limit the waves per CU (occupancy
+// sensitivity measurements); 0 in production
+static unsigned epl_lds_pad() {
+    static const unsigned pad = std::getenv("RSX_EPL_LDS_PAD") ? (unsigned)std::atoi(std::getenv("RSX_EPL_LDS_PAD")) : 0u;
+    return pad;
+}
 
 void launch_vss_epl(bool rollout, const Params& P, const Buffers& b, int n_steps, hipStream_t s) {
     const int tiles = (P.num_envs + 63) / 64;
@@ -16,7 +25,7 @@ void launch_vss_epl(bool rollout, const Params& P, const Buffers& b, int n_steps
         hipLaunchKernelGGL(vss_epl_rollout_kernel, grid, dim3(64), 0, s, b.state, b.aux, b.actions, b.flags,
                            P.num_envs, P.state_dim, (int)(grid.x >> 3), n_steps, P, b);
     else
-        hipLaunchKernelGGL((vss_epl_kernel<MODE_STEP>), grid, dim3(64), 0, s, b.state, b.aux, b.actions, b.flags,
+        hipLaunchKernelGGL((vss_epl_kernel<MODE_STEP>), grid, dim3(64), epl_lds_pad(), s, b.state, b.aux, b.actions, b.flags,
                            P.num_envs, P.state_dim, (int)(grid.x >> 3), n_steps, P, b);
 }
 

@@ -61,11 +61,6 @@ struct Buffers {
     const float* actions;  // [B][act_dim] or nullptr = random
     unsigned long long* metrics;  // [RSX_METRICS]
     unsigned long long* mslots;   // [MSLOTS][RSX_METRICS]: per-block-group partial sums of the episode counters (see metric_slot)
-    // MODE_SERVE (persistent kernel): doorbell written by the caller's stream, completion counter read by it
-    unsigned long long* serve_seq;   // step number requested so far; bit 63 = stop
-    unsigned long long* serve_done;  // += 1 per wave and step served
-    unsigned long long serve_base;   // steps requested before this launch
-    unsigned long long serve_timeout;  // give up after this many 100 MHz ticks without a request
 #ifdef RSX_TIMING
     unsigned long long* dbg;      // [8][gridDim] s_memtime stamps (development builds only)
 #endif
@@ -1353,25 +1348,13 @@ __device__ __forceinline__ StepDraw draw_for_step(const Params& P, const uint32_
 //   MODE_RESET   reset() with random placement
 //   MODE_REFRESH open a new episode on the state already in the buffers for the envs flagged in
 //                the `truncated` bytes (reset_to); observations recomputed, state untouched
-//   MODE_SERVE   persistent: the state stays in registers like in MODE_ROLLOUT, but every step waits for a
-//                doorbell (a 64-bit sequence number in signal memory, written in stream order by the
-//                caller after its policy has produced the actions), reads the fed actions, and
-//                publishes observation / reward / flags with a system-scope release + a completion
-//                counter the caller's stream waits on.  No kernel boundary per env.step(): no launch,
-//                no L2 write-back / invalidate, no state reload.  Leaves on a stop request or when no
-//                request arrives for serve_timeout ticks (a lost host must not hang the GPU).
-constexpr int MODE_STEP = 0, MODE_RESET = 1, MODE_REFRESH = 2, MODE_ROLLOUT = 3, MODE_SERVE = 4;
-constexpr unsigned long long SERVE_STOP = 1ull << 63;
-#ifndef RSX_SERVE_SLEEP
-#define RSX_SERVE_SLEEP 1   // x 64 cycles between two polls of the doorbell
-#endif
+constexpr int MODE_STEP = 0, MODE_RESET = 1, MODE_REFRESH = 2, MODE_ROLLOUT = 3;
 
 template <int KIND, int L, int TASK, int NR, int MODE>
 __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
     // A multi-step launch is short of SGPRs, not of start-up latency: there the preloaded copies
     // are left dead and everything is fetched from the kernarg segment when it is needed.
-    constexpr bool HOT = MODE != MODE_ROLLOUT && MODE != MODE_SERVE;
-    constexpr bool SERVE = MODE == MODE_SERVE;
+    constexpr bool HOT = MODE != MODE_ROLLOUT;
     constexpr bool DOBS = RSX_DIRECT_OBS != 0;
     Params P = P_;
     Buffers bufs = bufs_;
@@ -1380,9 +1363,8 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
         bufs.state = hp_state; bufs.aux = hp_aux; bufs.actions = hp_in; bufs.flags = hp_flags;
     }
     const int n_steps_arg = hp_n_steps;
-    constexpr int mode = (MODE == MODE_ROLLOUT || SERVE) ? MODE_STEP : MODE;
-    const int n_steps = MODE == MODE_ROLLOUT ? n_steps_arg : (SERVE ? 0x7FFFFFFF : 1);
-    int served = 0;   // MODE_SERVE: steps done by this launch
+    constexpr int mode = MODE == MODE_ROLLOUT ? MODE_STEP : MODE;
+    const int n_steps = MODE == MODE_ROLLOUT ? n_steps_arg : 1;
     using K = KC<KIND>;
     using T = TC<TASK>;
     constexpr int G = 64 / L;
@@ -1441,7 +1423,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
     }
     // metrics[0] (env-steps) is counted on the device by ONE lane of the grid: launches of a handle
     // are stream-ordered, so a plain read-modify-write is race free and costs no atomic
-    const bool counts_steps = (MODE == MODE_STEP || MODE == MODE_ROLLOUT || SERVE) && blockIdx.x == 0 && lane == 0;
+    const bool counts_steps = (MODE == MODE_STEP || MODE == MODE_ROLLOUT) && blockIdx.x == 0 && lane == 0;
     unsigned long long steps_before = 0;
     if (counts_steps) steps_before = bufs.metrics[0];
     float reward = 0.0f; int term = 0, trunc = 0;
@@ -1449,20 +1431,18 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
     bool against = false;  // goal conceded (metrics[3]; scrimmage)
     bool was_reset = false;
     // caller-fed actions of the agent lane (robot 0); fed launches run a single step
-    const bool fed = (MODE == MODE_STEP && bufs.actions != nullptr) || SERVE;
+    const bool fed = MODE == MODE_STEP && bufs.actions != nullptr;
     float act[AD];
 #pragma unroll
     for (int i = 0; i < AD; ++i) act[i] = 0.0f;
-    if (!SERVE) {
-        if (TASK == RSX_TASK_SSL_SCRIMMAGE) {   // every robot is commanded: [B][N][4]
-            if (fed && is_robot) {
+    if (TASK == RSX_TASK_SSL_SCRIMMAGE) {   // every robot is commanded: [B][N][4]
+        if (fed && is_robot) {
 #pragma unroll
-                for (int i = 0; i < AD; ++i) act[i] = bufs.actions[((size_t)e * N + b) * AD + i];
-            }
-        } else if (fed && is_robot && b == 0) {
-#pragma unroll
-            for (int i = 0; i < AD; ++i) act[i] = bufs.actions[(size_t)e * AD + i];
+            for (int i = 0; i < AD; ++i) act[i] = bufs.actions[((size_t)e * N + b) * AD + i];
         }
+    } else if (fed && is_robot && b == 0) {
+#pragma unroll
+        for (int i = 0; i < AD; ++i) act[i] = bufs.actions[(size_t)e * AD + i];
     }
 
     // single-step launches: this step's random numbers, computed in the shadow of the loads
@@ -1478,39 +1458,6 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
     RSX_STAMP(1);
 
     for (int it = 0; it < n_steps; ++it) {
-        if (SERVE) {
-            // doorbell: lane 0 polls the sequence number (system scope: it is written by the command
-            // processor of another queue), sleeping between polls; stop request or timeout end the loop
-            const unsigned long long want = bufs.serve_base + (unsigned long long)it + 1ull;
-            int go = 1;
-            if (lane == 0) {
-                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                for (;;) {
-                    const unsigned long long seq = __hip_atomic_load(bufs.serve_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-                    if ((seq & ~SERVE_STOP) >= want) break;          // a requested step is served even when the stop is already in
-                    if (seq & SERVE_STOP) { go = 0; break; }
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > bufs.serve_timeout) {
-                        // nobody rings any more: release whoever might still wait on the counter, then leave
-                        __hip_atomic_store(bufs.serve_done, 0x7FFFFFFFFFFFFFFFull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                        go = 0; break;
-                    }
-                    __builtin_amdgcn_s_sleep(RSX_SERVE_SLEEP);
-                }
-            }
-            go = __builtin_amdgcn_readfirstlane(go);
-            if (!go) break;
-            // the actions were written by a kernel of another queue (possibly through another XCD's L2)
-            const uint32_t* const au = reinterpret_cast<const uint32_t*>(bufs.actions);
-            if (TASK == RSX_TASK_SSL_SCRIMMAGE) {
-                if (is_robot) {
-#pragma unroll
-                    for (int i = 0; i < AD; ++i) act[i] = __uint_as_float(__hip_atomic_load(au + ((size_t)e * N + b) * AD + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-                }
-            } else if (is_robot && b == 0) {
-#pragma unroll
-                for (int i = 0; i < AD; ++i) act[i] = __uint_as_float(__hip_atomic_load(au + (size_t)e * AD + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-            }
-        }
         bool ended;
         const float obs_ts = prev_pot;   // the task scalar as this step's observation sees it (before the reward moves it)
         if (mode == 2) {
@@ -1699,7 +1646,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
                     else pz = make_float4(P.sc_sx * ((float)(b % 6) - 2.5f) + P.sc_j * jx,
                                           P.sc_sy * ((float)(b / 6) - 1.5f) + P.sc_j * jy, 360.0f * u01(u.z), 0.0f);
                 }
-            } else if ((TASK == RSX_TASK_VSS_V0 || TASK == RSX_TASK_SSL_STATIC_DEFENDERS) && MODE != MODE_ROLLOUT) {   // also MODE_SERVE: latency matters
+            } else if ((TASK == RSX_TASK_VSS_V0 || TASK == RSX_TASK_SSL_STATIC_DEFENDERS) && MODE != MODE_ROLLOUT) {
                 if (ended) pz = place_env_parallel<TASK, L, NR>(P, N, env_id, episode, b, g, is_robot, sh.A, sh.draws[g]);
             } else {
                 if (ended && is_ball) place_env<TASK, L>(P, N, env_id, episode, g, sh.A, sh.draws[g]);
@@ -1740,14 +1687,6 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
             }
         }
         wave_sync();
-        if (SERVE) {
-            // publish: episode step counters, then everything this wave wrote becomes visible to the whole
-            // system (L2 write-back), then one count per wave — the caller's stream waits for all of them
-            if (live && b == 0) auxe[(size_t)ROW_STEPS * B] = __int_as_float(steps);
-            served += 1;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-            if (lane == 0) __hip_atomic_fetch_add(bufs.serve_done, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
     }
 
     RSX_STAMP(5);
@@ -1764,7 +1703,7 @@ __global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Param
         auxe[(size_t)ROW_PREV_POT * B] = prev_pot;
         if (TASK != RSX_TASK_VSS_V0) auxe[(size_t)ROW_EP_RET * B] = ep_ret;
     }
-    if (counts_steps) bufs.metrics[0] = steps_before + (unsigned long long)P.num_envs * (unsigned long long)(SERVE ? served : n_steps);
+    if (counts_steps) bufs.metrics[0] = steps_before + (unsigned long long)P.num_envs * (unsigned long long)n_steps;
     RSX_STAMP(6);
 #ifdef RSX_TIMING
     __builtin_amdgcn_s_waitcnt(0x0F70);

@@ -57,3 +57,147 @@ def allreduce_metrics(metrics, device=None):
         t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.cpu().numpy()
+
+
+def device_tag(device_index):
+    """'cuda:3 pci 0000:c5:00.0 <name>' of a visible device — for the per-rank diagnostics of a multi-GPU run."""
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(device_index)
+        pci = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0))
+        return f"cuda:{device_index} pci {pci} {p.name}"
+    except Exception as ex:   # diagnostics must never take a run down
+        return f"cuda:{device_index} ({ex!r})"
+
+
+class MetricsCollective:
+    """The one inter-GPU exchange of a sharded run: the sum of a small int64 vector (64 bytes every 100 steps),
+    off the critical path of every rank.  It must therefore never be able to take the run down:
+
+      * a gloo group over 127.0.0.1 is the control plane (always there: rendezvous, agreement, fallback);
+      * the RCCL group (``backend="nccl"``) is created next to it and PROBED — one all-reduce of a vector of ones on
+        a side stream, waited for with a timeout from a watchdog thread;
+      * the ranks then agree over gloo (MIN of their ok flags): all ok -> RCCL carries the metrics; otherwise every rank
+        uses gloo for the 64 bytes and ``describe()`` says why ("gloo (rccl failed: ...)"), so that the scaling
+        value of the run still prints.
+
+    ``prefer``: "nccl" (default on a GPU run), "gloo" (CPU tests, shared-device test mode).  ``simulate_failure``
+    makes the probe fail on the given ranks (tests of the degraded mode: "all", or a rank number)."""
+
+    def __init__(self, rank, world, device=None, prefer="nccl", timeout_s=60.0, simulate_failure=None, log=None):
+        import datetime
+        import torch
+        import torch.distributed as dist
+        self.rank, self.world, self.device = rank, world, device
+        self.torch, self.dist = torch, dist
+        self.log = log or (lambda msg: None)
+        self.reason = None
+        self.rccl_ranks = 0
+        self.group = None   # RCCL group when it works
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        # a failing RCCL collective must end in the probe's timeout, not in torch's watchdog tearing the process down
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+        os.environ.setdefault("TORCH_NCCL_ENABLE_MONITORING", "0")
+        if not dist.is_initialized():
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=max(60.0, 4 * timeout_s)))
+        self.ctl = dist.group.WORLD
+        ok, why = 0, None
+        if prefer == "nccl":
+            ok, why = self._probe_rccl(timeout_s, simulate_failure)
+        else:
+            why = f"not requested (prefer={prefer})"
+        flags = torch.tensor([ok, 1 - ok], dtype=torch.int64)
+        dist.all_reduce(flags, group=self.ctl)               # [ranks ok, ranks failed]
+        self.rccl_ranks = int(flags[0])
+        if prefer == "nccl" and int(flags[1]) > 0:
+            failed = int(flags[1])
+            self.reason = why if why else f"{failed} other rank(s) failed the probe"
+            if self.group is not None:
+                self.log(f"RCCL probe ok here, but {failed} rank(s) failed: the metrics go over gloo on every rank")
+            self.group = None
+            self.rccl_ranks = 0
+        elif prefer != "nccl":
+            self.reason = None
+        self.backend = "rccl" if self.group is not None else "gloo"
+
+    def _probe_rccl(self, timeout_s, simulate_failure):
+        import datetime
+        import threading
+        torch, dist = self.torch, self.dist
+        sim = simulate_failure is not None and (str(simulate_failure) == "all" or str(simulate_failure) == str(self.rank))
+        result = {}
+
+        def attempt():
+            try:
+                if sim:
+                    raise RuntimeError("simulated (--simulate-rccl-failure)")
+                if not torch.cuda.is_available():
+                    raise RuntimeError("no HIP device visible")
+                g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=timeout_s),
+                                   device_id=torch.device("cuda", self.device) if self.device is not None else None)
+                side = torch.cuda.Stream(device=self.device)
+                with torch.cuda.stream(side):
+                    t = torch.ones(8, dtype=torch.int64, device=torch.device("cuda", self.device))
+                    dist.all_reduce(t, group=g)
+                    side.synchronize()
+                if int(t[0].item()) != self.world:
+                    raise RuntimeError(f"probe all-reduce returned {int(t[0].item())}, expected {self.world}")
+                result["group"] = g
+            except Exception as ex:   # noqa: BLE001 — anything RCCL throws ends in the degraded mode
+                result["error"] = f"{type(ex).__name__}: {ex}".splitlines()[0][:300]
+
+        # dist.new_group is itself a collective over the control plane: every rank must call it, also the ones that
+        # simulate a failure afterwards — so a simulated failure skips the call on EVERY rank only with "all";
+        # a single simulated rank creates the group and then refuses to use it
+        if sim and str(simulate_failure) != "all":
+            sim = False
+            refuse = True
+        else:
+            refuse = False
+        th = threading.Thread(target=attempt, daemon=True)
+        th.start()
+        th.join(timeout_s + 5.0)
+        if th.is_alive():
+            self.log(f"RCCL probe did not finish within {timeout_s:.0f} s")
+            return 0, f"probe timed out after {timeout_s:.0f} s"
+        if refuse and "group" in result:
+            self.log("RCCL probe: simulated failure on this rank")
+            return 0, "simulated (--simulate-rccl-failure)"
+        if "group" in result:
+            self.group = result["group"]
+            return 1, None
+        self.log(f"RCCL unavailable: {result.get('error')}")
+        return 0, result.get("error", "unknown error")
+
+    def describe(self):
+        if self.backend == "rccl":
+            return "rccl"
+        return "gloo" if self.reason is None else f"gloo (rccl failed: {self.reason})"
+
+    def buffer_device(self):
+        """where the vectors handed to all_reduce() have to live"""
+        return self.torch.device("cuda", self.device) if self.backend == "rccl" else self.torch.device("cpu")
+
+    def all_reduce(self, t, op=None):
+        op = op if op is not None else self.dist.ReduceOp.SUM
+        self.dist.all_reduce(t, op=op, group=self.group if self.backend == "rccl" else self.ctl)
+        return t
+
+    def barrier(self):
+        if self.backend == "rccl":
+            # a collective on the device: ranks leave it when every rank's stream has reached it
+            t = self.torch.zeros(1, dtype=self.torch.int32, device=self.buffer_device())
+            self.dist.all_reduce(t, group=self.group)
+            self.torch.cuda.synchronize()
+        else:
+            if self.torch.cuda.is_available():
+                self.torch.cuda.synchronize()
+            self.dist.barrier(group=self.ctl)
+
+    def close(self):
+        try:
+            self.dist.barrier(group=self.ctl)
+            self.dist.destroy_process_group()
+        except Exception:   # noqa: BLE001
+            pass

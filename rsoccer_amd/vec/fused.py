@@ -45,7 +45,6 @@ class VecFusedEnv:
         self._t = self.sim.task_tensors()
         self._info_views = None
         self._pending = None
-        self._serving = False
         self.field = self.sim.get_field_params()
         self.single_action_space = gym.spaces.Box(low=-1, high=1, shape=(self.sim.act_dim,), dtype=np.float32)
         self.single_observation_space = gym.spaces.Box(low=-1.2, high=1.2, shape=(self.sim.obs_dim,), dtype=np.float32)
@@ -102,28 +101,9 @@ class VecFusedEnv:
                 a.copy_(torch.from_numpy(np.ascontiguousarray(actions, dtype=np.float32)))
             self._keep = a  # keep the tensor alive until the launch has consumed it
             ptr = a.data_ptr()
-        if self._serving:
-            if ptr is None:   # the persistent kernel always takes fed actions: draw them here
-                self._t["actions"].uniform_(-1.0, 1.0)
-                ptr = self._t["actions"].data_ptr()
-            self.sim.serve_step(ptr, self._stream())
-        else:
-            self.sim.task_step(ptr, self._stream())
+        self.sim.task_step(ptr, self._stream())
         t = self._t
         return t["obs"], t["reward"], t["terminated"], t["truncated"], self._info()
-
-    def serve_start(self, timeout_ms=2000):
-        """Switch ``step()`` to the persistent serving kernel (``rsx_serve_*``): the state stays in
-        registers and each step is a doorbell + a completion wait on the current stream instead of a
-        kernel launch (VSS-v0 3v3 and SSLStaticDefenders; identical results).  ``reset()``, ``metrics()``
-        and ``step_random()`` need ``serve_stop()`` first."""
-        self.sim.serve_start(timeout_ms)
-        self._serving = True
-
-    def serve_stop(self):
-        if self._serving:
-            self._serving = False
-            self.sim.serve_stop()
 
     def step_async(self, actions=None):
         """``gymnasium.vector``-style split call: enqueue the step (host-asynchronous, stream-ordered,
@@ -172,7 +152,6 @@ class VecFusedEnv:
         return self.sim.state_tensor()
 
     def close(self):
-        self.serve_stop()
         self.sim.close()
 
 

@@ -37,6 +37,20 @@ def test_gpus_n_self_launches_its_ranks_dry_run():
     assert line["n_gpus"] == 2 and line["dry_run"] is True
     assert line["env_steps_counted"] == 2 * 33 * 7          # both shards were counted
     assert line["env_id_bases_sum"] == 0 + 33               # rank r owns [r*B, (r+1)*B)
+    # no HIP device here: RCCL cannot come up, the 64 bytes go over gloo and the line says why (degraded mode)
+    assert line["collective"]["backend"].startswith("gloo (rccl failed:") and line["collective"]["rccl_ranks"] == 0
+    assert "[bench rank 1/2" in res.stderr                  # per-rank diagnostics, prefixed, on stderr
+
+
+@pytest.mark.parametrize("who", ["all", "1"])
+def test_forced_rccl_failure_falls_back_to_gloo_and_still_prints(who):
+    """the collective is 64 bytes off the critical path: when RCCL fails (here: simulated, on every rank or on one
+    only) every rank switches to gloo for it and the scaling value still prints"""
+    res, line = _run(["--gpus", "3", "--steps", "5", "--warmup", "0", "--envs", "10", "--dry-run",
+                      "--simulate-rccl-failure", who, "--rccl-timeout", "20"])
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert line["n_gpus"] == 3 and line["env_steps_counted"] == 3 * 10 * 5
+    assert line["collective"]["backend"].startswith("gloo (rccl failed:") and line["collective"]["rccl_ranks"] == 0
 
 
 def test_gpus_must_match_the_world_size():
@@ -81,9 +95,20 @@ def test_bench_rccl_path_with_one_rank():
     res, line = _run(["--steps", "150", "--warmup", "50", "--no-cpu-baseline", "--no-extra", "--no-rollout"],
                      env={"RSX_BENCH_FORCE_DIST": "1"})
     assert res.returncode == 0, res.stdout + res.stderr
-    assert line["collective"]["backend"] == "rccl" and line["collective"]["ranks"] == 1
+    assert line["collective"]["backend"] == "rccl" and line["collective"]["ranks"] == 1 and line["collective"]["rccl_ranks"] == 1
+    assert "pci" in line["collective"]["devices"][0]
     m = _single_handle_metrics(4096, 150, 50)
     assert line["env_steps_counted"] == int(m[0]) == 4096 * 200 and line["episodes"] == int(m[1])
+
+
+@pytest.mark.gpu
+def test_bench_forced_rccl_failure_on_the_gpu_box_degrades_to_gloo():
+    """the same run with the RCCL probe made to fail: metrics over gloo, identical counts, the line says so"""
+    res, line = _run(["--steps", "150", "--warmup", "50", "--no-cpu-baseline", "--no-extra", "--no-rollout",
+                      "--simulate-rccl-failure", "all"], env={"RSX_BENCH_FORCE_DIST": "1"})
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert line["collective"]["backend"].startswith("gloo (rccl failed: ") and line["collective"]["rccl_ranks"] == 0
+    assert line["env_steps_counted"] == 4096 * 200
 
 
 @pytest.mark.gpu
@@ -97,7 +122,9 @@ def test_bench_two_ranks_equal_one_handle():
                       "--no-cpu-baseline", "--no-extra", "--no-rollout"], env=env)
     assert res.returncode == 0, res.stdout + res.stderr
     assert line["n_gpus"] == 2 and line["collective"]["ranks"] == 2
-    assert len(line["collective"]["per_rank_ms_per_step"]) == 2
+    if torch.cuda.device_count() >= 2:                      # whenever two devices are there, the exchange must be RCCL's
+        assert line["collective"]["backend"] == "rccl" and line["collective"]["rccl_ranks"] == 2
+    assert len(line["collective"]["per_rank_ms_per_step"]) == 2 and len(line["collective"]["devices"]) == 2
     assert abs(line["value"] - 2 * B * K / (line["ms_per_step"] * 1e-3 * K)) < 1e-6 * line["value"]
     m = _single_handle_metrics(2 * B, K, W)
     assert line["env_steps_counted"] == int(m[0]) == 2 * B * (K + W)

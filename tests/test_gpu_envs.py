@@ -330,55 +330,6 @@ def test_scrimmage_env_11v11_api():
     crowded.close()
 
 
-def test_serving_kernel_is_bit_identical_and_cannot_hang():
-    """rsx_serve_*: a persistent kernel keeps the state in registers and takes one doorbell per step
-    (experimental: on this ROCm stack a resident kernel delays every other dispatch by ~1 ms, so it is
-    NOT the fast path — DESIGN.md 5.1 — but it must be correct and safe).  Same actions -> same
-    observations / rewards / flags / final state as per-step launches; other calls are refused while
-    serving; without doorbells the kernel leaves by itself and the handle is usable again."""
-    import time
-    import torch
-    from rsoccer_amd import _lib as L
-    from rsoccer_amd.vec import VecVSSEnv
-    a, b = VecVSSEnv(256, seed=11, max_episode_steps=9), VecVSSEnv(256, seed=11, max_episode_steps=9)
-    a.reset(); b.reset()
-    g = torch.Generator(device="cuda"); g.manual_seed(2)
-    acts = torch.rand(24, 256, 2, device="cuda", generator=g) * 2 - 1
-    st = torch.cuda.current_stream()
-    st.synchronize()
-    b.serve_start(timeout_ms=1500)
-    with pytest.raises(L.RsxError, match="serving"):
-        b.sim.task_step_n(1)
-    for t in range(24):                                       # NB: no device-wide synchronize while serving
-        oa = a.step(acts[t]); ob = b.step(acts[t])
-        st.synchronize()
-        for x, y in zip(oa[:4], ob[:4]):
-            assert torch.equal(x, y), t
-        assert torch.equal(oa[4]["final_obs"], ob[4]["final_obs"])
-    b.serve_stop()
-    assert np.array_equal(a.sim.get_state_full(), b.sim.get_state_full())
-    assert a.metrics() == b.metrics()
-    # a lost caller: the kernel gives up after its timeout, the state is saved, stepping goes on
-    b.serve_start(timeout_ms=300)
-    gone = False
-    for _ in range(8):                                        # well past the timeout: it must have left
-        time.sleep(0.5)
-        try:
-            b.step(acts[0])
-            st.synchronize()
-        except L.RsxError as ex:
-            assert "no longer running" in str(ex)
-            gone = True
-            break
-    assert gone
-    b._serving = False
-    assert b.metrics()["env_steps"] == a.metrics()["env_steps"]   # nothing was served in between
-    oa = a.step(acts[1]); ob = b.step(acts[1])
-    torch.cuda.synchronize()
-    assert torch.equal(oa[0], ob[0])
-    a.close(); b.close()
-
-
 def test_scalar_hook_adapter_equals_independent_single_envs():
     """VecScalarHookEnv: unmodified reference-shaped task classes (scalar hooks, vss_gym_base.py:197-211)
     as slots of ONE batched simulator give exactly what the same classes give as independent

@@ -796,23 +796,26 @@ def test_checkpoint_resume_is_bit_identical_across_handles_and_layouts(monkeypat
         sim.task_attach(task, seed, base, 40)
         return sim, sim.task_tensors()
 
-    a, ta = make("lanes")
-    a.task_reset()
-    a.task_step_n(50); a.task_rollout(20)
-    blob = a.task_checkpoint()
-    assert blob.dtype == np.uint8 and blob.size > B * 4 * (5 + 6 * (nb + ny))
-    a.task_step_n(30); a.task_rollout(25); a.task_step(None)
-    want = snapshot(a, ta)
-    a.close()
+    for first, second in (("lanes", "epl"), ("epl", "lanes")):   # saved by one kernel layout, continued by the other
+        a, ta = make(first)
+        a.task_reset()
+        a.task_step_n(50); a.task_rollout(20)
+        if first == "epl":
+            a.task_step_n(3)   # the last launch before the save is a single-step one (the kernel that does not keep every aux row current)
+        blob = a.task_checkpoint()
+        assert blob.dtype == np.uint8 and blob.size > B * 4 * (5 + 6 * (nb + ny))
+        a.task_step_n(30); a.task_rollout(25); a.task_step(None)
+        want = snapshot(a, ta)
+        a.close()
 
-    b, tb = make("epl")                       # another handle, the other layout, never reset
-    with pytest.raises(L.RsxError, match="must come before the first step"):
-        b.task_step(None)
-    b.task_restore(blob)
-    b.task_step_n(30); b.task_rollout(25); b.task_step(None)
-    got = snapshot(b, tb)
-    assert np.array_equal(got, want, equal_nan=True)
-    b.close()
+        b, tb = make(second)                  # another handle, the other layout, never reset
+        with pytest.raises(L.RsxError, match="must come before the first step"):
+            b.task_step(None)
+        b.task_restore(blob)
+        b.task_step_n(30); b.task_rollout(25); b.task_step(None)
+        got = snapshot(b, tb)
+        assert np.array_equal(got, want, equal_nan=True), (first, second)
+        b.close()
 
     c, _ = make("lanes")                      # a damaged blob is refused
     with pytest.raises(L.RsxError, match="truncated"):
@@ -828,3 +831,13 @@ def test_checkpoint_resume_is_bit_identical_across_handles_and_layouts(monkeypat
     with pytest.raises(L.RsxError, match="different configuration"):
         e.task_restore(blob)
     e.close()
+    f = L.Sim(kind, ft, nb, ny, 20, B)       # ... another time step
+    f.task_attach(task, seed, base, 40)
+    with pytest.raises(L.RsxError, match="field type or time step"):
+        f.task_restore(blob)
+    f.close()
+    g = L.Sim(kind, ft, nb, ny, 25, B)       # ... and another TimeLimit
+    g.task_attach(task, seed, base, 41)
+    with pytest.raises(L.RsxError, match="max_episode_steps"):
+        g.task_restore(blob)
+    g.close()
