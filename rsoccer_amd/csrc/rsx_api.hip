@@ -634,6 +634,9 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
         if (lay && std::strcmp(lay, "epl") == 0) h->epl = true;
         else if (lay && std::strcmp(lay, "lanes") == 0) h->epl = false;
         else h->epl = P.num_envs >= (task == RSX_TASK_VSS_V0 ? RSX_EPL_MIN_ENVS : RSX_EPL_MIN_ENVS_SSL);
+        // those kernels address rows with 32-bit byte offsets (buffer instructions): arrays of 2 GB and more stay with the lane-group kernels
+        const size_t rows = (size_t)std::max(P.state_dim + X_ROWS, aux_rows(P.n_robots));
+        if (rows * (size_t)P.num_envs * sizeof(float) >= ((size_t)1 << 31) || (size_t)P.num_envs * P.obs_dim * sizeof(float) >= ((size_t)1 << 31)) h->epl = false;
     }
     h->task_ready = false;
     HIP_TRY(hipDeviceSynchronize());   // null-stream memsets done before any caller stream steps

@@ -82,12 +82,27 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
     __shared__ EplShared sh;
     const int lane = threadIdx.x;
     const int tile = tile_of_block(hp_per_xcd);
-    const int e = tile * 64 + lane;
-    const bool live = e < P.num_envs;
+    const int e_raw = tile * 64 + lane;
+    const bool live = e_raw < P.num_envs;
+    // lanes beyond the batch shadow its last env: every load is valid and unconditional (no branch per load),
+    // stores and counters are masked
+    const int e = live ? e_raw : P.num_envs - 1;
     const size_t B = (size_t)P.num_envs;
     const uint32_t env_id = P.env_id_base + (uint32_t)e;
-    float* const st = bufs.state + e;
-    float* const auxe = bufs.aux + e;
+    // Addresses: buffer instructions — one resource per array in scalar registers, the row as the scalar offset, ONE
+    // 32-bit byte offset per lane (the env's column).  Plain pointer arithmetic compiled to a 64-bit vector add per
+    // row access (112 v_lshl_add_u64 + 60 v_mad_i64_i32 per step) and kept row pointers alive in register pairs.
+    // 32-bit offsets: the host picks this kernel only while the state is smaller than 2 GB.
+    const uint32_t eo = 4u * (uint32_t)e;
+    const __amdgpu_buffer_rsrc_t S = __builtin_amdgcn_make_buffer_rsrc(bufs.state, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t A = __builtin_amdgcn_make_buffer_rsrc(bufs.aux, 0, -1, 0x00020000);
+    const int B4 = 4 * P.num_envs;   // bytes per row
+    auto ld = [eo](const __amdgpu_buffer_rsrc_t rs, int row_off) -> float {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)eo, row_off, 0));
+    };
+    auto stf = [eo](const __amdgpu_buffer_rsrc_t rs, int row_off, float v) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, (int)eo, row_off, 0);
+    };
 
     // Register budget: four waves per SIMD need <= 128 VGPRs, so in single-step launches nothing is
     // kept in registers longer than it is needed: the OU state goes back to memory as soon as the
@@ -107,20 +122,20 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
 #pragma unroll
     for (int k = 0; k < N; ++k) {
 #pragma unroll
-        for (int f = 0; f < 6; ++f) raw[k][f] = live ? st[(size_t)(5 + 6 * k + f) * B] : 0.0f;
+        for (int f = 0; f < 6; ++f) raw[k][f] = ld(S, (5 + 6 * k + f) * B4);
         ou[k][0] = ou[k][1] = 0.0f;
-        if (k >= 1 && live) { ou[k][0] = auxe[(size_t)(ROW_OU + 2 * k) * B]; ou[k][1] = auxe[(size_t)(ROW_OU + 2 * k + 1) * B]; }
+        if (k >= 1) { ou[k][0] = ld(A, (ROW_OU + 2 * k) * B4); ou[k][1] = ld(A, (ROW_OU + 2 * k + 1) * B4); }
     }
-    if (live) {
+    {
 #pragma unroll
-        for (int f = 0; f < 5; ++f) rawb[f] = st[(size_t)f * B];
-        rawb[5] = st[(size_t)P.state_dim * B];
-        rawb[6] = st[(size_t)(P.state_dim + 1) * B];
-        steps = __float_as_int(auxe[(size_t)ROW_STEPS * B]);
-        episode = __float_as_uint(auxe[(size_t)ROW_EPISODE * B]);
+        for (int f = 0; f < 5; ++f) rawb[f] = ld(S, f * B4);
+        rawb[5] = ld(S, P.state_dim * B4);
+        rawb[6] = ld(S, (P.state_dim + 1) * B4);
+        steps = __float_as_int(ld(A, ROW_STEPS * B4));
+        episode = __float_as_uint(ld(A, ROW_EPISODE * B4));
         if (!STEP) {
 #pragma unroll
-            for (int i = 1; i <= 3; ++i) info[i] = auxe[(size_t)(ROW_INFO + i) * B];
+            for (int i = 1; i <= 3; ++i) info[i] = ld(A, (ROW_INFO + i) * B4);
         }
     }
     const bool counts_steps = blockIdx.x == 0 && lane == 0;   // metrics[0]: see task_step_kernel
@@ -128,7 +143,7 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
     if (counts_steps) steps_before = bufs.metrics[0];
     const bool fed = MODE == MODE_STEP && bufs.actions != nullptr;
     float act0 = 0.0f, act1 = 0.0f;
-    if (fed && live) { act0 = bufs.actions[(size_t)e * 2]; act1 = bufs.actions[(size_t)e * 2 + 1]; }
+    if (fed) { act0 = bufs.actions[(size_t)e * 2]; act1 = bufs.actions[(size_t)e * 2 + 1]; }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): all loads land once, before the step loop
 #pragma unroll
     for (int k = 0; k < N; ++k) {   // interpret_body, robot
@@ -188,7 +203,7 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
             q0[k] = vss_wheel(a0); q1[k] = vss_wheel(a1);
             const float qq[2] = {q0[k], q1[k]};
             robot_targets<KIND>(P, r[k], qq);
-            if (STEP && k >= 1 && live) { auxe[(size_t)(ROW_OU + 2 * k) * B] = ou[k][0]; auxe[(size_t)(ROW_OU + 2 * k + 1) * B] = ou[k][1]; }
+            if (STEP && k >= 1 && live) { stf(A, (ROW_OU + 2 * k) * B4, ou[k][0]); stf(A, (ROW_OU + 2 * k + 1) * B4, ou[k][1]); }
             if (STEP) __builtin_amdgcn_sched_barrier(0);   // one robot after the other: interleaving them for ILP costs a wave of occupancy
         }
         const float en0 = q0[0], en1 = q1[0];   // the agent's wheel commands: energy term of the reward
@@ -348,9 +363,9 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
         }
 
         // ---- wire-format values, observation, reward ----
-        if (STEP && live) {   // cumulative shaping terms of the episode: fetched now, used after the observation
+        if (STEP) {   // cumulative shaping terms of the episode: fetched now, used after the observation
 #pragma unroll
-            for (int i = 1; i <= 3; ++i) info[i] = auxe[(size_t)(ROW_INFO + i) * B];
+            for (int i = 1; i <= 3; ++i) info[i] = ld(A, (ROW_INFO + i) * B4);
         }
         float ob[EPL_OD];   // this env's observation, in registers
 #pragma unroll
@@ -361,8 +376,8 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
             sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
             epl_obs_robot(P, ob, k, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, wd);
             if (STEP && live) {   // wire format, robot by robot (an env that resets below writes its rows again)
-                float* p = st + (size_t)(5 + 6 * k) * B;
-                p[0] = r[k].x; p[B] = r[k].y; p[2 * B] = r[k].th; p[3 * B] = r[k].vx; p[4 * B] = r[k].vy; p[5 * B] = wd;
+                const int p0 = (5 + 6 * k) * B4;
+                stf(S, p0, r[k].x); stf(S, p0 + B4, r[k].y); stf(S, p0 + 2 * B4, r[k].th); stf(S, p0 + 3 * B4, r[k].vx); stf(S, p0 + 4 * B4, r[k].vy); stf(S, p0 + 5 * B4, wd);
             }
             if (STEP) __builtin_amdgcn_sched_barrier(0);
         }
@@ -398,11 +413,11 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
         const bool ended = live && (term | trunc);
         if (live) {
 #pragma unroll
-            for (int i = 1; i <= 3; ++i) auxe[(size_t)(ROW_INFO + i) * B] = info[i];
+            for (int i = 1; i <= 3; ++i) stf(A, (ROW_INFO + i) * B4, info[i]);
             if (term || first_step) {   // goal counters: non-zero on a terminal step only, cleared on the next first step
-                auxe[(size_t)(ROW_INFO + 0) * B] = info[0]; auxe[(size_t)(ROW_INFO + 4) * B] = info[4]; auxe[(size_t)(ROW_INFO + 5) * B] = info[5];
+                stf(A, (ROW_INFO + 0) * B4, info[0]); stf(A, (ROW_INFO + 4) * B4, info[4]); stf(A, (ROW_INFO + 5) * B4, info[5]);
             }
-            auxe[(size_t)ROW_REWARD * B] = reward;
+            stf(A, ROW_REWARD * B4, reward);
             bufs.flags[e] = (uint8_t)term; bufs.flags[B + e] = (uint8_t)trunc;
         }
 
@@ -458,10 +473,10 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
                     wdeg[k] = 0.0f;
                     sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
                     epl_obs_robot(P, ob, k, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, 0.0f);
-                    if (STEP) {   // this env's rows were written before the reset was known
-                        float* p = st + (size_t)(5 + 6 * k) * B;
-                        p[0] = r[k].x; p[B] = r[k].y; p[2 * B] = r[k].th; p[3 * B] = 0.0f; p[4 * B] = 0.0f; p[5 * B] = 0.0f;
-                        if (k >= 1) { auxe[(size_t)(ROW_OU + 2 * k) * B] = 0.0f; auxe[(size_t)(ROW_OU + 2 * k + 1) * B] = 0.0f; }
+                    if (STEP && live) {   // this env's rows were written before the reset was known
+                        const int p0 = (5 + 6 * k) * B4;
+                        stf(S, p0, r[k].x); stf(S, p0 + B4, r[k].y); stf(S, p0 + 2 * B4, r[k].th); stf(S, p0 + 3 * B4, 0.0f); stf(S, p0 + 4 * B4, 0.0f); stf(S, p0 + 5 * B4, 0.0f);
+                        if (k >= 1) { stf(A, (ROW_OU + 2 * k) * B4, 0.0f); stf(A, (ROW_OU + 2 * k + 1) * B4, 0.0f); }
                     }
                 }
                 ball = Body{};
@@ -478,18 +493,18 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
         if (!STEP) {
 #pragma unroll
             for (int k = 0; k < N; ++k) {
-                float* p = st + (size_t)(5 + 6 * k) * B;
-                p[0] = r[k].x; p[B] = r[k].y; p[2 * B] = r[k].th; p[3 * B] = r[k].vx; p[4 * B] = r[k].vy; p[5 * B] = wdeg[k];
-                if (k >= 1) { auxe[(size_t)(ROW_OU + 2 * k) * B] = ou[k][0]; auxe[(size_t)(ROW_OU + 2 * k + 1) * B] = ou[k][1]; }
+                const int p0 = (5 + 6 * k) * B4;
+                stf(S, p0, r[k].x); stf(S, p0 + B4, r[k].y); stf(S, p0 + 2 * B4, r[k].th); stf(S, p0 + 3 * B4, r[k].vx); stf(S, p0 + 4 * B4, r[k].vy); stf(S, p0 + 5 * B4, wdeg[k]);
+                if (k >= 1) { stf(A, (ROW_OU + 2 * k) * B4, ou[k][0]); stf(A, (ROW_OU + 2 * k + 1) * B4, ou[k][1]); }
             }
         }
-        st[0] = ball.x; st[B] = ball.y; st[3 * B] = ball.vx; st[4 * B] = ball.vy;
+        stf(S, 0, ball.x); stf(S, B4, ball.y); stf(S, 3 * B4, ball.vx); stf(S, 4 * B4, ball.vy);
         const float z_out = K::r_ball + ball.z;
         if (ball_extra_in || z_out != K::r_ball || ball.vz != 0.0f || ball.om != 0.0f) {   // was or is off its resting values
-            st[2 * B] = z_out; st[(size_t)P.state_dim * B] = ball.vz; st[(size_t)(P.state_dim + 1) * B] = ball.om;
+            stf(S, 2 * B4, z_out); stf(S, P.state_dim * B4, ball.vz); stf(S, (P.state_dim + 1) * B4, ball.om);
         }
-        auxe[(size_t)ROW_STEPS * B] = __int_as_float(steps);
-        if (!STEP || new_episode) auxe[(size_t)ROW_EPISODE * B] = __uint_as_float(episode);
+        stf(A, ROW_STEPS * B4, __int_as_float(steps));
+        if (!STEP || new_episode) stf(A, ROW_EPISODE * B4, __uint_as_float(episode));
     }
     if (counts_steps) bufs.metrics[0] = steps_before + (unsigned long long)P.num_envs * (unsigned long long)n_steps;
 }
@@ -498,8 +513,11 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
 // memory system: 154 VGPRs without a spill (3 waves per SIMD) beat 128 VGPRs with 84 B of scratch per lane —
 // the spills alone were 150 MB of the 794 MB a 1 M-env launch moved; without them it moves 631 MB, 1.11 x the
 // algorithmic bytes.  Multi-step launches are limited by instruction issue and prefer the fourth wave.
+#ifndef RSX_EPL_WAVES
+#define RSX_EPL_WAVES 3
+#endif
 template <int MODE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void vss_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_EPL_WAVES, RSX_EPL_WAVES))) void vss_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
     static_assert(MODE == MODE_STEP, "single-step entry point");
     vss_epl_body<MODE_STEP>(hp_state, hp_aux, hp_in, hp_flags, hp_num_envs, hp_state_dim, hp_per_xcd, hp_n_steps, P_, bufs_);
 }

@@ -95,12 +95,22 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
     __shared__ SeplShared<N> sh;
     const int lane = threadIdx.x;
     const int tile = tile_of_block(hp_per_xcd);
-    const int e = tile * 64 + lane;
-    const bool live = e < P.num_envs;
+    const int e_raw = tile * 64 + lane;
+    const bool live = e_raw < P.num_envs;
+    const int e = live ? e_raw : P.num_envs - 1;   // lanes beyond the batch shadow its last env (loads valid and unconditional; stores, counters masked)
     const size_t B = (size_t)P.num_envs;
     const uint32_t env_id = P.env_id_base + (uint32_t)e;
-    float* const st = bufs.state + e;
-    float* const auxe = bufs.aux + e;
+    // buffer addressing (see rsx_epl.hpp): resource per array + row as the scalar offset + one 32-bit lane offset
+    const uint32_t eo = 4u * (uint32_t)e;
+    const __amdgpu_buffer_rsrc_t S = __builtin_amdgcn_make_buffer_rsrc(bufs.state, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t A = __builtin_amdgcn_make_buffer_rsrc(bufs.aux, 0, -1, 0x00020000);
+    const int B4 = 4 * P.num_envs;   // bytes per row
+    auto ld = [eo](const __amdgpu_buffer_rsrc_t rs, int row_off) -> float {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)eo, row_off, 0));
+    };
+    auto stf = [eo](const __amdgpu_buffer_rsrc_t rs, int row_off, float v) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, (int)eo, row_off, 0);
+    };
 
     RSX_STAMP(0);
     // ---- load ----
@@ -115,31 +125,31 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
 #pragma unroll
     for (int k = 0; k < N; ++k) {
 #pragma unroll
-        for (int f = 0; f < 6; ++f) raw[k][f] = live ? st[(size_t)(5 + RS * k + f) * B] : 0.0f;
+        for (int f = 0; f < 6; ++f) raw[k][f] = ld(S, (5 + RS * k + f) * B4);
         ir_in[k] = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) wheels[k][i] = 0.0f;
         // infrared is refreshed by every step that has physics; a step without (time_step 0) keeps the stored flag
-        if (P.n_sub == 0 && live) ir_in[k] = st[(size_t)(5 + RS * k + 6) * B] != 0.0f;
+        if (P.n_sub == 0) ir_in[k] = ld(S, (5 + RS * k + 6) * B4) != 0.0f;
     }
-    if (live) {
+    {
 #pragma unroll
-        for (int f = 0; f < 5; ++f) rawb[f] = st[(size_t)f * B];
-        rawb[5] = st[(size_t)P.state_dim * B];
-        rawb[6] = st[(size_t)(P.state_dim + 1) * B];
-        steps = __float_as_int(auxe[(size_t)ROW_STEPS * B]);
-        episode = __float_as_uint(auxe[(size_t)ROW_EPISODE * B]);
+        for (int f = 0; f < 5; ++f) rawb[f] = ld(S, f * B4);
+        rawb[5] = ld(S, P.state_dim * B4);
+        rawb[6] = ld(S, (P.state_dim + 1) * B4);
+        steps = __float_as_int(ld(A, ROW_STEPS * B4));
+        episode = __float_as_uint(ld(A, ROW_EPISODE * B4));
 #pragma unroll
-        for (int i = 0; i < ID; ++i) info[i] = auxe[(size_t)(ROW_INFO + i) * B];
-        ep_ret = auxe[(size_t)ROW_EP_RET * B];
-        if (HAS_TS) prev_pot = auxe[(size_t)ROW_PREV_POT * B];
+        for (int i = 0; i < ID; ++i) info[i] = ld(A, (ROW_INFO + i) * B4);
+        ep_ret = ld(A, ROW_EP_RET * B4);
+        if (HAS_TS) prev_pot = ld(A, ROW_PREV_POT * B4);
     }
     const bool counts_steps = blockIdx.x == 0 && lane == 0;   // metrics[0]: see task_step_kernel
     unsigned long long steps_before = 0;
     if (counts_steps) steps_before = bufs.metrics[0];
     const bool fed = MODE == MODE_STEP && bufs.actions != nullptr;
     float act[5] = {0, 0, 0, 0, 0};
-    if (fed && live) {
+    if (fed) {
 #pragma unroll
         for (int i = 0; i < AD; ++i) act[i] = bufs.actions[(size_t)e * AD + i];
     }
@@ -467,8 +477,8 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
         const bool ended = live && (term | trunc);
         if (live) {
 #pragma unroll
-            for (int i = 0; i < ID; ++i) auxe[(size_t)(ROW_INFO + i) * B] = info[i];
-            auxe[(size_t)ROW_REWARD * B] = reward;
+            for (int i = 0; i < ID; ++i) stf(A, (ROW_INFO + i) * B4, info[i]);
+            stf(A, ROW_REWARD * B4, reward);
             bufs.flags[e] = (uint8_t)term; bufs.flags[B + e] = (uint8_t)trunc;
         }
 
@@ -518,19 +528,19 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
     if (live) {
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-            float* p = st + (size_t)(5 + RS * k) * B;
-            p[0] = r[k].x; p[B] = r[k].y; p[2 * B] = r[k].th; p[3 * B] = r[k].vx; p[4 * B] = r[k].vy; p[5 * B] = wdeg[k];
-            p[6 * B] = r[k].ir ? 1.0f : 0.0f;
+            const int p0 = (5 + RS * k) * B4;
+            stf(S, p0, r[k].x); stf(S, p0 + B4, r[k].y); stf(S, p0 + 2 * B4, r[k].th); stf(S, p0 + 3 * B4, r[k].vx); stf(S, p0 + 4 * B4, r[k].vy); stf(S, p0 + 5 * B4, wdeg[k]);
+            stf(S, p0 + 6 * B4, r[k].ir ? 1.0f : 0.0f);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) p[(size_t)(7 + i) * B] = wheels[k][i];
+            for (int i = 0; i < 4; ++i) stf(S, p0 + (7 + i) * B4, wheels[k][i]);
         }
-        st[0] = ball.x; st[B] = ball.y; st[2 * B] = K::r_ball + ball.z; st[3 * B] = ball.vx; st[4 * B] = ball.vy;
-        st[(size_t)P.state_dim * B] = ball.vz;
-        st[(size_t)(P.state_dim + 1) * B] = ball.om;
-        auxe[(size_t)ROW_STEPS * B] = __int_as_float(steps);
-        auxe[(size_t)ROW_EPISODE * B] = __uint_as_float(episode);
-        auxe[(size_t)ROW_EP_RET * B] = ep_ret;
-        if (HAS_TS) auxe[(size_t)ROW_PREV_POT * B] = prev_pot;
+        stf(S, 0, ball.x); stf(S, B4, ball.y); stf(S, 2 * B4, K::r_ball + ball.z); stf(S, 3 * B4, ball.vx); stf(S, 4 * B4, ball.vy);
+        stf(S, P.state_dim * B4, ball.vz);
+        stf(S, (P.state_dim + 1) * B4, ball.om);
+        stf(A, ROW_STEPS * B4, __int_as_float(steps));
+        stf(A, ROW_EPISODE * B4, __uint_as_float(episode));
+        stf(A, ROW_EP_RET * B4, ep_ret);
+        if (HAS_TS) stf(A, ROW_PREV_POT * B4, prev_pot);
     }
     if (counts_steps) bufs.metrics[0] = steps_before + (unsigned long long)P.num_envs * (unsigned long long)n_steps;
     RSX_STAMP(12);
