@@ -30,6 +30,10 @@ struct EplShared {
     // holds its env's 40 values in registers and stores them as ten 16-byte pieces (the index arithmetic
     // of a staged, coalesced copy-out cost 5 % of the kernel's VALU instructions and a wave of occupancy).
     struct { float acc[4][EPL_NB][64]; float accw[64]; } c;
+    // single-step launches park the six headings (degrees) here during the physics: they are only integrated there
+    // (one fused multiply-add and a wrap per sub-step), and six registers less is what lets the rest of the step stay
+    // in registers at a higher occupancy; column = lane, private to it
+    float th[EPL_NR][64];
 };
 
 // VSS-v0 observation of a 3v3 env into registers (vss_gym.py:93-117): same values as write_obs<VSS, VSS_V0>
@@ -55,10 +59,17 @@ __device__ __forceinline__ void epl_obs_robot(const Params& P, float* ob, const 
         r[4] = clampf(om_deg * T::inv_max_w, -1.2f, 1.2f);
     }
 }
-__device__ __forceinline__ void epl_store_row(float* dst, const float* ob) {   // 40 floats = ten 16-byte stores
-    float4* d4 = reinterpret_cast<float4*>(dst);
+// one observation row (40 floats = ten 16-byte stores) of `rows` ([B][40]); eo = 4 * env: buffer addressing, no
+// 64-bit address arithmetic and no pointer pair kept across the physics
+__device__ __forceinline__ void epl_store_row(float* rows, const uint32_t eo, const float* ob) {
+    const __amdgpu_buffer_rsrc_t O = __builtin_amdgcn_make_buffer_rsrc(rows, 0, -1, 0x00020000);
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int i = 0; i < 10; ++i) d4[i] = make_float4(ob[4 * i], ob[4 * i + 1], ob[4 * i + 2], ob[4 * i + 3]);
+    for (int i = 0; i < 10; ++i) {
+        const u4 v = {__builtin_bit_cast(unsigned, ob[4 * i]), __builtin_bit_cast(unsigned, ob[4 * i + 1]),
+                      __builtin_bit_cast(unsigned, ob[4 * i + 2]), __builtin_bit_cast(unsigned, ob[4 * i + 3])};
+        __builtin_amdgcn_raw_buffer_store_b128(v, O, (int)(EPL_OD * eo), 16 * i, 0);
+    }
 }
 
 // pair p -> (i, j), i < j, lexicographic: every body then receives its partners in index order
@@ -88,7 +99,7 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
     // stores and counters are masked
     const int e = live ? e_raw : P.num_envs - 1;
     const size_t B = (size_t)P.num_envs;
-    const uint32_t env_id = P.env_id_base + (uint32_t)e;
+    const uint32_t env_id = P.env_id_base + (uint32_t)e;   // (the reset path derives its own copy from eo)
     // Addresses: buffer instructions — one resource per array in scalar registers, the row as the scalar offset, ONE
     // 32-bit byte offset per lane (the env's column).  Plain pointer arithmetic compiled to a 64-bit vector add per
     // row access (112 v_lshl_add_u64 + 60 v_mad_i64_i32 per step) and kept row pointers alive in register pairs.
@@ -131,19 +142,21 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
         for (int f = 0; f < 5; ++f) rawb[f] = ld(S, f * B4);
         rawb[5] = ld(S, P.state_dim * B4);
         rawb[6] = ld(S, (P.state_dim + 1) * B4);
-        steps = __float_as_int(ld(A, ROW_STEPS * B4));
-        episode = __float_as_uint(ld(A, ROW_EPISODE * B4));
-        if (!STEP) {
+        if (!STEP) {   // (single-step launches fetch the episode bookkeeping after the physics: nothing of it is live before)
+            steps = __float_as_int(ld(A, ROW_STEPS * B4));
+            episode = __float_as_uint(ld(A, ROW_EPISODE * B4));
 #pragma unroll
             for (int i = 1; i <= 3; ++i) info[i] = ld(A, (ROW_INFO + i) * B4);
         }
     }
-    const bool counts_steps = blockIdx.x == 0 && lane == 0;   // metrics[0]: see task_step_kernel
-    unsigned long long steps_before = 0;
-    if (counts_steps) steps_before = bufs.metrics[0];
+    const bool counts_steps = blockIdx.x == 0 && lane == 0;   // metrics[0]: see task_step_kernel (read-modify-write at the end: no 64-bit value held across the step)
     const bool fed = MODE == MODE_STEP && bufs.actions != nullptr;
     float act0 = 0.0f, act1 = 0.0f;
-    if (fed) { act0 = bufs.actions[(size_t)e * 2]; act1 = bufs.actions[(size_t)e * 2 + 1]; }
+    if (fed) {
+        const __amdgpu_buffer_rsrc_t AC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bufs.actions), 0, -1, 0x00020000);
+        act0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(AC, (int)(2u * eo), 0, 0));
+        act1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(AC, (int)(2u * eo), 4, 0));
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): all loads land once, before the step loop
 #pragma unroll
     for (int k = 0; k < N; ++k) {   // interpret_body, robot
@@ -153,19 +166,21 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
         wdeg[k] = raw[k][5];
         r[k].om = raw[k][5] * K::deg2rad;
         sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
+        if (STEP) sh.th[k][lane] = r[k].th;
         if (STEP) __builtin_amdgcn_sched_barrier(0);
     }
     ball.x = rawb[0]; ball.y = rawb[1]; ball.vx = rawb[3]; ball.vy = rawb[4];
     ball.z = rawb[2] - K::r_ball; ball.vz = rawb[5]; ball.om = rawb[6];
     // the three internal ball rows (height, vertical speed, spin) rarely change in VSS: they are
     // written back only when they did
-    const bool ball_extra_in = rawb[2] != K::r_ball || rawb[5] != 0.0f || rawb[6] != 0.0f;   // anything but "resting, no spin"
+    int ball_extra_flag = (rawb[2] != K::r_ball || rawb[5] != 0.0f || rawb[6] != 0.0f) ? 1 : 0;   // anything but "resting, no spin"
+    asm volatile("" : "+v"(ball_extra_flag));   // decided HERE: one flag across the step instead of the three rows it is made of
+    const bool ball_extra_in = ball_extra_flag != 0;
     bool new_episode = false;
 
     float reward = 0.0f; int term = 0, trunc = 0;
 
     for (int it = 0; it < n_steps; ++it) {
-        const bool first_step = steps == 0;
         const uint32_t t = P.tick_base + (uint32_t)it;   // see task_step_kernel
         if (STEP || it == 0) {
             // The previous ball potential (vss_gym.py:256-283) is the potential of the ball where this step
@@ -177,6 +192,7 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
             float dy2 = 2.0f * (dy * dy);
             float dist_1 = -sqrtf(dx_a * dx_a + dy2), dist_2 = sqrtf(dx_d * dx_d + dy2);
             prev_pot = ((dist_1 + dist_2) * P.inv_len_cm - 1.0f) * 0.5f;
+            if (STEP) asm volatile("" : "+v"(prev_pot));   // computed HERE: one value across the physics, not the two coordinates it is made of
         }
         // ---- actions -> commands (vss_gym.py:119-142,235-254) ----
         float q0[N], q1[N];
@@ -206,7 +222,8 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
             if (STEP && k >= 1 && live) { stf(A, (ROW_OU + 2 * k) * B4, ou[k][0]); stf(A, (ROW_OU + 2 * k + 1) * B4, ou[k][1]); }
             if (STEP) __builtin_amdgcn_sched_barrier(0);   // one robot after the other: interleaving them for ILP costs a wave of occupancy
         }
-        const float en0 = q0[0], en1 = q1[0];   // the agent's wheel commands: energy term of the reward
+        float energy = -(fabsf(q0[0]) + fabsf(q1[0]));   // the agent's wheel commands: energy term of the reward
+        asm volatile("" : "+v"(energy));   // computed HERE: one value across the physics instead of the two commands
 
         // ---- physics: n_sub sub-steps, the whole env in registers ----
         if (P.n_sub && !(ball.z > 0.0f || ball.vz > 0.0f)) {   // rolling resistance, once per step()
@@ -234,8 +251,12 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
                 o.vy = fma_(vf, o.s, vl * o.c);
                 o.x = fma_(o.vx, P.h, o.x);
                 o.y = fma_(o.vy, P.h, o.y);
-                o.th = fma_(o.om, P.h_deg, o.th);
-                o.th = wrap_deg(o.th);
+                if (STEP) {
+                    sh.th[k][lane] = wrap_deg(fma_(o.om, P.h_deg, sh.th[k][lane]));
+                } else {
+                    o.th = fma_(o.om, P.h_deg, o.th);
+                    o.th = wrap_deg(o.th);
+                }
                 rotate_heading(o.om * P.h, o.c, o.s);
             }
             if (ball.z > 0.0f || ball.vz > 0.0f) {
@@ -276,6 +297,7 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
             constexpr unsigned PM[EPL_NB] = {0x00003Fu, 0x0007C1u, 0x007842u, 0x038884u, 0x0C9108u, 0x152210u, 0x1A4420u};
             bool deep = false;
             for (int sweep = 0; sweep < 2; ++sweep) {   // the second sweep runs the same (cached) instructions
+                if (sweep == 1 && !__any(deep)) break;   // no env of the wave had a deep pair: no second pair test either
                 const unsigned touching = (sweep == 0 || deep) ? find_touching() : 0u;   // second: envs with a deep pair only
                 if (!__any(touching != 0)) break;
                 // some env of the wave has a contact: the sums are addressed by body index and go through
@@ -363,16 +385,20 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
         }
 
         // ---- wire-format values, observation, reward ----
-        if (STEP) {   // cumulative shaping terms of the episode: fetched now, used after the observation
+        if (STEP) {   // episode bookkeeping and cumulative shaping terms: fetched now, used after the observation
+            steps = __float_as_int(ld(A, ROW_STEPS * B4));
+            episode = __float_as_uint(ld(A, ROW_EPISODE * B4));
 #pragma unroll
             for (int i = 1; i <= 3; ++i) info[i] = ld(A, (ROW_INFO + i) * B4);
         }
+        const bool first_step = steps == 0;
         float ob[EPL_OD];   // this env's observation, in registers
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             const float wd = r[k].om * K::rad2deg;
             wdeg[k] = wd;
             r[k].om = wd * K::deg2rad;
+            if (STEP) r[k].th = sh.th[k][lane];
             sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
             epl_obs_robot(P, ob, k, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, wd);
             if (STEP && live) {   // wire format, robot by robot (an env that resets below writes its rows again)
@@ -402,7 +428,6 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
                 float nrm = sqrtf(rbx * rbx + rby * rby);
                 float mv = nrm > 0.0f ? (rbx / nrm) * r[0].vx + (rby / nrm) * r[0].vy : 0.0f;   // unguarded in vss_gym.py:298
                 float move = clampf(mv * 2.5f, -5.0f, 5.0f);
-                float energy = -(fabsf(en0) + fabsf(en1));
                 float t_move = 0.2f * move, t_grad = 0.8f * grad, t_en = 2e-4f * energy;
                 reward = (t_move + t_grad) + t_en;
                 info[1] += t_move; info[2] += t_grad; info[3] += t_en;
@@ -418,13 +443,17 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
                 stf(A, (ROW_INFO + 0) * B4, info[0]); stf(A, (ROW_INFO + 4) * B4, info[4]); stf(A, (ROW_INFO + 5) * B4, info[5]);
             }
             stf(A, ROW_REWARD * B4, reward);
-            bufs.flags[e] = (uint8_t)term; bufs.flags[B + e] = (uint8_t)trunc;
+            {
+                const __amdgpu_buffer_rsrc_t FL = __builtin_amdgcn_make_buffer_rsrc(bufs.flags, 0, -1, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)term, FL, (int)(eo >> 2), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)trunc, FL, (int)(eo >> 2), P.num_envs, 0);
+            }
         }
 
         // ---- episode end: same-step auto-reset, one lane = one env ----
         if (__any(ended)) {
             if (ended) {
-                epl_store_row(bufs.final_obs + (size_t)e * EPL_OD, ob);   // terminal observation
+                epl_store_row(bufs.final_obs, eo, ob);   // terminal observation
                 episode += 1; new_episode = true;
                 unsigned long long* const ms = metric_slot(bufs);
                 atomicAdd(&ms[1], 1ull);
@@ -435,14 +464,18 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
                 if (trunc && !term) atomicAdd(&ms[6], 1ull);
                 // placement: the reference's sequential rejection sampling (vss_gym.py:194-233)
                 uint32_t n = 0;
+                uint32_t eo_r = eo;
+                asm volatile("" : "+v"(eo_r));   // an opaque copy: otherwise the first Philox round of the step's draws (same counter word) is kept alive across the physics for this rare path
+                const uint32_t env_id_r = P.env_id_base + (eo_r >> 2);
                 auto draw = [&]() -> float2 {
-                    const u32x4 u = philox4x32(env_id, episode, n++, DOM_PLACE, P.key0, P.key1);
+                    const u32x4 u = philox4x32(env_id_r, episode, n++, DOM_PLACE, P.key0, P.key1);
                     return make_float2(u01(u.x), u01(u.y));
                 };
                 float bx, by;
                 { const float2 u = draw(); bx = P.pl_xlo + P.pl_xspan * u.x; by = P.pl_ylo + P.pl_yspan * u.y; }
                 // scratch for the poses placed so far: this lane's column of the (now idle) contact sums
-                float* const px = &sh.c.acc[0][0][lane], * const py = &sh.c.acc[1][0][lane], * const pth = &sh.c.acc[2][0][lane];
+                const int lane_r = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // = lane (64-thread workgroups), re-derived: not kept across the physics for this rare path
+                float* const px = &sh.c.acc[0][0][lane_r], * const py = &sh.c.acc[1][0][lane_r], * const pth = &sh.c.acc[2][0][lane_r];
                 for (int k = 0; k < N; ++k) {
                     float x = 0.0f, y = 0.0f;
                     for (int tt = 0; tt < 64; ++tt) {
@@ -485,7 +518,7 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
             }
         }
         // ---- observation out: this lane's row, ten 16-byte stores ----
-        if (live) epl_store_row(bufs.obs + (size_t)e * EPL_OD, ob);
+        if (live) epl_store_row(bufs.obs, eo, ob);
     }
 
     // ---- store (wire format) ----
@@ -506,7 +539,7 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
         stf(A, ROW_STEPS * B4, __int_as_float(steps));
         if (!STEP || new_episode) stf(A, ROW_EPISODE * B4, __uint_as_float(episode));
     }
-    if (counts_steps) bufs.metrics[0] = steps_before + (unsigned long long)P.num_envs * (unsigned long long)n_steps;
+    if (counts_steps) bufs.metrics[0] = bufs.metrics[0] + (unsigned long long)P.num_envs * (unsigned long long)n_steps;
 }
 
 // Two entry points, two register budgets (measured).  Single-step launches are limited by the
@@ -514,7 +547,7 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
 // the spills alone were 150 MB of the 794 MB a 1 M-env launch moved; without them it moves 631 MB, 1.11 x the
 // algorithmic bytes.  Multi-step launches are limited by instruction issue and prefer the fourth wave.
 #ifndef RSX_EPL_WAVES
-#define RSX_EPL_WAVES 3
+#define RSX_EPL_WAVES 4
 #endif
 template <int MODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_EPL_WAVES, RSX_EPL_WAVES))) void vss_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
