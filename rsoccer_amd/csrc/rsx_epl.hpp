@@ -34,6 +34,7 @@ struct EplShared {
     // (one fused multiply-add and a wrap per sub-step), and six registers less is what lets the rest of the step stay
     // in registers at a higher occupancy; column = lane, private to it
     float th[EPL_NR][64];
+    int ball_extra[64];   // single-step launches: "the ball's internal rows were off their resting values at load time", parked across the step
 };
 
 // VSS-v0 observation of a 3v3 env into registers (vss_gym.py:93-117): same values as write_obs<VSS, VSS_V0>
@@ -175,7 +176,7 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
     // written back only when they did
     int ball_extra_flag = (rawb[2] != K::r_ball || rawb[5] != 0.0f || rawb[6] != 0.0f) ? 1 : 0;   // anything but "resting, no spin"
     asm volatile("" : "+v"(ball_extra_flag));   // decided HERE: one flag across the step instead of the three rows it is made of
-    const bool ball_extra_in = ball_extra_flag != 0;
+    if (STEP) sh.ball_extra[lane] = ball_extra_flag;   // ... and that one in LDS (private column)
     bool new_episode = false;
 
     float reward = 0.0f; int term = 0, trunc = 0;
@@ -226,50 +227,23 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
         asm volatile("" : "+v"(energy));   // computed HERE: one value across the physics instead of the two commands
 
         // ---- physics: n_sub sub-steps, the whole env in registers ----
-        if (P.n_sub && !(ball.z > 0.0f || ball.vz > 0.0f)) {   // rolling resistance, once per step()
-            float sp2 = fma_(ball.vx, ball.vx, ball.vy * ball.vy);
-            if (sp2 > 0.0f) {
-                float sp = sqrtf(sp2), ns = sp - P.mu_g_dt;
-                if (ns < 0.0f) ns = 0.0f;
-                float kk = ns / sp;
-                ball.vx = ball.vx * kk; ball.vy = ball.vy * kk;
-            }
-            const float aw = fabsf(ball.om) - P.spin_dec_dt;   // spin decay, once per step()
-            ball.om = aw > 0.0f ? (ball.om < 0.0f ? -aw : aw) : 0.0f;
-        }
+        ball_step_friction(P, ball);   // rolling resistance + spin decay, once per step() (rsx_body.hpp, like every per-body formula below)
         for (int sub = 0; sub < P.n_sub; ++sub) {
             // A: actuation + integration
 #pragma unroll
             for (int k = 0; k < N; ++k) {
                 Body& o = r[k];
-                float vf = fma_(o.vy, o.s, o.vx * o.c);
-                float vl = fma_(o.vy, o.c, -(o.vx * o.s));
-                vf = vf + clampf(o.t0 - vf, -P.a_lin_h, P.a_lin_h);
-                vl = vl - clampf(vl, -P.a_lat_h, P.a_lat_h);
-                o.om = o.om + clampf(o.t1 - o.om, -P.a_ang_h, P.a_ang_h);
-                o.vx = fma_(vf, o.c, -(vl * o.s));
-                o.vy = fma_(vf, o.s, vl * o.c);
-                o.x = fma_(o.vx, P.h, o.x);
-                o.y = fma_(o.vy, P.h, o.y);
-                if (STEP) {
-                    sh.th[k][lane] = wrap_deg(fma_(o.om, P.h_deg, sh.th[k][lane]));
+                if (STEP) {   // the heading lives in LDS during the physics (see EplShared)
+                    actuate_robot<KIND>(P, o);
+                    o.x = fma_(o.vx, P.h, o.x);
+                    o.y = fma_(o.vy, P.h, o.y);
+                    sh.th[k][lane] = advance_heading(P, o.om, sh.th[k][lane]);
+                    rotate_heading(o.om * P.h, o.c, o.s);
                 } else {
-                    o.th = fma_(o.om, P.h_deg, o.th);
-                    o.th = wrap_deg(o.th);
-                }
-                rotate_heading(o.om * P.h, o.c, o.s);
-            }
-            if (ball.z > 0.0f || ball.vz > 0.0f) {
-                ball.vz = ball.vz - P.g_h;
-                ball.z = fma_(ball.vz, P.h, ball.z);
-                if (ball.z <= 0.0f) {
-                    ball.z = 0.0f;
-                    ball.vz = -ball.vz * K::e_ground;
-                    if (ball.vz < K::vz_min) ball.vz = 0.0f;
+                    integrate_robot<KIND>(P, o);
                 }
             }
-            ball.x = fma_(ball.vx, P.h, ball.x);
-            ball.y = fma_(ball.vy, P.h, ball.y);
+            integrate_ball<KIND>(P, ball);
 
             // B: contacts, Jacobi over the post-integration snapshot.  Every pair once; the exact
             // integer form of 0 < d2 < thr (see rsx_kernels.hpp) gives one bit per touching pair.
@@ -329,29 +303,17 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
                     const float rs = rb ? K::rs_rb : K::rs_rr, ope = rb ? K::ope_rb : K::ope_rr;
                     const float mu = rb ? K::mu_rb : K::mu_rr;
                     const float lever_j = rb ? K::r_ball : K::r_robot;
-                    float unused = 0.0f;
-                    // body i (a robot) sees j ...
-                    {
-                        const float dx = bj.x - bi.x, dy = bj.y - bi.y;
-                        const float d2 = fma_(dx, dx, dy * dy);
-                        float a0 = sh.c.acc[0][i][lane], a1 = sh.c.acc[1][i][lane], a2 = sh.c.acc[2][i][lane], a3 = sh.c.acc[3][i][lane];
-                        contact_response(bi, make_float4(bj.x, bj.y, bj.vx, bj.vy), d2, rs, ope, rb ? K::w_rb_r : K::w_rr,
-                                         rb ? K::kt_rb_r : K::kt_rr, mu, 0.0f, fma_(wj, lever_j, wi * K::r_robot), K::beta, K::pen2,
-                                         a0, a1, a2, a3, unused, deep);
-                        sh.c.acc[0][i][lane] = a0; sh.c.acc[1][i][lane] = a1; sh.c.acc[2][i][lane] = a2; sh.c.acc[3][i][lane] = a3;
-                    }
-                    // ... and j sees i, from its own point of view (what its lane computes in the other layout)
-                    {
-                        const float dx = bi.x - bj.x, dy = bi.y - bj.y;
-                        const float d2 = fma_(dx, dx, dy * dy);
-                        float a0 = sh.c.acc[0][j][lane], a1 = sh.c.acc[1][j][lane], a2 = sh.c.acc[2][j][lane], a3 = sh.c.acc[3][j][lane];
-                        float a4 = rb ? sh.c.accw[lane] : 0.0f;
-                        contact_response(bj, make_float4(bi.x, bi.y, bi.vx, bi.vy), d2, rs, ope, rb ? K::w_rb_b : K::w_rr,
-                                         rb ? K::kt_rb_b : K::kt_rr, mu, rb ? K::spin_c : 0.0f, fma_(wi, K::r_robot, wj * lever_j), K::beta, K::pen2,
-                                         a0, a1, a2, a3, a4, deep);
-                        sh.c.acc[0][j][lane] = a0; sh.c.acc[1][j][lane] = a1; sh.c.acc[2][j][lane] = a2; sh.c.acc[3][j][lane] = a3;
-                        if (rb) sh.c.accw[lane] = a4;
-                    }
+                    // both sides of the pair with one normal (contact_pair, rsx_body.hpp); each body's sums are read-modify-written
+                    // in pair order = partner-index order
+                    float ai[4] = {sh.c.acc[0][i][lane], sh.c.acc[1][i][lane], sh.c.acc[2][i][lane], sh.c.acc[3][i][lane]};
+                    float aj[4] = {sh.c.acc[0][j][lane], sh.c.acc[1][j][lane], sh.c.acc[2][j][lane], sh.c.acc[3][j][lane]};
+                    float awj = rb ? sh.c.accw[lane] : 0.0f;
+                    contact_pair(bi, bj, fma_(wj, lever_j, wi * K::r_robot), fma_(wi, K::r_robot, wj * lever_j), rs, ope,
+                                 rb ? K::w_rb_r : K::w_rr, rb ? K::w_rb_b : K::w_rr, rb ? K::kt_rb_r : K::kt_rr, rb ? K::kt_rb_b : K::kt_rr,
+                                 mu, rb ? K::spin_c : 0.0f, K::beta, K::pen2, ai, aj, awj, deep);
+                    sh.c.acc[0][i][lane] = ai[0]; sh.c.acc[1][i][lane] = ai[1]; sh.c.acc[2][i][lane] = ai[2]; sh.c.acc[3][i][lane] = ai[3];
+                    sh.c.acc[0][j][lane] = aj[0]; sh.c.acc[1][j][lane] = aj[1]; sh.c.acc[2][j][lane] = aj[2]; sh.c.acc[3][j][lane] = aj[3];
+                    if (rb) sh.c.accw[lane] = awj;
                 }
                 wave_sync();
                 // only a body that touched something is updated (the others keep their bits); the registers
@@ -372,16 +334,8 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
             }
             // C: walls
 #pragma unroll
-            for (int k = 0; k < N; ++k) {
-                int hit;
-                walls<KIND>(P, K::r_robot, K::e_wr, r[k].x, r[k].y, r[k].vx, r[k].vy, hit);
-            }
-            {
-                const float vx0 = ball.vx, vy0 = ball.vy;
-                int hit = 0;
-                walls<KIND>(P, K::r_ball, K::e_wb, ball.x, ball.y, ball.vx, ball.vy, hit);
-                if (hit) ball_wall_spin<KIND>(hit, vx0, vy0, ball.vx, ball.vy, ball.om);
-            }
+            for (int k = 0; k < N; ++k) robot_walls<KIND>(P, r[k]);
+            ball_walls<KIND>(P, ball);
         }
 
         // ---- wire-format values, observation, reward ----
@@ -533,6 +487,7 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
         }
         stf(S, 0, ball.x); stf(S, B4, ball.y); stf(S, 3 * B4, ball.vx); stf(S, 4 * B4, ball.vy);
         const float z_out = K::r_ball + ball.z;
+        const bool ball_extra_in = (STEP ? sh.ball_extra[threadIdx.x] : ball_extra_flag) != 0;
         if (ball_extra_in || z_out != K::r_ball || ball.vz != 0.0f || ball.om != 0.0f) {   // was or is off its resting values
             stf(S, 2 * B4, z_out); stf(S, P.state_dim * B4, ball.vz); stf(S, (P.state_dim + 1) * B4, ball.om);
         }

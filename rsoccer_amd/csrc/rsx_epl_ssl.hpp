@@ -202,48 +202,12 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
 
         RSX_STAMP(3);
         // ---- physics: n_sub sub-steps, the whole env in registers ----
-        if (P.n_sub && !(ball.z > 0.0f || ball.vz > 0.0f)) {   // rolling resistance + spin decay, once per step()
-            float sp2 = fma_(ball.vx, ball.vx, ball.vy * ball.vy);
-            if (sp2 > 0.0f) {
-                float sp = sqrtf(sp2), ns = sp - P.mu_g_dt;
-                if (ns < 0.0f) ns = 0.0f;
-                float kk = ns / sp;
-                ball.vx = ball.vx * kk; ball.vy = ball.vy * kk;
-            }
-            const float aw = fabsf(ball.om) - P.spin_dec_dt;
-            ball.om = aw > 0.0f ? (ball.om < 0.0f ? -aw : aw) : 0.0f;
-        }
+        ball_step_friction(P, ball);   // rolling resistance + spin decay, once per step() (rsx_body.hpp, like every per-body formula below)
         for (int sub = 0; sub < P.n_sub; ++sub) {
             // A: actuation + integration (holonomic)
 #pragma unroll
-            for (int k = 0; k < N; ++k) {
-                Body& o = r[k];
-                float vf = fma_(o.vy, o.s, o.vx * o.c);
-                float vl = fma_(o.vy, o.c, -(o.vx * o.s));
-                float dx = o.t0 - vf, dy = o.t1 - vl;
-                float d2 = fma_(dx, dx, dy * dy);
-                if (d2 > P.a_lin_h2) { float sc = P.a_lin_h / sqrtf(d2); dx = dx * sc; dy = dy * sc; }
-                vf = vf + dx; vl = vl + dy;
-                o.om = o.om + clampf(o.t2 - o.om, -P.a_ang_h, P.a_ang_h);
-                o.vx = fma_(vf, o.c, -(vl * o.s));
-                o.vy = fma_(vf, o.s, vl * o.c);
-                o.x = fma_(o.vx, P.h, o.x);
-                o.y = fma_(o.vy, P.h, o.y);
-                o.th = fma_(o.om, P.h_deg, o.th);
-                o.th = wrap_deg(o.th);
-                rotate_heading(o.om * P.h, o.c, o.s);
-            }
-            if (ball.z > 0.0f || ball.vz > 0.0f) {
-                ball.vz = ball.vz - P.g_h;
-                ball.z = fma_(ball.vz, P.h, ball.z);
-                if (ball.z <= 0.0f) {
-                    ball.z = 0.0f;
-                    ball.vz = -ball.vz * K::e_ground;
-                    if (ball.vz < K::vz_min) ball.vz = 0.0f;
-                }
-            }
-            ball.x = fma_(ball.vx, P.h, ball.x);
-            ball.y = fma_(ball.vy, P.h, ball.y);
+            for (int k = 0; k < N; ++k) integrate_robot<KIND>(P, r[k]);
+            integrate_ball<KIND>(P, ball);
 
             if (sub == 0) RSX_STAMP(4);
             // B: contacts.  One bit per touching robot pair (exact integer form of 0 < d2 < thr, see
@@ -308,21 +272,13 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
                         { const bool m = i == k; bi.x = m ? r[k].x : bi.x; bi.y = m ? r[k].y : bi.y; bi.vx = m ? r[k].vx : bi.vx; bi.vy = m ? r[k].vy : bi.vy; wi = m ? r[k].om : wi; }   // selects, not branches
                         { const bool m = j == k; bj.x = m ? r[k].x : bj.x; bj.y = m ? r[k].y : bj.y; bj.vx = m ? r[k].vx : bj.vx; bj.vy = m ? r[k].vy : bj.vy; wj = m ? r[k].om : wj; }
                     }
+                    float ai[4] = {sh.c.acc[0][i][lane], sh.c.acc[1][i][lane], sh.c.acc[2][i][lane], sh.c.acc[3][i][lane]};
+                    float aj[4] = {sh.c.acc[0][j][lane], sh.c.acc[1][j][lane], sh.c.acc[2][j][lane], sh.c.acc[3][j][lane]};
                     float unused = 0.0f;
-                    {
-                        const float dx = bj.x - bi.x, dy = bj.y - bi.y;
-                        float a0 = sh.c.acc[0][i][lane], a1 = sh.c.acc[1][i][lane], a2 = sh.c.acc[2][i][lane], a3 = sh.c.acc[3][i][lane];
-                        contact_response(bi, make_float4(bj.x, bj.y, bj.vx, bj.vy), fma_(dx, dx, dy * dy), K::rs_rr, K::ope_rr, K::w_rr, K::kt_rr,
-                                         K::mu_rr, 0.0f, fma_(wj, K::r_robot, wi * K::r_robot), K::beta, K::pen2, a0, a1, a2, a3, unused, deep);
-                        sh.c.acc[0][i][lane] = a0; sh.c.acc[1][i][lane] = a1; sh.c.acc[2][i][lane] = a2; sh.c.acc[3][i][lane] = a3;
-                    }
-                    {
-                        const float dx = bi.x - bj.x, dy = bi.y - bj.y;
-                        float a0 = sh.c.acc[0][j][lane], a1 = sh.c.acc[1][j][lane], a2 = sh.c.acc[2][j][lane], a3 = sh.c.acc[3][j][lane];
-                        contact_response(bj, make_float4(bi.x, bi.y, bi.vx, bi.vy), fma_(dx, dx, dy * dy), K::rs_rr, K::ope_rr, K::w_rr, K::kt_rr,
-                                         K::mu_rr, 0.0f, fma_(wi, K::r_robot, wj * K::r_robot), K::beta, K::pen2, a0, a1, a2, a3, unused, deep);
-                        sh.c.acc[0][j][lane] = a0; sh.c.acc[1][j][lane] = a1; sh.c.acc[2][j][lane] = a2; sh.c.acc[3][j][lane] = a3;
-                    }
+                    contact_pair(bi, bj, fma_(wj, K::r_robot, wi * K::r_robot), fma_(wi, K::r_robot, wj * K::r_robot), K::rs_rr, K::ope_rr,
+                                 K::w_rr, K::w_rr, K::kt_rr, K::kt_rr, K::mu_rr, 0.0f, K::beta, K::pen2, ai, aj, unused, deep);   // both sides, one normal (rsx_body.hpp)
+                    sh.c.acc[0][i][lane] = ai[0]; sh.c.acc[1][i][lane] = ai[1]; sh.c.acc[2][i][lane] = ai[2]; sh.c.acc[3][i][lane] = ai[3];
+                    sh.c.acc[0][j][lane] = aj[0]; sh.c.acc[1][j][lane] = aj[1]; sh.c.acc[2][j][lane] = aj[2]; sh.c.acc[3][j][lane] = aj[3];
                 }
                 // robot-ball, robot by robot (the ball sums the robots' records in robot order): kicker mouth
                 // (flat face at dck) or body circle; n points robot -> ball.  Mirrors ssl_sweep.
@@ -427,16 +383,8 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
             }
             // C: walls
 #pragma unroll
-            for (int k = 0; k < N; ++k) {
-                int hit;
-                walls<KIND>(P, K::r_robot, K::e_wr, r[k].x, r[k].y, r[k].vx, r[k].vy, hit);
-            }
-            {
-                const float vx0 = ball.vx, vy0 = ball.vy;
-                int hit = 0;
-                walls<KIND>(P, K::r_ball, K::e_wb, ball.x, ball.y, ball.vx, ball.vy, hit);
-                if (hit) ball_wall_spin<KIND>(hit, vx0, vy0, ball.vx, ball.vy, ball.om);
-            }
+            for (int k = 0; k < N; ++k) robot_walls<KIND>(P, r[k]);
+            ball_walls<KIND>(P, ball);
             if (sub == 0) RSX_STAMP(7);
         }
         RSX_STAMP(8);

@@ -41,6 +41,7 @@
 
 #include "rsx_math.hpp"
 #include "rsx_params.hpp"
+#include "rsx_body.hpp"
 
 namespace rsx {
 
@@ -64,16 +65,6 @@ struct Buffers {
 #ifdef RSX_TIMING
     unsigned long long* dbg;      // [8][gridDim] s_memtime stamps (development builds only)
 #endif
-};
-
-// what one lane keeps in registers for its body
-struct Body {
-    float x, y, vx, vy;       // all bodies
-    float th, om, c, s;       // robots: heading (DEGREES, the wire unit), rate (rad/s), cos/sin(heading)
-    float t0, t1, t2;         // VSS: v target, omega target | SSL: local vx, vy, omega targets
-    float kick_x, kick_z;     // SSL
-    float z, vz;              // ball: height above rest, vertical speed
-    int drib, ir;
 };
 
 // observation values go straight from the lane that owns them to the row in HBM (scattered 4-byte stores
@@ -114,152 +105,6 @@ struct Shared {
 #define RSX_VSS_HINTS 6
 #endif
 #define RSX_RARE_B(KIND, bit, c) (((KIND) == RSX_KIND_SSL || (RSX_VSS_HINTS & (bit))) ? __builtin_expect(!!(c), 0) : !!(c))
-
-// clamp a circle (radius r, restitution rest) into the playable region
-template <int KIND>
-__device__ __forceinline__ void walls(const Params& P, const float r, const float rest, float& x,
-                                      float& y, float& vx, float& vy, int& hit /* bit 0: vx reflected, bit 1: vy */) {
-    using K = KC<KIND>;
-    float ax = fabsf(x), ay = fabsf(y);
-    const float sx = signf(x), sy = signf(y);  // only read when |x| (|y|) exceeds a positive limit
-    if (KIND == RSX_KIND_VSS) {
-        // predicated form of: inside a goal box (|x| > L/2) the limits are the goal's side and
-        // back walls, otherwise the touch line and - outside the goal mouth - the goal line
-        const bool in_goal = ax > P.half_len;
-        const float yl = (in_goal ? P.ghw : P.half_wid) - r;
-        const float xl = (in_goal ? P.half_len + P.gd : P.half_len) - r;
-        const bool hy = ay > yl;
-        const bool hx = (ax > xl) & (in_goal | (ay > P.ghw - r));
-        const float ny = sy * yl, nx = sx * xl;
-        const bool fy = hy & (vy * sy > 0.0f), fx = hx & (vx * sx > 0.0f);
-        y = hy ? ny : y; vy = fy ? -rest * vy : vy;
-        x = hx ? nx : x; vx = fx ? -rest * vx : vx;
-        hit = (fx ? 1 : 0) | (fy ? 2 : 0);
-    } else {
-        // predicated like the VSS clamp: conditional stores to x / y / vx / vy inside nested
-        // branches get merged by the compiler into stores through a selected POINTER, which
-        // pins the body's velocity in scratch memory (a global-memory round trip per access)
-        const float yl = (P.half_wid + K::margin) - r, xl = (P.half_len + K::margin) - r;
-        const bool hy = ay > yl;
-        const bool fy0 = hy & (vy * sy > 0.0f);
-        y = hy ? sy * yl : y; vy = fy0 ? -rest * vy : vy; ay = hy ? yl : ay;
-        const bool hx = ax > xl;
-        const bool fx0 = hx & (vx * sx > 0.0f);
-        x = hx ? sx * xl : x; vx = fx0 ? -rest * vx : vx; ax = hx ? xl : ax;
-        hit = (fx0 ? 1 : 0) | (fy0 ? 2 : 0);
-        if (ax > P.half_len) {   // beyond a goal line: the goal's walls (rare)
-            const float back = P.half_len + P.gd;
-            const bool in_mouth = ay < P.ghw;
-            const bool inside = in_mouth & (ax < back);
-            const bool c1 = inside & (ax > back - r);                       // back wall, from inside
-            const bool c2 = inside & (ay > P.ghw - r);                      // side wall, from inside
-            const bool c3 = in_mouth & !(ax < back) & (ax < back + r);      // behind the back wall
-            const bool c4 = !in_mouth & (ay < P.ghw + r) & (ax < back);     // outside, touching a side wall
-            const float vxs = vx * sx, vys = vy * sy;
-            const bool fx = (c1 & (vxs > 0.0f)) | (c3 & (vxs < 0.0f));
-            const bool fy = (c2 & (vys > 0.0f)) | (c4 & (vys < 0.0f));
-            x = c1 ? sx * (back - r) : (c3 ? sx * (back + r) : x);
-            y = c2 ? sy * (P.ghw - r) : (c4 ? sy * (P.ghw + r) : y);
-            vx = fx ? -rest * vx : vx;
-            vy = fy ? -rest * vy : vy;
-            hit |= (fx ? 1 : 0) | (fy ? 2 : 0);
-        }
-    }
-}
-
-// A bounce of the BALL off a wall with Coulomb friction at the contact point: couples the velocity
-// component along the wall with the spin about the vertical axis.  (vx0, vy0) = velocity before
-// walls(): the ball moved INTO the wall, so its sign names the wall's side.
-template <int KIND>
-__device__ __forceinline__ void ball_wall_spin(const int hit, const float vx0, const float vy0,
-                                               float& vx, float& vy, float& om) {
-    using K = KC<KIND>;
-    if (hit & 2) {
-        const float sg = vy0 < 0.0f ? -1.0f : 1.0f;
-        const float vc = vx - (om * K::r_ball) * sg;
-        const float lim = K::mu_wb * (K::ope_wb * fabsf(vy0));
-        const float d = clampf(-(vc * K::kw), -lim, lim);
-        vx = vx + d; om = om - (sg * d) * K::spin_c;
-    }
-    if (hit & 1) {
-        const float sg = vx0 < 0.0f ? -1.0f : 1.0f;
-        const float vc = vy + (om * K::r_ball) * sg;
-        const float lim = K::mu_wb * (K::ope_wb * fabsf(vx0));
-        const float d = clampf(-(vc * K::kw), -lim, lim);
-        vy = vy + d; om = om + (sg * d) * K::spin_c;
-    }
-}
-
-// per-step command processing of a robot lane: wheel / velocity commands -> targets
-template <int KIND>
-__device__ __forceinline__ void robot_targets(const Params& P, Body& o, const float* q /*C cmds*/) {
-    using K = KC<KIND>;
-    if (KIND == RSX_KIND_VSS) {
-        float wl = clampf(q[0], -K::w_max, K::w_max);
-        float wr = clampf(q[1], -K::w_max, K::w_max);
-        o.t0 = (wl + wr) * K::half_rw;
-        o.t1 = (wr - wl) * K::rw_2b;
-        o.t2 = 0.0f; o.kick_x = 0.0f; o.kick_z = 0.0f; o.drib = 0;
-    } else {
-        float vtx, vty, omt;
-        if (q[0] != 0.0f) {
-            float w0 = clampf(q[1], -K::w_max, K::w_max), w1 = clampf(q[2], -K::w_max, K::w_max);
-            float w2 = clampf(q[3], -K::w_max, K::w_max), w3 = clampf(q[4], -K::w_max, K::w_max);
-            vtx = (((P.pinv[0][0] * w0 + P.pinv[0][1] * w1) + P.pinv[0][2] * w2) + P.pinv[0][3] * w3) * K::r_wheel;
-            vty = (((P.pinv[1][0] * w0 + P.pinv[1][1] * w1) + P.pinv[1][2] * w2) + P.pinv[1][3] * w3) * K::r_wheel;
-            omt = (((P.pinv[2][0] * w0 + P.pinv[2][1] * w1) + P.pinv[2][2] * w2) + P.pinv[2][3] * w3) * K::r_wheel;
-        } else {
-            vtx = q[1]; vty = q[2]; omt = q[3];
-            float m = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float wi = ((vty * P.wc[i] - vtx * P.ws[i]) + omt * K::r_robot) * K::inv_rw;
-                float a = fabsf(wi);
-                if (a > m) m = a;
-            }
-            if (m > K::w_max) { float sc = K::w_max / m; vtx = vtx * sc; vty = vty * sc; omt = omt * sc; }
-        }
-        o.t0 = vtx; o.t1 = vty; o.t2 = omt;
-        o.kick_x = q[5]; o.kick_z = q[6]; o.drib = q[7] != 0.0f;
-    }
-}
-
-// Response of a body to ONE touching partner, from the body's point of view (each side of a pair
-// evaluates this with its own constants).  n = unit normal body -> partner, pen = penetration,
-// (dvx, dvy) = v_partner - v_body, wsum = om_partner * lever_partner + om_body * lever_body (surface
-// speeds at the contact point), w / kt = the body's share of the normal / tangential impulse,
-// mu = Coulomb coefficient, spin_c = spin per unit of tangential velocity change (ball only).
-__device__ __forceinline__ void respond(const float nx, const float ny, const float pen, const float dvx,
-                                        const float dvy, const float wsum, const float ope, const float w,
-                                        const float kt, const float mu, const float spin_c, const float beta,
-                                        float& avx, float& avy, float& apx, float& apy, float& aw) {
-    float vn = fma_(dvx, nx, dvy * ny);
-    if (vn < 0.0f) {
-        float q = ope * vn * w;                           // <= 0: pushes the body away from the partner
-        avx = fma_(q, nx, avx); avy = fma_(q, ny, avy);
-        float vt = fma_(dvy, nx, -(dvx * ny)) - wsum;     // along t = (-ny, nx)
-        float lim = q * mu;
-        float ft = clampf(vt * kt, lim, -lim);            // sticking impulse, Coulomb-limited
-        avx = fma_(-ft, ny, avx); avy = fma_(ft, nx, avy);
-        aw = fma_(ft, spin_c, aw);
-    }
-    float pc = beta * pen * w;
-    apx = fma_(-pc, nx, apx); apy = fma_(-pc, ny, apy);
-}
-
-// circle - circle pair known to overlap (d2 = squared centre distance)
-__device__ __forceinline__ void contact_response(const Body& o, const float4 oj, const float d2,
-                                                 const float rs, const float ope, const float w,
-                                                 const float kt, const float mu, const float spin_c,
-                                                 const float wsum, const float beta, const float pen2,
-                                                 float& avx, float& avy, float& apx, float& apy, float& aw,
-                                                 bool& deep) {
-    float dx = oj.x - o.x, dy = oj.y - o.y;
-    float d = sqrtf(d2), inv = 1.0f / d;
-    respond(dx * inv, dy * inv, rs - d, oj.z - o.vx, oj.w - o.vy, wsum, ope, w, kt, mu, spin_c, beta,
-            avx, avy, apx, apy, aw);
-    deep |= rs - d > pen2;   // an impact at speed or a jammed pile: the env gets a second sweep
-}
 
 // lanes of the env in slot g: body j sits at lane j * G + g
 template <int L>
@@ -517,49 +362,16 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
     // ball is on the ground (exact stop, never reverses) — keeps the sqrt + divide chain out of
     // the sub-step loop, where the ball lane's branch is serialised with the robots' work.
     // Same place: the spin about the vertical axis decays at a constant rate to an exact stop.
-    if (is_ball && P.n_sub && !(o.z > 0.0f || o.vz > 0.0f)) {
-        float sp2 = fma_(o.vx, o.vx, o.vy * o.vy);
-        if (sp2 > 0.0f) {
-            float sp = sqrtf(sp2), ns = sp - P.mu_g_dt;
-            if (ns < 0.0f) ns = 0.0f;
-            float k = ns / sp;
-            o.vx = o.vx * k; o.vy = o.vy * k;
-        }
-        const float aw = fabsf(o.om) - P.spin_dec_dt;
-        o.om = aw > 0.0f ? (o.om < 0.0f ? -aw : aw) : 0.0f;
-    }
+    if (is_ball) ball_step_friction(P, o);
 
     for (int sub = 0; sub < P.n_sub; ++sub) {
         // ---- A: actuation + integration ----
-        if (is_robot) {
-            float vf = fma_(o.vy, o.s, o.vx * o.c);
-            float vl = fma_(o.vy, o.c, -(o.vx * o.s));
-            if (KIND == RSX_KIND_VSS) {
-                vf = vf + clampf(o.t0 - vf, -P.a_lin_h, P.a_lin_h);
-                vl = vl - clampf(vl, -P.a_lat_h, P.a_lat_h);
-                o.om = o.om + clampf(o.t1 - o.om, -P.a_ang_h, P.a_ang_h);
-            } else {
-                float dx = o.t0 - vf, dy = o.t1 - vl;
-                float d2 = fma_(dx, dx, dy * dy);
-                if (d2 > P.a_lin_h2) { float sc = P.a_lin_h / sqrtf(d2); dx = dx * sc; dy = dy * sc; }
-                vf = vf + dx; vl = vl + dy;
-                o.om = o.om + clampf(o.t2 - o.om, -P.a_ang_h, P.a_ang_h);
-            }
-            o.vx = fma_(vf, o.c, -(vl * o.s));
-            o.vy = fma_(vf, o.s, vl * o.c);
-            o.th = fma_(o.om, P.h_deg, o.th);
-            o.th = wrap_deg(o.th);
+        if (is_robot) {   // rsx_body.hpp: the per-body arithmetic is stated once for all kernel layouts
+            actuate_robot<KIND>(P, o);
+            o.th = advance_heading(P, o.om, o.th);
             rotate_heading(o.om * P.h, o.c, o.s);
         }
-        if (RSX_RARE_B(KIND, 1, is_ball && (o.z > 0.0f || o.vz > 0.0f))) {   // the ball in flight
-            o.vz = o.vz - P.g_h;
-            o.z = fma_(o.vz, P.h, o.z);
-            if (o.z <= 0.0f) {
-                o.z = 0.0f;
-                o.vz = -o.vz * K::e_ground;
-                if (o.vz < K::vz_min) o.vz = 0.0f;
-            }
-        }
+        if (RSX_RARE_B(KIND, 1, is_ball && (o.z > 0.0f || o.vz > 0.0f))) ball_flight(P, o, K::e_ground, K::vz_min);   // the ball in flight
         // the position advance is the same instruction pair for robots and the ball, outside the role branches
         // (every role branch of a lane group costs a save / branch / restore of the exec mask; idle lanes hold zeros)
         o.x = fma_(o.vx, P.h, o.x);
