@@ -19,6 +19,8 @@ namespace rsx {
 // rsx_epl.hip (own translation unit, own compiler flags)
 void launch_vss_epl(bool rollout, const Params& P, const Buffers& b, int n_steps, hipStream_t s);
 void launch_ssl_epl(int task, bool rollout, const Params& P, const Buffers& b, int n_steps, hipStream_t s);
+// rsx_big.hip: the 32-lanes-per-env kernel of the SSL 11v11 scrimmage task built for large batches
+void launch_scrimmage_big(bool rollout, const Params& P, const Buffers& b, int n_steps, hipStream_t s);
 }
 
 using namespace rsx;
@@ -44,6 +46,10 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #ifndef RSX_EPL_MIN_ENVS
 #define RSX_EPL_MIN_ENVS 131072
 #endif
+// smallest batch of the SSL 11v11 scrimmage task stepped by the large-batch build of its kernel (rsx_big.hip)
+#ifndef RSX_BIG_MIN_ENVS
+#define RSX_BIG_MIN_ENVS 8192
+#endif
 #ifndef RSX_EPL_MIN_ENVS_SSL
 #define RSX_EPL_MIN_ENVS_SSL 65536
 #endif
@@ -55,6 +61,7 @@ struct rsx_sim {
     int field_type = 0, time_step_ms = 0;   // as given to rsx_create (checkpoint header)
     int L = 8;   // lanes per env
     int NR = 0;  // compile-time robot count of the selected kernel variant (0 = generic)
+    bool big = false;  // SSL 11v11 scrimmage: step / rollout launches use the large-batch build of the 32-lane kernel (rsx_big.hip)
     bool epl = false;  // VSS-v0 3v3 / the registered SSL tasks: step and rollout launches use the one-lane-per-env kernels (large batches)
     // one allocation per lifetime stage (few pages -> few TLB entries per launch)
     char* arena_sim = nullptr;   // state | cmds
@@ -207,6 +214,7 @@ void launch_task_m(const rsx_sim* h, const float* actions, int n_steps, hipStrea
     if (NRS <= 7 && h->NR == NRS && h->L == 8) { RSX_LAUNCH((task_step_kernel<KIND, 8, TASK, (NRS <= 7 ? NRS : 0), MODE>), h->P, b, n_steps); return; }
     if (NRS <= 7 && h->NR == NRS && h->L == 16) { RSX_LAUNCH((task_step_kernel<KIND, 16, TASK, (NRS <= 7 ? NRS : 0), MODE>), h->P, b, n_steps); return; }
     if (TASK == RSX_TASK_SSL_SCRIMMAGE && h->NR == 22 && h->L == 32) {   // 11v11: robot count known at compile time
+        if (h->big && (MODE == MODE_STEP || MODE == MODE_ROLLOUT)) { launch_scrimmage_big(MODE == MODE_ROLLOUT, h->P, b, n_steps, s); return; }
         RSX_LAUNCH((task_step_kernel<KIND, 32, TASK, (TASK == RSX_TASK_SSL_SCRIMMAGE ? 22 : 0), MODE>), h->P, b, n_steps);
         return;
     }
@@ -628,6 +636,11 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
     // The five registered tasks: which tile layout steps the envs.  Both give identical results; the one-lane-
     // per-env kernel needs enough envs to fill the chip with its long waves.
     h->epl = false;
+    h->big = false;
+    if ((task == RSX_TASK_SSL_SCRIMMAGE || task == RSX_TASK_SSL_SCRIMMAGE_CROWDED) && h->NR == 22 && h->L == 32) {
+        const char* bg = std::getenv("RSX_BIG");   // development override: 0 / 1
+        h->big = bg ? bg[0] == '1' : P.num_envs >= RSX_BIG_MIN_ENVS;
+    }
     const bool fixed_ssl = task == RSX_TASK_SSL_DRIBBLING || task == RSX_TASK_SSL_CONTESTED || task == RSX_TASK_SSL_PASS_ENDURANCE;   // team sizes checked above
     if ((task == RSX_TASK_VSS_V0 && h->NR == 6 && h->L == 8) || (task == RSX_TASK_SSL_STATIC_DEFENDERS && h->NR == 7 && h->L == 8) || fixed_ssl) {
         const char* lay = std::getenv("RSX_LAYOUT");

@@ -8,8 +8,8 @@
 // (rsx_epl.hpp, rsx_epl_ssl.hpp) and four lanes per env (rsx_quad_ssl.hpp) — differ in WHERE a body lives and how
 // partners are found; they all call these functions on a `Body`, so a change of the model is one edit, and the
 // layouts cannot drift apart (they are compared bit for bit in tests/test_gpu_parity.py anyway).
-// The executable definition of the model stays the CPU oracle (oracle/rsx_oracle_impl.h), which shares no code
-// with this file.  Reference call sites replaced: robosim.VSS.step / robosim.SSL.step, rsoccer_gym/Simulators/
+// (The executable DEFINITION of the model is a separate CPU restatement under the test infrastructure, which shares
+// no code with this file: DESIGN.md section 2.)  Reference call sites replaced: robosim.VSS.step / robosim.SSL.step, rsoccer_gym/Simulators/
 // rsim.py:102,155.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -18,6 +18,7 @@
 #pragma once
 #include "rsx_kernels.hpp"
 
+
 namespace rsx {
 
 constexpr int EPL_NR = 6;           // VSS 3v3
@@ -30,11 +31,6 @@ struct EplShared {
     // holds its env's 40 values in registers and stores them as ten 16-byte pieces (the index arithmetic
     // of a staged, coalesced copy-out cost 5 % of the kernel's VALU instructions and a wave of occupancy).
     struct { float acc[4][EPL_NB][64]; float accw[64]; } c;
-    // single-step launches park the six headings (degrees) here during the physics: they are only integrated there
-    // (one fused multiply-add and a wrap per sub-step), and six registers less is what lets the rest of the step stay
-    // in registers at a higher occupancy; column = lane, private to it
-    float th[EPL_NR][64];
-    int ball_extra[64];   // single-step launches: "the ball's internal rows were off their resting values at load time", parked across the step
 };
 
 // VSS-v0 observation of a 3v3 env into registers (vss_gym.py:93-117): same values as write_obs<VSS, VSS_V0>
@@ -167,7 +163,6 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
         wdeg[k] = raw[k][5];
         r[k].om = raw[k][5] * K::deg2rad;
         sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
-        if (STEP) sh.th[k][lane] = r[k].th;
         if (STEP) __builtin_amdgcn_sched_barrier(0);
     }
     ball.x = rawb[0]; ball.y = rawb[1]; ball.vx = rawb[3]; ball.vy = rawb[4];
@@ -176,7 +171,7 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
     // written back only when they did
     int ball_extra_flag = (rawb[2] != K::r_ball || rawb[5] != 0.0f || rawb[6] != 0.0f) ? 1 : 0;   // anything but "resting, no spin"
     asm volatile("" : "+v"(ball_extra_flag));   // decided HERE: one flag across the step instead of the three rows it is made of
-    if (STEP) sh.ball_extra[lane] = ball_extra_flag;   // ... and that one in LDS (private column)
+    const bool ball_extra_in = ball_extra_flag != 0;
     bool new_episode = false;
 
     float reward = 0.0f; int term = 0, trunc = 0;
@@ -231,18 +226,7 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
         for (int sub = 0; sub < P.n_sub; ++sub) {
             // A: actuation + integration
 #pragma unroll
-            for (int k = 0; k < N; ++k) {
-                Body& o = r[k];
-                if (STEP) {   // the heading lives in LDS during the physics (see EplShared)
-                    actuate_robot<KIND>(P, o);
-                    o.x = fma_(o.vx, P.h, o.x);
-                    o.y = fma_(o.vy, P.h, o.y);
-                    sh.th[k][lane] = advance_heading(P, o.om, sh.th[k][lane]);
-                    rotate_heading(o.om * P.h, o.c, o.s);
-                } else {
-                    integrate_robot<KIND>(P, o);
-                }
-            }
+            for (int k = 0; k < N; ++k) integrate_robot<KIND>(P, r[k]);
             integrate_ball<KIND>(P, ball);
 
             // B: contacts, Jacobi over the post-integration snapshot.  Every pair once; the exact
@@ -251,24 +235,27 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
             const bool ball_low = ball.z < K::robot_h;
             constexpr uint32_t T_RR = __builtin_bit_cast(uint32_t, K::rs_rr2) - 1u;
             constexpr uint32_t T_RB = __builtin_bit_cast(uint32_t, K::rs_rb2) - 1u;
+            // bits of `touching` that involve body k (pairs in lexicographic order, see epl_pair)
+            constexpr unsigned PM[EPL_NB] = {0x00003Fu, 0x0007C1u, 0x007842u, 0x038884u, 0x0C9108u, 0x152210u, 0x1A4420u};
             auto find_touching = [&]() -> unsigned {
+                // bit p = pair p touches.  The pairs are visited in REVERSE order and each result is shifted in from the
+                // right (acc = acc + acc + bit: a compare and ONE add-with-carry per pair, no bit constant in a register),
+                // so pair p ends up at bit p; the ball's height gates its six pairs once, at the end
                 unsigned touching = 0;
-                int p = 0;
 #pragma unroll
-                for (int i = 0; i < N; ++i) {
+                for (int i = N - 1; i >= 0; --i) {
 #pragma unroll
-                    for (int j = i + 1; j <= N; ++j, ++p) {
+                    for (int j = N; j > i; --j) {
                         const float xj = j == N ? ball.x : r[j < N ? j : 0].x, yj = j == N ? ball.y : r[j < N ? j : 0].y;
                         const float dx = xj - r[i].x, dy = yj - r[i].y;
                         const uint32_t u = __float_as_uint(fma_(dx, dx, dy * dy)) - 1u;
-                        const bool tch = j == N ? ((u < T_RB) & ball_low) : (u < T_RR);
-                        touching |= tch ? 1u << p : 0u;
+                        // (spelled as the two instructions it is: the compiler's own choice for `2 acc + (u < thr)` is a compare, a
+                        // select of the bit and a share of a shift and an OR)
+                        asm("v_cmp_gt_u32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(touching) : "v"(u), "s"(j == N ? T_RB : T_RR) : "vcc");
                     }
                 }
-                return touching;
+                return ball_low ? touching : (touching & ~PM[N]);
             };
-            // bits of `touching` that involve body k (pairs in lexicographic order, see epl_pair)
-            constexpr unsigned PM[EPL_NB] = {0x00003Fu, 0x0007C1u, 0x007842u, 0x038884u, 0x0C9108u, 0x152210u, 0x1A4420u};
             bool deep = false;
             for (int sweep = 0; sweep < 2; ++sweep) {   // the second sweep runs the same (cached) instructions
                 if (sweep == 1 && !__any(deep)) break;   // no env of the wave had a deep pair: no second pair test either
@@ -352,7 +339,6 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
             const float wd = r[k].om * K::rad2deg;
             wdeg[k] = wd;
             r[k].om = wd * K::deg2rad;
-            if (STEP) r[k].th = sh.th[k][lane];
             sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
             epl_obs_robot(P, ob, k, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, wd);
             if (STEP && live) {   // wire format, robot by robot (an env that resets below writes its rows again)
@@ -487,7 +473,6 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
         }
         stf(S, 0, ball.x); stf(S, B4, ball.y); stf(S, 3 * B4, ball.vx); stf(S, 4 * B4, ball.vy);
         const float z_out = K::r_ball + ball.z;
-        const bool ball_extra_in = (STEP ? sh.ball_extra[threadIdx.x] : ball_extra_flag) != 0;
         if (ball_extra_in || z_out != K::r_ball || ball.vz != 0.0f || ball.om != 0.0f) {   // was or is off its resting values
             stf(S, 2 * B4, z_out); stf(S, P.state_dim * B4, ball.vz); stf(S, (P.state_dim + 1) * B4, ball.om);
         }

@@ -217,15 +217,16 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
             constexpr uint32_t T_RR = __builtin_bit_cast(uint32_t, K::rs_rr2) - 1u;
             constexpr float NEAR2 = 0.13f * 0.13f;   // > (dck_rb + ir_tol)^2 + half_kw^2 = 0.126^2 and > rs_rb^2
             auto find_pairs = [&]() -> unsigned {
+                // bit p = pair p touches: pairs visited in reverse order, each result shifted in from the right (a compare
+                // and one add-with-carry per pair, no bit constant in a register; see rsx_epl.hpp)
                 unsigned touching = 0;
-                int p = 0;
 #pragma unroll
-                for (int i = 0; i < N; ++i) {
+                for (int i = N - 2; i >= 0; --i) {
 #pragma unroll
-                    for (int j = i + 1; j < N; ++j, ++p) {
+                    for (int j = N - 1; j > i; --j) {
                         const float dx = r[j].x - r[i].x, dy = r[j].y - r[i].y;
                         const uint32_t u = __float_as_uint(fma_(dx, dx, dy * dy)) - 1u;
-                        touching |= (u < T_RR) ? 1u << p : 0u;
+                        asm("v_cmp_gt_u32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(touching) : "v"(u), "s"(T_RR) : "vcc");
                     }
                 }
                 return touching;
@@ -233,17 +234,19 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
             auto find_near = [&]() -> unsigned {
                 unsigned near = 0;
 #pragma unroll
-                for (int k = 0; k < N; ++k) {
+                for (int k = N - 1; k >= 0; --k) {
                     const float dx = ball.x - r[k].x, dy = ball.y - r[k].y;
-                    near |= (ball_low & (fma_(dx, dx, dy * dy) < NEAR2)) ? 1u << k : 0u;
+                    const float d2 = fma_(dx, dx, dy * dy);
+                    asm("v_cmp_gt_f32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(near) : "v"(d2), "s"(NEAR2) : "vcc");
                 }
-                return near;
+                return ball_low ? near : 0u;
             };
             bool deep = false;
             BallOverride bo{false, false, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int k = 0; k < N; ++k) r[k].ir = 0;   // refreshed by the first sweep; robots far from the ball: no infrared
             for (int sweep = 0; sweep < 2; ++sweep) {   // the second sweep runs the same (cached) instructions
+                if (sweep == 1 && !__any(deep)) break;   // no env of the wave had a deep pair: no second pair test either
                 const bool mine = sweep == 0 || deep;   // second: envs with a deep pair only
                 const unsigned touching = mine ? find_pairs() : 0u;
                 const unsigned near = mine ? find_near() : 0u;

@@ -233,7 +233,8 @@ __device__ __forceinline__ bool ssl_sweep(const Params& P, Body& o, const int N,
             for (int j = 1; j < NRX; ++j) um = min(um, u[j]);
             if (RSX_RARE_B(KIND, 2, um < T_RR)) {
 #pragma unroll
-                for (int j = 0; j < NRX; ++j) todo |= u[j] < T_RR ? 1u << j : 0u;
+                for (int j = NRX - 1; j >= 0; --j)   // slot j ends at bit j: shifted in from the right, highest slot first (a compare and an add-with-carry per slot, no bit constant in a register)
+                    asm("v_cmp_gt_u32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(todo) : "v"(u[j]), "s"(T_RR) : "vcc");
             }
         } else {
 #pragma unroll 4
@@ -436,12 +437,16 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                             // response, rarely two) instead of one response block per distinct partner
                             // index present anywhere in the wave.  The wave that finishes last sets a
                             // single-step launch's duration, and it is always one with contacts.
+                            // slot j ends at bit j: shifted in from the right, highest slot first — a compare and an add-with-
+                            // carry per slot, no bit constant in a register; the ball's height gates its pairs afterwards
                             unsigned todo = 0;
+                            const uint32_t thr_r = is_ball ? T_RB : T_RR;   // robot slots: robot-ball pairs for the ball lane
 #pragma unroll
-                            for (int j = 0; j <= NR; ++j) {
-                                const bool rb = is_ball || j == NR;
-                                todo |= ((u[j] < (rb ? T_RB : T_RR)) & (!rb | ball_low)) ? 1u << j : 0u;
+                            for (int j = NR; j >= 0; --j) {
+                                if (j == NR) asm("v_cmp_gt_u32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(todo) : "v"(u[j]), "s"(T_RB) : "vcc");
+                                else asm("v_cmp_gt_u32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(todo) : "v"(u[j]), "v"(thr_r) : "vcc");
                             }
+                            if (!ball_low) todo = is_ball ? 0u : (todo & ~(1u << NR));
                             float avx = 0.0f, avy = 0.0f, apx = 0.0f, apy = 0.0f, aw = 0.0f;
                             const float lever = is_ball ? K::r_ball : K::r_robot;
                             // software-pipelined: the next partner's slot is fetched while the current

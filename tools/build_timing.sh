@@ -8,5 +8,6 @@ mkdir -p tools/_dev
 C="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-value -mllvm -amdgpu-kernarg-preload-count=12 -Iinclude -Irsoccer_amd/csrc -DRSX_TIMING -c"
 hipcc $C -mllvm -amdgpu-sched-strategy=max-ilp -o /tmp/_rsx_t_api.o rsoccer_amd/csrc/rsx_api.hip
 hipcc $C -fno-slp-vectorize -o /tmp/_rsx_t_epl.o rsoccer_amd/csrc/rsx_epl.hip
-hipcc --offload-arch=gfx950 -fPIC -shared -o tools/_dev/librsx_hip_timing.so /tmp/_rsx_t_api.o /tmp/_rsx_t_epl.o
+hipcc $C -fno-slp-vectorize -o /tmp/_rsx_t_big.o rsoccer_amd/csrc/rsx_big.hip
+hipcc --offload-arch=gfx950 -fPIC -shared -o tools/_dev/librsx_hip_timing.so /tmp/_rsx_t_api.o /tmp/_rsx_t_epl.o /tmp/_rsx_t_big.o
 echo built tools/_dev/librsx_hip_timing.so

@@ -4,7 +4,8 @@
 cd "$(dirname "$0")/.."
 COMMON="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -mllvm -amdgpu-kernarg-preload-count=12 -Iinclude -Irsoccer_amd/csrc -Rpass-analysis=kernel-resource-usage -c"
 ( hipcc $COMMON -mllvm -amdgpu-sched-strategy=max-ilp -o /tmp/_rsx_probe_api.o rsoccer_amd/csrc/rsx_api.hip 2>&1
-  hipcc $COMMON -fno-slp-vectorize -o /tmp/_rsx_probe_epl.o rsoccer_amd/csrc/rsx_epl.hip 2>&1 ) | python3 -c '
+  hipcc $COMMON -fno-slp-vectorize -o /tmp/_rsx_probe_epl.o rsoccer_amd/csrc/rsx_epl.hip 2>&1
+  hipcc $COMMON -fno-slp-vectorize -o /tmp/_rsx_probe_big.o rsoccer_amd/csrc/rsx_big.hip 2>&1 ) | python3 -c '
 import sys,re
 cur=None;rows={}
 for l in sys.stdin:
