@@ -1167,8 +1167,11 @@ __device__ __forceinline__ StepDraw draw_for_step(const Params& P, const uint32_
 //                the `truncated` bytes (reset_to); observations recomputed, state untouched
 constexpr int MODE_STEP = 0, MODE_RESET = 1, MODE_REFRESH = 2, MODE_ROLLOUT = 3;
 
+#ifndef RSX_TASK_KERNEL_ATTR
+#define RSX_TASK_KERNEL_ATTR   // (rsx_big.hip sets an occupancy target for its build of this kernel)
+#endif
 template <int KIND, int L, int TASK, int NR, int MODE>
-__global__ __launch_bounds__(64) void task_step_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
+__global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
     // A multi-step launch is short of SGPRs, not of start-up latency: there the preloaded copies
     // are left dead and everything is fetched from the kernarg segment when it is needed.
     constexpr bool HOT = MODE != MODE_ROLLOUT;

@@ -92,7 +92,7 @@ class _VecBaseEnv:
         self.commands = self.sim.cmds_tensor().view(n, self.sim.cmd_dim, self.num_envs)
         self.last_frame = None
         self.steps = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
-        self._zeros = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
+        self._device_placement = None   # whether _get_initial_positions() returns device tensors (known after the first call)
 
     def _stream(self):
         return self._torch.cuda.current_stream(self.device).cuda_stream
@@ -122,15 +122,25 @@ class _VecBaseEnv:
         obs = self._frame_to_observations()
         reward, done = self._calculate_reward_and_done()
         done = done.to(torch.bool)
-        truncated = self.steps >= self.max_episode_steps if self.max_episode_steps else self._zeros
+        truncated = self.steps >= self.max_episode_steps if self.max_episode_steps else torch.zeros_like(done)   # a fresh tensor per call
         info = {}
         if self.auto_reset:
             ended = done | truncated
-            info["final_obs"] = obs
-            self._place(ended)
-            self.steps.masked_fill_(ended, 0)
-            # the placement wrote the CURRENT buffer; reset envs get their first observation
-            obs = torch.where(ended[:, None], self._frame_to_observations(), obs)
+            info["final_obs"] = obs.clone()     # the hook may hand out a buffer it reuses
+            if self._device_placement is None:  # decided once: what the subclass' placement hook returns
+                self._device_placement = isinstance(self._get_initial_positions()[0], torch.Tensor)
+            if self._device_placement:
+                # device placement: stream-ordered and masked on the device, no host round trip — every step
+                self._place(ended)
+                self.steps.masked_fill_(ended, 0)
+                # the placement wrote the CURRENT buffer; reset envs get their first observation
+                obs = torch.where(ended[:, None], self._frame_to_observations(), obs)
+            elif bool(ended.any()):
+                # host-array placement (robosim.reset format) costs a synchronisation and a state round trip: only
+                # when an episode really ended (`ended.any()` is itself one small read-back per step on this path)
+                self._place(ended)
+                self.steps.masked_fill_(ended, 0)
+                obs = torch.where(ended[:, None], self._frame_to_observations(), obs)
         return obs, reward, done, truncated, info
 
     def reset(self, env_mask=None):
