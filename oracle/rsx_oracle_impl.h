@@ -477,7 +477,22 @@ static void SUF(step_core)(SUF(rsxo_env)* e, const R* cmds) {
          * one over the corrected snapshot when some pair was deep (impacts at speed, jammed piles);
          * what kicker and dribbler decided in the first sweep is applied after the impulses ---- */
         SUF(kick) K; memset(&K, 0, sizeof(K));
-        if (SUF(contacts)(e, b, 1, &K)) SUF(contacts)(e, b, 0, &K);
+        if (SUF(contacts)(e, b, 1, &K)) {
+            int deep = SUF(contacts)(e, b, 0, &K);
+            /* model EXPERIMENTS only (RSXO_SWEEPS / RSXO_PROJECT, tools/exp_jam.py; both off in the model of DESIGN.md 4):
+             * more Jacobi sweeps, and position-only Gauss-Seidel passes over the robot - robot overlaps */
+            for (int sw = 2; sw < c->exp_sweeps && deep; ++sw) deep = SUF(contacts)(e, b, 0, &K);
+            for (int it = 0; it < c->exp_project; ++it)
+                for (int i = 0; i < N; ++i)
+                    for (int j = i + 1; j < N; ++j) {
+                        R dx = b[j].x - b[i].x, dy = b[j].y - b[i].y;
+                        R d2 = dx * dx + dy * dy;
+                        if (d2 < e->rs_rr2 && d2 > RC(0)) {
+                            R d = R_SQRT(d2), k = RC(0.5) * (e->rs_rr - d) / d;
+                            b[i].x -= k * dx; b[i].y -= k * dy; b[j].x += k * dx; b[j].y += k * dy;
+                        }
+                    }
+        }
         if (K.ovr) {
             ball->vx = K.ovx; ball->vy = K.ovy; ball->om = RC(0);
             if (K.okick && K.ovz > RC(0)) ball->vz = K.ovz;

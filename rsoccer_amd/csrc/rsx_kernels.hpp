@@ -262,12 +262,15 @@ __device__ __forceinline__ bool ssl_sweep(const Params& P, Body& o, const int N,
         float dx = ob.x - o.x, dy = ob.y - o.y;
         float nx = 0.0f, ny = 0.0f, pen = -1.0f;
         bool mouth = false, touch = false;
-        if (ball_low) {
+        // a mouth, circle or infrared contact needs the ball's centre within 0.126 m of the robot's ((dck_rb + ir_tol)^2
+        // + half_kw^2 = 0.126^2, and rs_rb < 0.126): everything farther away skips the geometry (same values when taken)
+        constexpr float NEAR2 = 0.13f * 0.13f;
+        const float d2 = fma_(dx, dx, dy * dy);
+        if (ball_low && d2 < NEAR2) {
             float lx = fma_(dx, o.c, dy * o.s), ly = fma_(dy, o.c, -(dx * o.s));
             if (fabsf(ly) < K::half_kw && lx > 0.0f) {
                 mouth = true; pen = K::dck_rb - lx; nx = o.c; ny = o.s; touch = pen > 0.0f;
             } else {
-                float d2 = fma_(dx, dx, dy * dy);
                 if (d2 < K::rs_rb2 && d2 > 0.0f) {
                     float d = sqrtf(d2), inv = 1.0f / d;
                     nx = dx * inv; ny = dy * inv; pen = K::rs_rb - d; touch = true;
