@@ -21,6 +21,7 @@ void launch_vss_epl(bool rollout, const Params& P, const Buffers& b, int n_steps
 void launch_ssl_epl(int task, bool rollout, const Params& P, const Buffers& b, int n_steps, hipStream_t s);
 // rsx_big.hip: the 32-lanes-per-env kernel of the SSL 11v11 scrimmage task built for large batches
 void launch_scrimmage_big(bool rollout, const Params& P, const Buffers& b, int n_steps, hipStream_t s);
+void launch_ssl_quad(const Params& P, const Buffers& b, hipStream_t s);   // rsx_quad_ssl.hpp: four lanes per env, single-step launches
 }
 
 using namespace rsx;
@@ -50,6 +51,10 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #ifndef RSX_BIG_MIN_ENVS
 #define RSX_BIG_MIN_ENVS 8192
 #endif
+// smallest batch of the scrimmage task stepped by the four-lanes-per-env kernel (0 = only when RSX_LAYOUT=quad asks for it)
+#ifndef RSX_QUAD_MIN_ENVS
+#define RSX_QUAD_MIN_ENVS 0
+#endif
 #ifndef RSX_EPL_MIN_ENVS_SSL
 #define RSX_EPL_MIN_ENVS_SSL 65536
 #endif
@@ -61,6 +66,7 @@ struct rsx_sim {
     int field_type = 0, time_step_ms = 0;   // as given to rsx_create (checkpoint header)
     int L = 8;   // lanes per env
     int NR = 0;  // compile-time robot count of the selected kernel variant (0 = generic)
+    bool quad = false; // SSL 11v11 scrimmage: single-step launches of a large batch use the four-lanes-per-env kernel (rsx_quad_ssl.hpp)
     bool big = false;  // SSL 11v11 scrimmage: step / rollout launches use the large-batch build of the 32-lane kernel (rsx_big.hip)
     bool epl = false;  // VSS-v0 3v3 / the registered SSL tasks: step and rollout launches use the one-lane-per-env kernels (large batches)
     // one allocation per lifetime stage (few pages -> few TLB entries per launch)
@@ -214,6 +220,7 @@ void launch_task_m(const rsx_sim* h, const float* actions, int n_steps, hipStrea
     if (NRS <= 7 && h->NR == NRS && h->L == 8) { RSX_LAUNCH((task_step_kernel<KIND, 8, TASK, (NRS <= 7 ? NRS : 0), MODE>), h->P, b, n_steps); return; }
     if (NRS <= 7 && h->NR == NRS && h->L == 16) { RSX_LAUNCH((task_step_kernel<KIND, 16, TASK, (NRS <= 7 ? NRS : 0), MODE>), h->P, b, n_steps); return; }
     if (TASK == RSX_TASK_SSL_SCRIMMAGE && h->NR == 22 && h->L == 32) {   // 11v11: robot count known at compile time
+        if (h->quad && MODE == MODE_STEP) { launch_ssl_quad(h->P, b, s); return; }
         if (h->big && (MODE == MODE_STEP || MODE == MODE_ROLLOUT)) { launch_scrimmage_big(MODE == MODE_ROLLOUT, h->P, b, n_steps, s); return; }
         RSX_LAUNCH((task_step_kernel<KIND, 32, TASK, (TASK == RSX_TASK_SSL_SCRIMMAGE ? 22 : 0), MODE>), h->P, b, n_steps);
         return;
@@ -636,10 +643,15 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
     // The five registered tasks: which tile layout steps the envs.  Both give identical results; the one-lane-
     // per-env kernel needs enough envs to fill the chip with its long waves.
     h->epl = false;
-    h->big = false;
+    h->big = false; h->quad = false;
     if ((task == RSX_TASK_SSL_SCRIMMAGE || task == RSX_TASK_SSL_SCRIMMAGE_CROWDED) && h->NR == 22 && h->L == 32) {
         const char* bg = std::getenv("RSX_BIG");   // development override: 0 / 1
         h->big = bg ? bg[0] == '1' : P.num_envs >= RSX_BIG_MIN_ENVS;
+        // four lanes per env: 32-bit row offsets (arrays below 2 GB), a real time step (the infrared row is rewritten)
+        const char* lay = std::getenv("RSX_LAYOUT");
+        const size_t rows = (size_t)std::max(P.state_dim + X_ROWS, aux_rows(P.n_robots));
+        const bool fits = rows * (size_t)P.num_envs * sizeof(float) < ((size_t)1 << 31) && P.n_sub > 0 && P.n_blue == 11;
+        h->quad = fits && (lay ? std::strcmp(lay, "quad") == 0 : (RSX_QUAD_MIN_ENVS > 0 && P.num_envs >= RSX_QUAD_MIN_ENVS));
     }
     const bool fixed_ssl = task == RSX_TASK_SSL_DRIBBLING || task == RSX_TASK_SSL_CONTESTED || task == RSX_TASK_SSL_PASS_ENDURANCE;   // team sizes checked above
     if ((task == RSX_TASK_VSS_V0 && h->NR == 6 && h->L == 8) || (task == RSX_TASK_SSL_STATIC_DEFENDERS && h->NR == 7 && h->L == 8) || fixed_ssl) {

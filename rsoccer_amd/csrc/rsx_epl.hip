@@ -8,6 +8,7 @@
 
 #include "rsx_epl.hpp"
 #include "rsx_epl_ssl.hpp"
+#include "rsx_quad_ssl.hpp"
 
 namespace rsx {
 
@@ -39,6 +40,13 @@ static void launch_ssl_epl_t(bool rollout, const Params& P, const Buffers& b, in
     else
         hipLaunchKernelGGL((ssl_epl_kernel<TASK, MODE_STEP>), grid, dim3(64), 0, s, b.state, b.aux, b.actions, b.flags,
                            P.num_envs, P.state_dim, (int)(grid.x >> 3), n_steps, P, b);
+}
+
+void launch_ssl_quad(const Params& P, const Buffers& b, hipStream_t s) {   // SSL 11v11 scrimmage, four lanes per env, single-step launches
+    const int tiles = (P.num_envs + Q_ENVS - 1) / Q_ENVS;
+    const dim3 grid((unsigned)(((tiles + 7) / 8) * 8));
+    hipLaunchKernelGGL((ssl_quad_kernel<MODE_STEP>), grid, dim3(64), 0, s, b.state, b.aux, b.actions, b.flags,
+                       P.num_envs, P.state_dim, (int)(grid.x >> 3), 1, P, b);
 }
 
 void launch_ssl_epl(int task, bool rollout, const Params& P, const Buffers& b, int n_steps, hipStream_t s) {
