@@ -51,9 +51,12 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #ifndef RSX_BIG_MIN_ENVS
 #define RSX_BIG_MIN_ENVS 8192
 #endif
-// smallest batch of the scrimmage task stepped by the four-lanes-per-env kernel (0 = only when RSX_LAYOUT=quad asks for it)
+// smallest batches of the scrimmage task stepped by the four-lanes-per-env kernel (RSX_LAYOUT=quad|lanes overrides)
 #ifndef RSX_QUAD_MIN_ENVS
-#define RSX_QUAD_MIN_ENVS 0
+#define RSX_QUAD_MIN_ENVS 32768
+#endif
+#ifndef RSX_QUAD_MIN_ENVS_CROWDED
+#define RSX_QUAD_MIN_ENVS_CROWDED 262144
 #endif
 #ifndef RSX_EPL_MIN_ENVS_SSL
 #define RSX_EPL_MIN_ENVS_SSL 65536
@@ -651,7 +654,10 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
         const char* lay = std::getenv("RSX_LAYOUT");
         const size_t rows = (size_t)std::max(P.state_dim + X_ROWS, aux_rows(P.n_robots));
         const bool fits = rows * (size_t)P.num_envs * sizeof(float) < ((size_t)1 << 31) && P.n_sub > 0 && P.n_blue == 11;
-        h->quad = fits && (lay ? std::strcmp(lay, "quad") == 0 : (RSX_QUAD_MIN_ENVS > 0 && P.num_envs >= RSX_QUAD_MIN_ENVS));
+        // measured crossovers: the spread line-up from 32 768 envs, the crowded one (contacts in every
+        // sub-step: the six robots of a lane are walked one after the other) only from 262 144
+        const int quad_min = task == RSX_TASK_SSL_SCRIMMAGE ? RSX_QUAD_MIN_ENVS : RSX_QUAD_MIN_ENVS_CROWDED;
+        h->quad = fits && (lay ? std::strcmp(lay, "quad") == 0 : (quad_min > 0 && P.num_envs >= quad_min));
     }
     const bool fixed_ssl = task == RSX_TASK_SSL_DRIBBLING || task == RSX_TASK_SSL_CONTESTED || task == RSX_TASK_SSL_PASS_ENDURANCE;   // team sizes checked above
     if ((task == RSX_TASK_VSS_V0 && h->NR == 6 && h->L == 8) || (task == RSX_TASK_SSL_STATIC_DEFENDERS && h->NR == 7 && h->L == 8) || fixed_ssl) {

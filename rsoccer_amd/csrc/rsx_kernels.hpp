@@ -247,14 +247,25 @@ __device__ __forceinline__ bool ssl_sweep(const Params& P, Body& o, const int N,
         if (RSX_RARE_B(KIND, 2, todo != 0)) {   // per-lane partner walk, see the VSS sweep
             bool& deep = touched;
             got = true;
-            while (todo) {
-                const int j = __builtin_ctz(todo);
-                todo &= todo - 1;
-                const float4 oj = sh.A[j * G + g];
-                const float wj = sh.W[j * G + g];
+            // software-pipelined like the VSS walk: the next partner's slot is fetched while the current response is computed
+            int jn = __builtin_ctz(todo);
+            todo &= todo - 1;
+            float4 nxt = sh.A[jn * G + g];
+            float nxw = sh.W[jn * G + g];
+            for (;;) {
+                const float4 oj = nxt;
+                const float wj = nxw;
+                const bool more = todo != 0;
+                if (more) {
+                    jn = __builtin_ctz(todo);
+                    todo &= todo - 1;
+                    nxt = sh.A[jn * G + g];
+                    nxw = sh.W[jn * G + g];
+                }
                 const float dx = oj.x - o.x, dy = oj.y - o.y;
                 contact_response(o, oj, fma_(dx, dx, dy * dy), K::rs_rr, K::ope_rr, K::w_rr, K::kt_rr, K::mu_rr, 0.0f,
                                  fma_(wj, K::r_robot, o.om * K::r_robot), K::beta, K::pen2, avx, avy, apx, apy, aw, deep);
+                if (!more) break;
             }
         }
         // robot - ball: kicker mouth (flat face at dck) or body circle; n points robot -> ball

@@ -561,6 +561,82 @@ def test_env_per_lane_layout_is_bit_identical(oracle_mod, monkeypatch, task, kin
     assert np.array_equal(outs["epl"], outs["lanes"], equal_nan=True)
 
 
+@pytest.mark.parametrize("task", [6, 7], ids=["spread", "crowded"])
+def test_quad_layout_is_bit_identical(oracle_mod, monkeypatch, task):
+    """SSL 11v11 scrimmage (BASELINE.json configs[3]) at large batches is stepped by a kernel with FOUR lanes per env, six
+    robots per lane (rsx_quad_ssl.hpp).  Forced on a small ragged batch here: the CPU oracle's bits and the 32-lane kernel's,
+    with fed and drawn actions (kicks), contacts in every sub-step (crowded line-up), goals and TimeLimit resets, counters."""
+    import torch
+    L = _lib()
+    O = oracle_mod
+    kind, ft, nb, ny = 1, 1, 11, 11
+    B, seed, base, max_steps = 75, 4711, 19, 40
+    outs = {}
+    refs = None
+    for layout in ("quad", "lanes"):
+        monkeypatch.setenv("RSX_LAYOUT", layout)
+        sim = L.Sim(kind, ft, nb, ny, 25, B)
+        sim.task_attach(task, seed, base, max_steps)
+        tens = sim.task_tensors()
+        sim.task_reset()
+        if layout == "quad":
+            refs = _mk_oracles(O, kind, ft, nb, ny, B)
+            for e, r in enumerate(refs):
+                r.task_attach(task, seed, base + e, max_steps)
+                r.task_reset()
+        rng = np.random.default_rng(11)
+        for t in range(100):
+            if t % 3 == 0:
+                a = rng.uniform(-1, 1, tuple(tens["actions"].shape)).astype(np.float32)
+                tens["actions"].copy_(torch.from_numpy(a))
+                sim.task_step(tens["actions"].data_ptr())
+                if layout == "quad":
+                    for e, r in enumerate(refs):
+                        r.task_step(a[e])
+            else:
+                sim.task_step(None)
+                if layout == "quad":
+                    for r in refs:
+                        r.task_step(None)
+            if layout == "quad" and t % 9 == 0:
+                _cmp_task(sim, refs, tens, t)
+        if layout == "quad":
+            _cmp_task(sim, refs, tens, "end")
+            want = sum(r.task_out()["metrics"] for r in refs)
+            assert np.array_equal(sim.read_metrics(), want) and want[1] >= B
+        torch.cuda.synchronize()
+        outs[layout] = np.concatenate([sim.get_state_full().ravel()] + [tens[k].cpu().numpy().astype(np.float64).ravel()
+                                      for k in ("obs", "reward", "terminated", "truncated", "info", "final_obs", "steps")]
+                                      + [sim.read_metrics().astype(np.float64)])
+        sim.close()
+    assert np.array_equal(outs["quad"], outs["lanes"], equal_nan=True)
+
+
+def test_scrimmage_large_batch_switches_to_the_quad_layout_and_agrees(monkeypatch):
+    """from 32 768 envs the spread scrimmage task picks the four-lanes-per-env kernel by itself; forcing the 32-lane kernel on
+    the same seeds gives the same buffers (full size, resets included)"""
+    import torch
+    L = _lib()
+    B = 32768
+    outs = []
+    for layout in (None, "lanes"):
+        if layout:
+            monkeypatch.setenv("RSX_LAYOUT", layout)
+        else:
+            monkeypatch.delenv("RSX_LAYOUT", raising=False)
+        sim = L.Sim(1, 1, 11, 11, 25, B)
+        sim.task_attach(6, 2025, 0, 25)
+        tens = sim.task_tensors()
+        sim.task_reset()
+        sim.task_step_n(40)
+        torch.cuda.synchronize()
+        outs.append((tens["obs"].clone(), tens["reward"].clone(), sim.state_tensor().clone(), sim.read_metrics()))
+        sim.close()
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert torch.equal(a, b)
+    assert np.array_equal(outs[0][3], outs[1][3]) and outs[0][3][1] >= B
+
+
 @pytest.mark.parametrize("task,kind,ft,nb,ny,B,steps", [(1, 0, 0, 3, 3, 512, 3000), (2, 1, 2, 1, 6, 384, 2000),
                                                        (5, 1, 2, 2, 0, 256, 1500)])
 def test_long_horizon_bitexact(oracle_mod, task, kind, ft, nb, ny, B, steps):
