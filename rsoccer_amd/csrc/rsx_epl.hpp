@@ -16,7 +16,7 @@
 // response from its own point of view with the same expressions, draws use the same Philox
 // counters (tests/test_gpu_parity.py::test_env_per_lane_layout_is_bit_identical).
 #pragma once
-#include "rsx_kernels.hpp"
+#include "rsx_epl_common.hpp"
 
 
 namespace rsx {
@@ -30,7 +30,7 @@ struct EplShared {
     // as scratch for the poses of a reset placement.  Observations do NOT pass through LDS: each lane
     // holds its env's 40 values in registers and stores them as ten 16-byte pieces (the index arithmetic
     // of a staged, coalesced copy-out cost 5 % of the kernel's VALU instructions and a wave of occupancy).
-    struct { float acc[4][EPL_NB][64]; float accw[64]; } c;
+    EplSums<EPL_NB> c;
 };
 
 // VSS-v0 observation of a 3v3 env into registers (vss_gym.py:93-117): same values as write_obs<VSS, VSS_V0>
@@ -56,28 +56,6 @@ __device__ __forceinline__ void epl_obs_robot(const Params& P, float* ob, const 
         r[4] = clampf(om_deg * T::inv_max_w, -1.2f, 1.2f);
     }
 }
-// one observation row (40 floats = ten 16-byte stores) of `rows` ([B][40]); eo = 4 * env: buffer addressing, no
-// 64-bit address arithmetic and no pointer pair kept across the physics
-__device__ __forceinline__ void epl_store_row(float* rows, const uint32_t eo, const float* ob) {
-    const __amdgpu_buffer_rsrc_t O = __builtin_amdgcn_make_buffer_rsrc(rows, 0, -1, 0x00020000);
-    typedef unsigned u4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-        const u4 v = {__builtin_bit_cast(unsigned, ob[4 * i]), __builtin_bit_cast(unsigned, ob[4 * i + 1]),
-                      __builtin_bit_cast(unsigned, ob[4 * i + 2]), __builtin_bit_cast(unsigned, ob[4 * i + 3])};
-        __builtin_amdgcn_raw_buffer_store_b128(v, O, (int)(EPL_OD * eo), 16 * i, 0);
-    }
-}
-
-// pair p -> (i, j), i < j, lexicographic: every body then receives its partners in index order
-__device__ __forceinline__ void epl_pair(int p, int& i, int& j) {
-    // rows of the upper triangle of a 7 x 7 matrix start at 0, 6, 11, 15, 18, 20
-    // (sums of comparisons and the closed form of the row start: the nested ?: chains compiled to exec-mask branches)
-    i = (int)(p >= 6) + (int)(p >= 11) + (int)(p >= 15) + (int)(p >= 18) + (int)(p >= 20);
-    const int start = i * 7 - ((i * (i + 1)) >> 1);
-    j = i + 1 + (p - start);
-}
-
 template <int MODE>
 __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, const Buffers& bufs_) {
     constexpr int KIND = RSX_KIND_VSS, TASK = RSX_TASK_VSS_V0, N = EPL_NR;
@@ -97,20 +75,9 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
     const int e = live ? e_raw : P.num_envs - 1;
     const size_t B = (size_t)P.num_envs;
     const uint32_t env_id = P.env_id_base + (uint32_t)e;   // (the reset path derives its own copy from eo)
-    // Addresses: buffer instructions — one resource per array in scalar registers, the row as the scalar offset, ONE
-    // 32-bit byte offset per lane (the env's column).  Plain pointer arithmetic compiled to a 64-bit vector add per
-    // row access (112 v_lshl_add_u64 + 60 v_mad_i64_i32 per step) and kept row pointers alive in register pairs.
-    // 32-bit offsets: the host picks this kernel only while the state is smaller than 2 GB.
-    const uint32_t eo = 4u * (uint32_t)e;
-    const __amdgpu_buffer_rsrc_t S = __builtin_amdgcn_make_buffer_rsrc(bufs.state, 0, -1, 0x00020000);
-    const __amdgpu_buffer_rsrc_t A = __builtin_amdgcn_make_buffer_rsrc(bufs.aux, 0, -1, 0x00020000);
-    const int B4 = 4 * P.num_envs;   // bytes per row
-    auto ld = [eo](const __amdgpu_buffer_rsrc_t rs, int row_off) -> float {
-        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)eo, row_off, 0));
-    };
-    auto stf = [eo](const __amdgpu_buffer_rsrc_t rs, int row_off, float v) {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, (int)eo, row_off, 0);
-    };
+    const EplIO io(bufs.state, bufs.aux, P.num_envs, e);   // this lane's column of the [rows][B] arrays (rsx_epl_common.hpp)
+    const uint32_t eo = io.eo;
+    const __amdgpu_buffer_rsrc_t S = io.S, A = io.A;
 
     // Register budget: four waves per SIMD need <= 128 VGPRs, so in single-step launches nothing is
     // kept in registers longer than it is needed: the OU state goes back to memory as soon as the
@@ -130,20 +97,20 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
 #pragma unroll
     for (int k = 0; k < N; ++k) {
 #pragma unroll
-        for (int f = 0; f < 6; ++f) raw[k][f] = ld(S, (5 + 6 * k + f) * B4);
+        for (int f = 0; f < 6; ++f) raw[k][f] = io.ld(S, 5 + 6 * k + f);
         ou[k][0] = ou[k][1] = 0.0f;
-        if (k >= 1) { ou[k][0] = ld(A, (ROW_OU + 2 * k) * B4); ou[k][1] = ld(A, (ROW_OU + 2 * k + 1) * B4); }
+        if (k >= 1) { ou[k][0] = io.ld(A, ROW_OU + 2 * k); ou[k][1] = io.ld(A, ROW_OU + 2 * k + 1); }
     }
     {
 #pragma unroll
-        for (int f = 0; f < 5; ++f) rawb[f] = ld(S, f * B4);
-        rawb[5] = ld(S, P.state_dim * B4);
-        rawb[6] = ld(S, (P.state_dim + 1) * B4);
+        for (int f = 0; f < 5; ++f) rawb[f] = io.ld(S, f);
+        rawb[5] = io.ld(S, P.state_dim);
+        rawb[6] = io.ld(S, P.state_dim + 1);
         if (!STEP) {   // (single-step launches fetch the episode bookkeeping after the physics: nothing of it is live before)
-            steps = __float_as_int(ld(A, ROW_STEPS * B4));
-            episode = __float_as_uint(ld(A, ROW_EPISODE * B4));
+            steps = __float_as_int(io.ld(A, ROW_STEPS));
+            episode = __float_as_uint(io.ld(A, ROW_EPISODE));
 #pragma unroll
-            for (int i = 1; i <= 3; ++i) info[i] = ld(A, (ROW_INFO + i) * B4);
+            for (int i = 1; i <= 3; ++i) info[i] = io.ld(A, ROW_INFO + i);
         }
     }
     const bool counts_steps = blockIdx.x == 0 && lane == 0;   // metrics[0]: see task_step_kernel (read-modify-write at the end: no 64-bit value held across the step)
@@ -215,7 +182,7 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
             q0[k] = vss_wheel(a0); q1[k] = vss_wheel(a1);
             const float qq[2] = {q0[k], q1[k]};
             robot_targets<KIND>(P, r[k], qq);
-            if (STEP && k >= 1 && live) { stf(A, (ROW_OU + 2 * k) * B4, ou[k][0]); stf(A, (ROW_OU + 2 * k + 1) * B4, ou[k][1]); }
+            if (STEP && k >= 1 && live) { io.st(A, ROW_OU + 2 * k, ou[k][0]); io.st(A, ROW_OU + 2 * k + 1, ou[k][1]); }
             if (STEP) __builtin_amdgcn_sched_barrier(0);   // one robot after the other: interleaving them for ILP costs a wave of occupancy
         }
         float energy = -(fabsf(q0[0]) + fabsf(q1[0]));   // the agent's wheel commands: energy term of the reward
@@ -236,7 +203,8 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
             constexpr uint32_t T_RR = __builtin_bit_cast(uint32_t, K::rs_rr2) - 1u;
             constexpr uint32_t T_RB = __builtin_bit_cast(uint32_t, K::rs_rb2) - 1u;
             // bits of `touching` that involve body k (pairs in lexicographic order, see epl_pair)
-            constexpr unsigned PM[EPL_NB] = {0x00003Fu, 0x0007C1u, 0x007842u, 0x038884u, 0x0C9108u, 0x152210u, 0x1A4420u};
+            constexpr unsigned PM[EPL_NB] = {epl_pair_mask<EPL_NB>(0), epl_pair_mask<EPL_NB>(1), epl_pair_mask<EPL_NB>(2), epl_pair_mask<EPL_NB>(3),
+                                             epl_pair_mask<EPL_NB>(4), epl_pair_mask<EPL_NB>(5), epl_pair_mask<EPL_NB>(6)};
             auto find_touching = [&]() -> unsigned {
                 // bit p = pair p touches.  The pairs are visited in REVERSE order and each result is shifted in from the
                 // right (acc = acc + acc + bit: a compare and ONE add-with-carry per pair, no bit constant in a register),
@@ -261,62 +229,14 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
                 if (sweep == 1 && !__any(deep)) break;   // no env of the wave had a deep pair: no second pair test either
                 const unsigned touching = (sweep == 0 || deep) ? find_touching() : 0u;   // second: envs with a deep pair only
                 if (!__any(touching != 0)) break;
-                // some env of the wave has a contact: the sums are addressed by body index and go through
-                // LDS (column = lane, conflict free); the bodies themselves are picked out of the registers
-                // by select chains (a snapshot in LDS would cost a wave of occupancy: 9 KB per wave)
-#pragma unroll
-                for (int k = 0; k < EPL_NB; ++k) {
-                    sh.c.acc[0][k][lane] = 0.0f; sh.c.acc[1][k][lane] = 0.0f;
-                    sh.c.acc[2][k][lane] = 0.0f; sh.c.acc[3][k][lane] = 0.0f;
-                }
-                sh.c.accw[lane] = 0.0f;
+                // some env of the wave has a contact: sums in LDS, pairs walked per lane, both sides of a pair from one normal
+                // (epl_walk_pairs, rsx_epl_common.hpp: the ball is body N, a circle like the robots)
+                epl_zero_sums(sh.c, lane);
                 wave_sync();
                 deep = false;
-                unsigned todo = touching;
-                while (todo) {   // each lane walks ITS touching pairs, in pair order
-                    const int p = __builtin_ctz(todo);
-                    todo &= todo - 1;
-                    int i, j;
-                    epl_pair(p, i, j);
-                    const bool rb = j == N;
-                    Body bi = Body{}, bj = Body{};
-                    float wi = 0.0f, wj = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < N; ++k) {   // i < N always; j may be the ball
-                        { const bool m = i == k; bi.x = m ? r[k].x : bi.x; bi.y = m ? r[k].y : bi.y; bi.vx = m ? r[k].vx : bi.vx; bi.vy = m ? r[k].vy : bi.vy; wi = m ? r[k].om : wi; }   // selects, not branches
-                        { const bool m = j == k; bj.x = m ? r[k].x : bj.x; bj.y = m ? r[k].y : bj.y; bj.vx = m ? r[k].vx : bj.vx; bj.vy = m ? r[k].vy : bj.vy; wj = m ? r[k].om : wj; }
-                    }
-                    if (j == N) { bj.x = ball.x; bj.y = ball.y; bj.vx = ball.vx; bj.vy = ball.vy; wj = ball.om; }
-                    const float rs = rb ? K::rs_rb : K::rs_rr, ope = rb ? K::ope_rb : K::ope_rr;
-                    const float mu = rb ? K::mu_rb : K::mu_rr;
-                    const float lever_j = rb ? K::r_ball : K::r_robot;
-                    // both sides of the pair with one normal (contact_pair, rsx_body.hpp); each body's sums are read-modify-written
-                    // in pair order = partner-index order
-                    float ai[4] = {sh.c.acc[0][i][lane], sh.c.acc[1][i][lane], sh.c.acc[2][i][lane], sh.c.acc[3][i][lane]};
-                    float aj[4] = {sh.c.acc[0][j][lane], sh.c.acc[1][j][lane], sh.c.acc[2][j][lane], sh.c.acc[3][j][lane]};
-                    float awj = rb ? sh.c.accw[lane] : 0.0f;
-                    contact_pair(bi, bj, fma_(wj, lever_j, wi * K::r_robot), fma_(wi, K::r_robot, wj * lever_j), rs, ope,
-                                 rb ? K::w_rb_r : K::w_rr, rb ? K::w_rb_b : K::w_rr, rb ? K::kt_rb_r : K::kt_rr, rb ? K::kt_rb_b : K::kt_rr,
-                                 mu, rb ? K::spin_c : 0.0f, K::beta, K::pen2, ai, aj, awj, deep);
-                    sh.c.acc[0][i][lane] = ai[0]; sh.c.acc[1][i][lane] = ai[1]; sh.c.acc[2][i][lane] = ai[2]; sh.c.acc[3][i][lane] = ai[3];
-                    sh.c.acc[0][j][lane] = aj[0]; sh.c.acc[1][j][lane] = aj[1]; sh.c.acc[2][j][lane] = aj[2]; sh.c.acc[3][j][lane] = aj[3];
-                    if (rb) sh.c.accw[lane] = awj;
-                }
+                epl_walk_pairs<KIND, N, true>(r, ball, sh.c, lane, touching, deep);
                 wave_sync();
-                // only a body that touched something is updated (the others keep their bits); the registers
-                // still hold the snapshot: nothing was modified during the walk
-#pragma unroll
-                for (int k = 0; k < N; ++k) {
-                    if (touching & PM[k]) {
-                        r[k].vx = r[k].vx + sh.c.acc[0][k][lane]; r[k].vy = r[k].vy + sh.c.acc[1][k][lane];
-                        r[k].x = r[k].x + sh.c.acc[2][k][lane]; r[k].y = r[k].y + sh.c.acc[3][k][lane];
-                    }
-                }
-                if (touching & PM[N]) {
-                    ball.vx = ball.vx + sh.c.acc[0][N][lane]; ball.vy = ball.vy + sh.c.acc[1][N][lane];
-                    ball.x = ball.x + sh.c.acc[2][N][lane]; ball.y = ball.y + sh.c.acc[3][N][lane];
-                    ball.om = ball.om + sh.c.accw[lane];
-                }
+                epl_apply_sums<N>(r, ball, sh.c, lane, [&](int k) { return (touching & PM[k]) != 0; });   // (the registers still held the snapshot)
                 wave_sync();
             }
             // C: walls
@@ -327,10 +247,10 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
 
         // ---- wire-format values, observation, reward ----
         if (STEP) {   // episode bookkeeping and cumulative shaping terms: fetched now, used after the observation
-            steps = __float_as_int(ld(A, ROW_STEPS * B4));
-            episode = __float_as_uint(ld(A, ROW_EPISODE * B4));
+            steps = __float_as_int(io.ld(A, ROW_STEPS));
+            episode = __float_as_uint(io.ld(A, ROW_EPISODE));
 #pragma unroll
-            for (int i = 1; i <= 3; ++i) info[i] = ld(A, (ROW_INFO + i) * B4);
+            for (int i = 1; i <= 3; ++i) info[i] = io.ld(A, ROW_INFO + i);
         }
         const bool first_step = steps == 0;
         float ob[EPL_OD];   // this env's observation, in registers
@@ -342,8 +262,7 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
             sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
             epl_obs_robot(P, ob, k, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, wd);
             if (STEP && live) {   // wire format, robot by robot (an env that resets below writes its rows again)
-                const int p0 = (5 + 6 * k) * B4;
-                stf(S, p0, r[k].x); stf(S, p0 + B4, r[k].y); stf(S, p0 + 2 * B4, r[k].th); stf(S, p0 + 3 * B4, r[k].vx); stf(S, p0 + 4 * B4, r[k].vy); stf(S, p0 + 5 * B4, wd);
+                io.st_robot(5 + 6 * k, r[k].x, r[k].y, r[k].th, r[k].vx, r[k].vy, wd);
             }
             if (STEP) __builtin_amdgcn_sched_barrier(0);
         }
@@ -378,22 +297,18 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
         const bool ended = live && (term | trunc);
         if (live) {
 #pragma unroll
-            for (int i = 1; i <= 3; ++i) stf(A, (ROW_INFO + i) * B4, info[i]);
+            for (int i = 1; i <= 3; ++i) io.st(A, ROW_INFO + i, info[i]);
             if (term || first_step) {   // goal counters: non-zero on a terminal step only, cleared on the next first step
-                stf(A, (ROW_INFO + 0) * B4, info[0]); stf(A, (ROW_INFO + 4) * B4, info[4]); stf(A, (ROW_INFO + 5) * B4, info[5]);
+                io.st(A, ROW_INFO + 0, info[0]); io.st(A, ROW_INFO + 4, info[4]); io.st(A, ROW_INFO + 5, info[5]);
             }
-            stf(A, ROW_REWARD * B4, reward);
-            {
-                const __amdgpu_buffer_rsrc_t FL = __builtin_amdgcn_make_buffer_rsrc(bufs.flags, 0, -1, 0x00020000);
-                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)term, FL, (int)(eo >> 2), 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)trunc, FL, (int)(eo >> 2), P.num_envs, 0);
-            }
+            io.st(A, ROW_REWARD, reward);
+            io.st_flags(bufs.flags, P.num_envs, term, trunc);
         }
 
         // ---- episode end: same-step auto-reset, one lane = one env ----
         if (__any(ended)) {
             if (ended) {
-                epl_store_row(bufs.final_obs, eo, ob);   // terminal observation
+                epl_store_row<EPL_OD>(bufs.final_obs, eo, ob);   // terminal observation
                 episode += 1; new_episode = true;
                 unsigned long long* const ms = metric_slot(bufs);
                 atomicAdd(&ms[1], 1ull);
@@ -447,9 +362,8 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
                     sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
                     epl_obs_robot(P, ob, k, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, 0.0f);
                     if (STEP && live) {   // this env's rows were written before the reset was known
-                        const int p0 = (5 + 6 * k) * B4;
-                        stf(S, p0, r[k].x); stf(S, p0 + B4, r[k].y); stf(S, p0 + 2 * B4, r[k].th); stf(S, p0 + 3 * B4, 0.0f); stf(S, p0 + 4 * B4, 0.0f); stf(S, p0 + 5 * B4, 0.0f);
-                        if (k >= 1) { stf(A, (ROW_OU + 2 * k) * B4, 0.0f); stf(A, (ROW_OU + 2 * k + 1) * B4, 0.0f); }
+                        io.st_robot(5 + 6 * k, r[k].x, r[k].y, r[k].th, 0.0f, 0.0f, 0.0f);
+                        if (k >= 1) { io.st(A, ROW_OU + 2 * k, 0.0f); io.st(A, ROW_OU + 2 * k + 1, 0.0f); }
                     }
                 }
                 ball = Body{};
@@ -458,7 +372,7 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
             }
         }
         // ---- observation out: this lane's row, ten 16-byte stores ----
-        if (live) epl_store_row(bufs.obs, eo, ob);
+        if (live) epl_store_row<EPL_OD>(bufs.obs, eo, ob);
     }
 
     // ---- store (wire format) ----
@@ -466,18 +380,17 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
         if (!STEP) {
 #pragma unroll
             for (int k = 0; k < N; ++k) {
-                const int p0 = (5 + 6 * k) * B4;
-                stf(S, p0, r[k].x); stf(S, p0 + B4, r[k].y); stf(S, p0 + 2 * B4, r[k].th); stf(S, p0 + 3 * B4, r[k].vx); stf(S, p0 + 4 * B4, r[k].vy); stf(S, p0 + 5 * B4, wdeg[k]);
-                if (k >= 1) { stf(A, (ROW_OU + 2 * k) * B4, ou[k][0]); stf(A, (ROW_OU + 2 * k + 1) * B4, ou[k][1]); }
+                io.st_robot(5 + 6 * k, r[k].x, r[k].y, r[k].th, r[k].vx, r[k].vy, wdeg[k]);
+                if (k >= 1) { io.st(A, ROW_OU + 2 * k, ou[k][0]); io.st(A, ROW_OU + 2 * k + 1, ou[k][1]); }
             }
         }
-        stf(S, 0, ball.x); stf(S, B4, ball.y); stf(S, 3 * B4, ball.vx); stf(S, 4 * B4, ball.vy);
+        io.st(S, 0, ball.x); io.st(S, 1, ball.y); io.st(S, 3, ball.vx); io.st(S, 4, ball.vy);
         const float z_out = K::r_ball + ball.z;
         if (ball_extra_in || z_out != K::r_ball || ball.vz != 0.0f || ball.om != 0.0f) {   // was or is off its resting values
-            stf(S, 2 * B4, z_out); stf(S, P.state_dim * B4, ball.vz); stf(S, (P.state_dim + 1) * B4, ball.om);
+            io.st(S, 2, z_out); io.st(S, P.state_dim, ball.vz); io.st(S, P.state_dim + 1, ball.om);
         }
-        stf(A, ROW_STEPS * B4, __int_as_float(steps));
-        if (!STEP || new_episode) stf(A, ROW_EPISODE * B4, __uint_as_float(episode));
+        io.st(A, ROW_STEPS, __int_as_float(steps));
+        if (!STEP || new_episode) io.st(A, ROW_EPISODE, __uint_as_float(episode));
     }
     if (counts_steps) bufs.metrics[0] = bufs.metrics[0] + (unsigned long long)P.num_envs * (unsigned long long)n_steps;
 }

@@ -19,7 +19,7 @@
 // a mouth or infrared contact needs < 12.6 cm), the ball's flight, SSL walls, eleven state rows per robot
 // (infrared and four wheel speeds are outputs: written every step, read only when the step has no physics).
 #pragma once
-#include "rsx_kernels.hpp"
+#include "rsx_epl_common.hpp"
 
 namespace rsx {
 
@@ -28,7 +28,7 @@ struct SeplShared {
     // contact sums (column = lane); the same bytes are the pose scratch A[body][lane] of a reset placement
     // (place_env).  Observations stay in registers and go out as vector stores (see rsx_epl.hpp).
     union {
-        struct { float acc[4][N + 1][64]; float accw[64]; } c;
+        EplSums<N + 1> c;
         float4 A[(N + 1) * 64];
     };
 };
@@ -38,44 +38,6 @@ template <> struct SeplTask<RSX_TASK_SSL_STATIC_DEFENDERS> { static constexpr in
 template <> struct SeplTask<RSX_TASK_SSL_DRIBBLING> { static constexpr int N = 5, NBLUE = 1, OD = 21, NCMD = 1, WMIN = 4, WMAX = 8; };          // dribbling.py:45-46
 template <> struct SeplTask<RSX_TASK_SSL_CONTESTED> { static constexpr int N = 2, NBLUE = 1, OD = 14, NCMD = 1, WMIN = 4, WMAX = 8; };          // contested_possession.py:46-47
 template <> struct SeplTask<RSX_TASK_SSL_PASS_ENDURANCE> { static constexpr int N = 2, NBLUE = 2, OD = 16, NCMD = 2, WMIN = 4, WMAX = 8; };     // pass_endurance.py:45-46
-
-// one observation row from registers: the widest stores the row's alignment allows (rows are OD floats apart)
-template <int OD>
-__device__ __forceinline__ void sepl_store_row(float* dst, const float* ob) {
-    if (OD % 4 == 0) {
-        float4* d4 = reinterpret_cast<float4*>(dst);
-#pragma unroll
-        for (int i = 0; i < OD / 4; ++i) d4[i] = make_float4(ob[4 * i], ob[4 * i + 1], ob[4 * i + 2], ob[4 * i + 3]);
-    } else if (OD % 2 == 0) {
-        float2* d2 = reinterpret_cast<float2*>(dst);
-#pragma unroll
-        for (int i = 0; i < OD / 2; ++i) d2[i] = make_float2(ob[2 * i], ob[2 * i + 1]);
-    } else {
-#pragma unroll
-        for (int i = 0; i < OD; ++i) dst[i] = ob[i];
-    }
-}
-
-// pair p -> (i, j), i < j < N, lexicographic: row r of the upper triangle starts at r*N - r*(r+1)/2
-template <int N>
-__device__ __forceinline__ void sepl_pair(int p, int& i, int& j) {
-    i = 0;
-#pragma unroll
-    for (int r = 1; r < N - 1; ++r) i += (int)(p >= r * N - r * (r + 1) / 2);   // sums of comparisons: no branches
-    const int start = i * N - ((i * (i + 1)) >> 1);
-    j = i + 1 + (p - start);
-}
-// bits of the pair set that involve robot k
-template <int N>
-__host__ __device__ constexpr unsigned sepl_pair_mask(int k) {
-    unsigned m = 0;
-    int p = 0;
-    for (int i = 0; i < N; ++i)
-        for (int j = i + 1; j < N; ++j, ++p)
-            if (i == k || j == k) m |= 1u << p;
-    return m;
-}
-static_assert(sepl_pair_mask<7>(0) == 0x00003Fu && sepl_pair_mask<7>(3) == 0x038884u && sepl_pair_mask<7>(6) == 0x1A4420u, "pair masks");
 
 // occupancy target (waves per SIMD): the 1v6 kernel holds 7 robots in registers (3-4 measured best); the smaller
 // tasks fit 128 VGPRs (4 waves) without spilling — 6 and 8 waves spill and measured 1.4x / 2.3x slower, 3 the same
@@ -100,17 +62,9 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
     const int e = live ? e_raw : P.num_envs - 1;   // lanes beyond the batch shadow its last env (loads valid and unconditional; stores, counters masked)
     const size_t B = (size_t)P.num_envs;
     const uint32_t env_id = P.env_id_base + (uint32_t)e;
-    // buffer addressing (see rsx_epl.hpp): resource per array + row as the scalar offset + one 32-bit lane offset
-    const uint32_t eo = 4u * (uint32_t)e;
-    const __amdgpu_buffer_rsrc_t S = __builtin_amdgcn_make_buffer_rsrc(bufs.state, 0, -1, 0x00020000);
-    const __amdgpu_buffer_rsrc_t A = __builtin_amdgcn_make_buffer_rsrc(bufs.aux, 0, -1, 0x00020000);
-    const int B4 = 4 * P.num_envs;   // bytes per row
-    auto ld = [eo](const __amdgpu_buffer_rsrc_t rs, int row_off) -> float {
-        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)eo, row_off, 0));
-    };
-    auto stf = [eo](const __amdgpu_buffer_rsrc_t rs, int row_off, float v) {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, (int)eo, row_off, 0);
-    };
+    const EplIO io(bufs.state, bufs.aux, P.num_envs, e);   // this lane's column of the [rows][B] arrays (rsx_epl_common.hpp)
+    const uint32_t eo = io.eo;
+    const __amdgpu_buffer_rsrc_t S = io.S, A = io.A;
 
     RSX_STAMP(0);
     // ---- load ----
@@ -125,24 +79,24 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
 #pragma unroll
     for (int k = 0; k < N; ++k) {
 #pragma unroll
-        for (int f = 0; f < 6; ++f) raw[k][f] = ld(S, (5 + RS * k + f) * B4);
+        for (int f = 0; f < 6; ++f) raw[k][f] = io.ld(S, 5 + RS * k + f);
         ir_in[k] = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) wheels[k][i] = 0.0f;
         // infrared is refreshed by every step that has physics; a step without (time_step 0) keeps the stored flag
-        if (P.n_sub == 0) ir_in[k] = ld(S, (5 + RS * k + 6) * B4) != 0.0f;
+        if (P.n_sub == 0) ir_in[k] = io.ld(S, 5 + RS * k + 6) != 0.0f;
     }
     {
 #pragma unroll
-        for (int f = 0; f < 5; ++f) rawb[f] = ld(S, f * B4);
-        rawb[5] = ld(S, P.state_dim * B4);
-        rawb[6] = ld(S, (P.state_dim + 1) * B4);
-        steps = __float_as_int(ld(A, ROW_STEPS * B4));
-        episode = __float_as_uint(ld(A, ROW_EPISODE * B4));
+        for (int f = 0; f < 5; ++f) rawb[f] = io.ld(S, f);
+        rawb[5] = io.ld(S, P.state_dim);
+        rawb[6] = io.ld(S, P.state_dim + 1);
+        steps = __float_as_int(io.ld(A, ROW_STEPS));
+        episode = __float_as_uint(io.ld(A, ROW_EPISODE));
 #pragma unroll
-        for (int i = 0; i < ID; ++i) info[i] = ld(A, (ROW_INFO + i) * B4);
-        ep_ret = ld(A, ROW_EP_RET * B4);
-        if (HAS_TS) prev_pot = ld(A, ROW_PREV_POT * B4);
+        for (int i = 0; i < ID; ++i) info[i] = io.ld(A, ROW_INFO + i);
+        ep_ret = io.ld(A, ROW_EP_RET);
+        if (HAS_TS) prev_pot = io.ld(A, ROW_PREV_POT);
     }
     const bool counts_steps = blockIdx.x == 0 && lane == 0;   // metrics[0]: see task_step_kernel
     unsigned long long steps_before = 0;
@@ -253,36 +207,11 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
                 if (sub == 0 && sweep == 0) RSX_STAMP(5);
                 if (!__any((touching | near) != 0)) break;
                 const bool first = sweep == 0;
-#pragma unroll
-                for (int k = 0; k < NB1; ++k) {
-                    sh.c.acc[0][k][lane] = 0.0f; sh.c.acc[1][k][lane] = 0.0f;
-                    sh.c.acc[2][k][lane] = 0.0f; sh.c.acc[3][k][lane] = 0.0f;
-                }
-                sh.c.accw[lane] = 0.0f;
+                epl_zero_sums(sh.c, lane);
                 wave_sync();
                 deep = false;
-                // robot-robot pairs, in pair order: every body receives its partners in index order
-                unsigned todo = touching;
-                while (todo) {
-                    const int p = __builtin_ctz(todo);
-                    todo &= todo - 1;
-                    int i, j;
-                    sepl_pair<N>(p, i, j);
-                    Body bi = Body{}, bj = Body{};
-                    float wi = 0.0f, wj = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < N; ++k) {
-                        { const bool m = i == k; bi.x = m ? r[k].x : bi.x; bi.y = m ? r[k].y : bi.y; bi.vx = m ? r[k].vx : bi.vx; bi.vy = m ? r[k].vy : bi.vy; wi = m ? r[k].om : wi; }   // selects, not branches
-                        { const bool m = j == k; bj.x = m ? r[k].x : bj.x; bj.y = m ? r[k].y : bj.y; bj.vx = m ? r[k].vx : bj.vx; bj.vy = m ? r[k].vy : bj.vy; wj = m ? r[k].om : wj; }
-                    }
-                    float ai[4] = {sh.c.acc[0][i][lane], sh.c.acc[1][i][lane], sh.c.acc[2][i][lane], sh.c.acc[3][i][lane]};
-                    float aj[4] = {sh.c.acc[0][j][lane], sh.c.acc[1][j][lane], sh.c.acc[2][j][lane], sh.c.acc[3][j][lane]};
-                    float unused = 0.0f;
-                    contact_pair(bi, bj, fma_(wj, K::r_robot, wi * K::r_robot), fma_(wi, K::r_robot, wj * K::r_robot), K::rs_rr, K::ope_rr,
-                                 K::w_rr, K::w_rr, K::kt_rr, K::kt_rr, K::mu_rr, 0.0f, K::beta, K::pen2, ai, aj, unused, deep);   // both sides, one normal (rsx_body.hpp)
-                    sh.c.acc[0][i][lane] = ai[0]; sh.c.acc[1][i][lane] = ai[1]; sh.c.acc[2][i][lane] = ai[2]; sh.c.acc[3][i][lane] = ai[3];
-                    sh.c.acc[0][j][lane] = aj[0]; sh.c.acc[1][j][lane] = aj[1]; sh.c.acc[2][j][lane] = aj[2]; sh.c.acc[3][j][lane] = aj[3];
-                }
+                // robot-robot pairs, in pair order: every body receives its partners in index order (rsx_epl_common.hpp)
+                epl_walk_pairs<KIND, N, false>(r, ball, sh.c, lane, touching, deep);
                 // robot-ball, robot by robot (the ball sums the robots' records in robot order): kicker mouth
                 // (flat face at dck) or body circle; n points robot -> ball.  Mirrors ssl_sweep.
                 unsigned rb_touch = 0;   // robots that touch the ball in this sweep
@@ -364,19 +293,9 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
                     }
                 }
                 wave_sync();
-                // only a body that touched something is updated (the others keep their bits)
-#pragma unroll
-                for (int k = 0; k < N; ++k) {
-                    if ((touching & sepl_pair_mask<N>(k)) | (rb_touch & (1u << k))) {   // pair bits that involve robot k
-                        r[k].vx = r[k].vx + sh.c.acc[0][k][lane]; r[k].vy = r[k].vy + sh.c.acc[1][k][lane];
-                        r[k].x = r[k].x + sh.c.acc[2][k][lane]; r[k].y = r[k].y + sh.c.acc[3][k][lane];
-                    }
-                }
-                if (rb_touch) {
-                    ball.vx = ball.vx + sh.c.acc[0][N][lane]; ball.vy = ball.vy + sh.c.acc[1][N][lane];
-                    ball.x = ball.x + sh.c.acc[2][N][lane]; ball.y = ball.y + sh.c.acc[3][N][lane];
-                    ball.om = ball.om + sh.c.accw[lane];
-                }
+                epl_apply_sums<N>(r, ball, sh.c, lane, [&](int k) {   // only a body that touched something is updated
+                    return k == N ? rb_touch != 0 : ((touching & epl_pair_mask<N>(k)) | (rb_touch & (1u << k))) != 0;
+                });
                 wave_sync();
             }
             if (sub == 0) RSX_STAMP(6);
@@ -428,16 +347,16 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
         const bool ended = live && (term | trunc);
         if (live) {
 #pragma unroll
-            for (int i = 0; i < ID; ++i) stf(A, (ROW_INFO + i) * B4, info[i]);
-            stf(A, ROW_REWARD * B4, reward);
-            bufs.flags[e] = (uint8_t)term; bufs.flags[B + e] = (uint8_t)trunc;
+            for (int i = 0; i < ID; ++i) io.st(A, ROW_INFO + i, info[i]);
+            io.st(A, ROW_REWARD, reward);
+            io.st_flags(bufs.flags, P.num_envs, term, trunc);
         }
 
         RSX_STAMP(10);
         // ---- episode end: same-step auto-reset, one lane = one env ----
         if (__any(ended)) {
             if (ended) {
-                sepl_store_row<OD>(bufs.final_obs + (size_t)e * OD, ob);   // terminal observation
+                epl_store_row<OD>(bufs.final_obs, eo, ob);   // terminal observation
                 episode += 1;
                 unsigned long long* const ms = metric_slot(bufs);
                 atomicAdd(&ms[1], 1ull);
@@ -471,7 +390,7 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
             }
         }
         // ---- observation out: this lane's row ----
-        if (live) sepl_store_row<OD>(bufs.obs + (size_t)e * OD, ob);
+        if (live) epl_store_row<OD>(bufs.obs, eo, ob);
     }
 
     RSX_STAMP(11);
@@ -479,19 +398,18 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
     if (live) {
 #pragma unroll
         for (int k = 0; k < N; ++k) {
-            const int p0 = (5 + RS * k) * B4;
-            stf(S, p0, r[k].x); stf(S, p0 + B4, r[k].y); stf(S, p0 + 2 * B4, r[k].th); stf(S, p0 + 3 * B4, r[k].vx); stf(S, p0 + 4 * B4, r[k].vy); stf(S, p0 + 5 * B4, wdeg[k]);
-            stf(S, p0 + 6 * B4, r[k].ir ? 1.0f : 0.0f);
+            io.st_robot(5 + RS * k, r[k].x, r[k].y, r[k].th, r[k].vx, r[k].vy, wdeg[k]);
+            io.st(S, 5 + RS * k + 6, r[k].ir ? 1.0f : 0.0f);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) stf(S, p0 + (7 + i) * B4, wheels[k][i]);
+            for (int i = 0; i < 4; ++i) io.st(S, 5 + RS * k + 7 + i, wheels[k][i]);
         }
-        stf(S, 0, ball.x); stf(S, B4, ball.y); stf(S, 2 * B4, K::r_ball + ball.z); stf(S, 3 * B4, ball.vx); stf(S, 4 * B4, ball.vy);
-        stf(S, P.state_dim * B4, ball.vz);
-        stf(S, (P.state_dim + 1) * B4, ball.om);
-        stf(A, ROW_STEPS * B4, __int_as_float(steps));
-        stf(A, ROW_EPISODE * B4, __uint_as_float(episode));
-        stf(A, ROW_EP_RET * B4, ep_ret);
-        if (HAS_TS) stf(A, ROW_PREV_POT * B4, prev_pot);
+        io.st(S, 0, ball.x); io.st(S, 1, ball.y); io.st(S, 2, K::r_ball + ball.z); io.st(S, 3, ball.vx); io.st(S, 4, ball.vy);
+        io.st(S, P.state_dim, ball.vz);
+        io.st(S, P.state_dim + 1, ball.om);
+        io.st(A, ROW_STEPS, __int_as_float(steps));
+        io.st(A, ROW_EPISODE, __uint_as_float(episode));
+        io.st(A, ROW_EP_RET, ep_ret);
+        if (HAS_TS) io.st(A, ROW_PREV_POT, prev_pot);
     }
     if (counts_steps) bufs.metrics[0] = steps_before + (unsigned long long)P.num_envs * (unsigned long long)n_steps;
     RSX_STAMP(12);
