@@ -48,7 +48,7 @@ METRIC = "env-steps/sec (whole node), VSS-v0 3v3 @4096 envs, 1/2/4/8 GPU + CPU r
 ALLREDUCE_EVERY = 100           # steps between metrics all-reduces
 STEADY_STEPS, STEADY_WARMUP = 2000, 200
 SWEEP_ENVS = (65536, 1048576, 4194304)
-EPL_MIN_ENVS = 131072           # rsx_api.hip: batches from here on use the one-lane-per-env kernel
+EPL_MIN_ENVS = 98304            # rsx_api.hip: batches from here on use the one-lane-per-env kernel
 
 
 def usable_cores():

@@ -41,11 +41,12 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 }  // namespace
 
-// smallest batch stepped by the one-lane-per-env kernels (measured crossovers, profiles/): VSS-v0 at
-// 131 072 envs; the SSL tasks at 65 536 (single-step launches break even there, multi-step launches
-// are already 1.3-2.5x faster)
+// smallest batch stepped by the one-lane-per-env kernels: measured crossovers of single-step launches (round 3,
+// gpurun_out/xover.txt -> profiles/r03_layout_crossovers.txt; multi-step launches cross earlier): VSS-v0 98 304 envs
+// (31.5 vs 29.3 us), static defenders 65 536 (29.2 vs 28.5), dribbling 49 152 (30.0 vs 29.2), contested possession
+// 32 768 (19.5 vs 18.8), pass endurance 32 768 (17.8 vs 15.3)
 #ifndef RSX_EPL_MIN_ENVS
-#define RSX_EPL_MIN_ENVS 131072
+#define RSX_EPL_MIN_ENVS 98304
 #endif
 // smallest batch of the SSL 11v11 scrimmage task stepped by the large-batch build of its kernel (rsx_big.hip)
 #ifndef RSX_BIG_MIN_ENVS
@@ -664,7 +665,8 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
         const char* lay = std::getenv("RSX_LAYOUT");
         if (lay && std::strcmp(lay, "epl") == 0) h->epl = true;
         else if (lay && std::strcmp(lay, "lanes") == 0) h->epl = false;
-        else h->epl = P.num_envs >= (task == RSX_TASK_VSS_V0 ? RSX_EPL_MIN_ENVS : RSX_EPL_MIN_ENVS_SSL);
+        else h->epl = P.num_envs >= (task == RSX_TASK_VSS_V0 ? RSX_EPL_MIN_ENVS : task == RSX_TASK_SSL_STATIC_DEFENDERS ? RSX_EPL_MIN_ENVS_SSL
+                                     : task == RSX_TASK_SSL_DRIBBLING ? 49152 : 32768);
         // those kernels address rows with 32-bit byte offsets (buffer instructions): arrays of 2 GB and more stay with the lane-group kernels
         const size_t rows = (size_t)std::max(P.state_dim + X_ROWS, aux_rows(P.n_robots));
         if (rows * (size_t)P.num_envs * sizeof(float) >= ((size_t)1 << 31) || (size_t)P.num_envs * P.obs_dim * sizeof(float) >= ((size_t)1 << 31)) h->epl = false;

@@ -285,6 +285,18 @@ __device__ __forceinline__ void ball_step_friction(const Params& P, Body& ball) 
         ball.om = aw > 0.0f ? (ball.om < 0.0f ? -aw : aw) : 0.0f;
     }
 }
+// SSL: is this body anywhere near a wall?  walls<SSL> changes nothing while |x| <= half_len (no goal geometry) and |y| <=
+// half_wid + margin - r_robot (the tightest of the y limits, robots' and ball's): kernels test a whole wave's bodies with
+// this and skip the clamp when none is out there (the division-A field is 12 m x 9 m: most sub-steps).  NaN ("ghost"
+// slots of rsx_quad_ssl.hpp) compares false.
+template <int KIND>
+__device__ __forceinline__ bool near_walls(const Params& P, const float x, const float y) {
+    using K = KC<KIND>;
+#ifdef RSX_NO_WALL_SKIP   // development A/B: always run the clamp
+    return true;
+#endif
+    return (fabsf(x) > P.half_len) | (fabsf(y) > (P.half_wid + K::margin) - K::r_robot);
+}
 // the ball's wall clamp incl. the friction of a bounce
 template <int KIND>
 __device__ __forceinline__ void ball_walls(const Params& P, Body& ball) {

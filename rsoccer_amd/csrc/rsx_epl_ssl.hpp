@@ -304,9 +304,16 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
                 if (bo.okick && bo.ovz > 0.0f) ball.vz = bo.ovz;
             }
             // C: walls
+            {   // only when some body of the wave is near a wall (near_walls, rsx_body.hpp: the clamp is the identity elsewhere)
+                bool nw = near_walls<KIND>(P, ball.x, ball.y);
 #pragma unroll
-            for (int k = 0; k < N; ++k) robot_walls<KIND>(P, r[k]);
-            ball_walls<KIND>(P, ball);
+                for (int k = 0; k < N; ++k) nw |= near_walls<KIND>(P, r[k].x, r[k].y);
+                if (__any(nw)) {
+#pragma unroll
+                    for (int k = 0; k < N; ++k) robot_walls<KIND>(P, r[k]);
+                    ball_walls<KIND>(P, ball);
+                }
+            }
             if (sub == 0) RSX_STAMP(7);
         }
         RSX_STAMP(8);

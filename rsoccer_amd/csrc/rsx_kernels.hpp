@@ -517,7 +517,8 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
         // ---- C: walls ----
         // SSL: every lane, no role branch (idle lanes hold zeros: inside every wall) — measured 1-3 % on the SSL tasks;
         // the VSS-v0 3v3 single-step kernel measured 1.5 % slower that way and keeps the branch
-        if (KIND == RSX_KIND_SSL || is_robot || is_ball) {
+        // (SSL also: only when some body of the wave is near a wall — near_walls, rsx_body.hpp: the clamp is the identity elsewhere)
+        if (KIND == RSX_KIND_SSL ? __any(near_walls<KIND>(P, o.x, o.y)) : (is_robot || is_ball)) {
             const float vx0 = o.vx, vy0 = o.vy;
             int hit = 0;
             walls<KIND>(P, is_ball ? K::r_ball : K::r_robot, is_ball ? K::e_wb : K::e_wr, o.x, o.y, o.vx, o.vy, hit);

@@ -361,10 +361,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             ball.vx = bo.ovx; ball.vy = bo.ovy; ball.om = 0.0f;
             if (bo.okick && bo.ovz > 0.0f) ball.vz = bo.ovz;
         }
-        // C: walls
+        // C: walls — only when some body of the wave is near one (near_walls, rsx_body.hpp: exact, the clamp is the identity elsewhere)
+        {
+            bool nw = near_walls<KIND>(P, ball.x, ball.y);
 #pragma unroll
-        for (int m = 0; m < R; ++m) { robot_walls<KIND>(P, r[m]); __builtin_amdgcn_sched_barrier(0); }
-        ball_walls<KIND>(P, ball);
+            for (int m = 0; m < R; ++m) nw |= near_walls<KIND>(P, r[m].x, r[m].y);
+            if (__any(nw)) {
+#pragma unroll
+                for (int m = 0; m < R; ++m) { robot_walls<KIND>(P, r[m]); __builtin_amdgcn_sched_barrier(0); }
+                ball_walls<KIND>(P, ball);
+            }
+        }
     }
 
     // ---- wire-format values, state rows, observation ----

@@ -19,7 +19,7 @@ def leg(sim, n, warm):
     return out
 for name, kind, ft, nb, ny, task, B, n, warm in (("vss", 0, 0, 3, 3, 1, 4096, 4000, 2000), ("vss", 0, 0, 3, 3, 1, 65536, 300, 300),
         ("vss", 0, 0, 3, 3, 1, 1 << 20, 100, 100), ("vss", 0, 0, 3, 3, 1, 1 << 22, 60, 60),
-        ("sd", 1, 2, 1, 6, 2, 2048, 2000, 300), ("sd", 1, 2, 1, 6, 2, 262144, 100, 100), ("drib", 1, 2, 1, 4, 3, 2048, 2000, 300),
+        ("sd", 1, 2, 1, 6, 2, 2048, 2000, 300), ("sd", 1, 2, 1, 6, 2, 262144, 100, 100), ("sd", 1, 2, 1, 6, 2, 1 << 20, 60, 60), ("drib", 1, 2, 1, 4, 3, 1 << 20, 60, 60), ("scrim", 1, 1, 11, 11, 6, 262144, 40, 40), ("drib", 1, 2, 1, 4, 3, 2048, 2000, 300),
         ("cont", 1, 2, 1, 1, 4, 2048, 2000, 300), ("pass", 1, 2, 2, 0, 5, 2048, 2000, 300),
         ("scrim", 1, 1, 11, 11, 6, 1024, 2000, 300), ("scrimC", 1, 1, 11, 11, 7, 1024, 2000, 300), ("scrim", 1, 1, 11, 11, 6, 65536, 100, 50),
         ("scrimC", 1, 1, 11, 11, 7, 65536, 100, 50), ("vss5", 0, 1, 5, 5, 1, 4096, 2000, 300)):

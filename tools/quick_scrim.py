@@ -1,5 +1,5 @@
-"""Development: the 11v11 scrimmage task over batch sizes; with tools/exp_epl_11v11.patch applied (an experimental
-one-lane-per-env variant of the task) RSX_LAYOUT=epl selects that kernel."""
+"""Development: the 11v11 scrimmage task over batch sizes, 32-lanes-per-env kernels (RSX_LAYOUT=lanes) against the
+four-lanes-per-env kernel of rsx_quad_ssl.hpp (RSX_LAYOUT=quad)."""
 import os, subprocess, sys
 CHILD = r'''
 import sys, os, time
@@ -18,6 +18,6 @@ for task, name in ((6, "spread"), (7, "crowded")):
         print(f"11v11 {name:8s} {B:8d} step {out[0]:8.2f} us ({NB*B/out[0]/8e4:5.1f} % of 8 TB/s)  one-launch {out[1]:8.2f} us/step ({NB*B/out[1]/8e4:5.1f} %)", flush=True)
         sim.close()
 '''
-for lay in ("lanes", "epl"):
+for lay in ("lanes", "quad"):
     print("== RSX_LAYOUT=" + lay, flush=True)
     subprocess.run([sys.executable, "-c", CHILD], env=dict(os.environ, RSX_LAYOUT=lay))
