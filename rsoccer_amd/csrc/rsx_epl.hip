@@ -14,6 +14,14 @@ namespace rsx {
 
 // development knob: RSX_EPL_LDS_PAD=<bytes> of dynamic LDS per workgroup limit the waves per CU (occupancy
 // sensitivity measurements); 0 in production
+// tile order of a single-step launch: alternates with the step counter (tile_of_block_zigzag, rsx_kernels.hpp);
+// RSX_EPL_ZIGZAG=0 keeps one direction (development A/B)
+static int step_per_xcd(const Params& P, const dim3& grid) {
+    static const bool zig = !(std::getenv("RSX_EPL_ZIGZAG") && std::atoi(std::getenv("RSX_EPL_ZIGZAG")) == 0);
+    const int per = (int)(grid.x >> 3);
+    return (zig && (P.tick_base & 1u)) ? -per : per;
+}
+
 static unsigned epl_lds_pad() {
     static const unsigned pad = std::getenv("RSX_EPL_LDS_PAD") ? (unsigned)std::atoi(std::getenv("RSX_EPL_LDS_PAD")) : 0u;
     return pad;
@@ -27,7 +35,7 @@ void launch_vss_epl(bool rollout, const Params& P, const Buffers& b, int n_steps
                            P.num_envs, P.state_dim, (int)(grid.x >> 3), n_steps, P, b);
     else
         hipLaunchKernelGGL((vss_epl_kernel<MODE_STEP>), grid, dim3(64), epl_lds_pad(), s, b.state, b.aux, b.actions, b.flags,
-                           P.num_envs, P.state_dim, (int)(grid.x >> 3), n_steps, P, b);
+                           P.num_envs, P.state_dim, step_per_xcd(P, grid), n_steps, P, b);
 }
 
 template <int TASK>
@@ -39,14 +47,14 @@ static void launch_ssl_epl_t(bool rollout, const Params& P, const Buffers& b, in
                            P.num_envs, P.state_dim, (int)(grid.x >> 3), n_steps, P, b);
     else
         hipLaunchKernelGGL((ssl_epl_kernel<TASK, MODE_STEP>), grid, dim3(64), 0, s, b.state, b.aux, b.actions, b.flags,
-                           P.num_envs, P.state_dim, (int)(grid.x >> 3), n_steps, P, b);
+                           P.num_envs, P.state_dim, step_per_xcd(P, grid), n_steps, P, b);
 }
 
 void launch_ssl_quad(const Params& P, const Buffers& b, hipStream_t s) {   // SSL 11v11 scrimmage, four lanes per env, single-step launches
     const int tiles = (P.num_envs + Q_ENVS - 1) / Q_ENVS;
     const dim3 grid((unsigned)(((tiles + 7) / 8) * 8));
     hipLaunchKernelGGL((ssl_quad_kernel<MODE_STEP>), grid, dim3(64), 0, s, b.state, b.aux, b.actions, b.flags,
-                       P.num_envs, P.state_dim, (int)(grid.x >> 3), 1, P, b);
+                       P.num_envs, P.state_dim, step_per_xcd(P, grid), 1, P, b);
 }
 
 void launch_ssl_epl(int task, bool rollout, const Params& P, const Buffers& b, int n_steps, hipStream_t s) {

@@ -67,7 +67,7 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
     const int n_steps = MODE == MODE_ROLLOUT ? hp_n_steps : 1;
     __shared__ EplShared sh;
     const int lane = threadIdx.x;
-    const int tile = tile_of_block(hp_per_xcd);
+    const int tile = tile_of_block_zigzag(hp_per_xcd);
     const int e_raw = tile * 64 + lane;
     const bool live = e_raw < P.num_envs;
     // lanes beyond the batch shadow its last env: every load is valid and unconditional (no branch per load),

@@ -56,7 +56,7 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
     const int n_steps = MODE == MODE_ROLLOUT ? hp_n_steps : 1;
     __shared__ SeplShared<N> sh;
     const int lane = threadIdx.x;
-    const int tile = tile_of_block(hp_per_xcd);
+    const int tile = tile_of_block_zigzag(hp_per_xcd);
     const int e_raw = tile * 64 + lane;
     const bool live = e_raw < P.num_envs;
     const int e = live ? e_raw : P.num_envs - 1;   // lanes beyond the batch shadow its last env (loads valid and unconditional; stores, counters masked)

@@ -633,6 +633,15 @@ __device__ __forceinline__ void store_body(const Params& P, float* __restrict__ 
 __device__ __forceinline__ int tile_of_block(const int per /* gridDim.x / 8: the grid is a multiple of 8 */) {
     return (blockIdx.x & 7) * per + (blockIdx.x >> 3);
 }
+// The large-batch single-step kernels walk an XCD's tiles in ALTERNATING directions from one launch to the next (the
+// launcher negates `per` on odd ticks): the tiles a launch starts with are then the ones the previous launch wrote
+// last, i.e. the part of the batch that still sits in the 256 MB memory-side cache (Infinity Cache survives kernel
+// boundaries; the L2s do not).  Which wave steps which env changes nothing in the results.
+__device__ __forceinline__ int tile_of_block_zigzag(const int per_signed) {
+    const int per = per_signed < 0 ? -per_signed : per_signed;
+    const int q = blockIdx.x >> 3;
+    return (blockIdx.x & 7) * per + (per_signed < 0 ? per - 1 - q : q);
+}
 
 // Kernel arguments.  The first twelve dwords are plain pointers / ints so that the command
 // processor PRELOADS them into SGPRs (-amdgpu-kernarg-preload-count=12, gfx940+): what the first

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     const int q = lane >> 2;           // env of the wave
     const int p = lane & 3;            // which quarter of the robots
     const bool bl = p == 3;            // the ball's lane (reward, termination, episode bookkeeping of the env)
-    const int tile = tile_of_block(hp_per_xcd);
+    const int tile = tile_of_block_zigzag(hp_per_xcd);
     const int e_raw = tile * Q_ENVS + q;
     int live_i = e_raw < P.num_envs ? 1 : 0;
     asm volatile("" : "+v"(live_i));               // decided here: one flag through the step, not the index it is made of
