@@ -391,12 +391,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             for (int m = 0; m < R; ++m) {
                 if (real(m)) {
                     const u2 v = {__builtin_bit_cast(unsigned, clampf(r[m].x * P.inv_max_pos, -1.2f, 1.2f)), __builtin_bit_cast(unsigned, clampf(r[m].y * P.inv_max_pos, -1.2f, 1.2f))};
-                    __builtin_amdgcn_raw_buffer_store_b64(v, rows, (int)oo, 8 * m, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(v, rows, (int)oo, 8 * m, RSX_OBS_AUX);
                 }
             }
             if (bl) {
                 const u2 v = {__builtin_bit_cast(unsigned, clampf(ball.x * P.inv_max_pos, -1.2f, 1.2f)), __builtin_bit_cast(unsigned, clampf(ball.y * P.inv_max_pos, -1.2f, 1.2f))};
-                __builtin_amdgcn_raw_buffer_store_b64(v, rows, (int)((uint32_t)Q_OD * eo), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(v, rows, (int)((uint32_t)Q_OD * eo), 0, RSX_OBS_AUX);
             }
         }
     };

@@ -74,7 +74,7 @@ def raw_random(name, kind, ft, nb, ny, B, bytes_per_step, K=1000):
     sim.close()
 
 
-SCRIM_BYTES = 2 * 4 * (5 + 11 * 22) + 4 * (2 + 2 * 22) + 4 + 1   # state r/w + obs + reward + done (commands are drawn on the device)
+SCRIM_BYTES = 2 * 4 * (5 + 11 * 22) + 4 * 8 * 22 + 4 * (2 + 2 * 22) + 4 + 1   # state r/w + commands + obs + reward + done = 2869 (bench.py's figure; the task draws its commands on the device, so 704 of these bytes are not moved)
 fused("configs[1] VSS-v0 3v3 fused", 0, 0, 3, 3, 1, 4096, 541)
 fused("configs[2] SSLStaticDefenders-v0 1v6 fused", 1, 2, 1, 6, 2, 2048, 981)
 fused("SSLDribbling-v0 1v4 fused", 1, 2, 1, 4, 3, 2048, 2 * 4 * 60 + 4 * 40 + 4 * 21 + 5)

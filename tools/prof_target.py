@@ -12,6 +12,9 @@ kind, ft, nb, ny = {1: (0, 0, 3, 3), 2: (1, 2, 1, 6), 3: (1, 2, 1, 4), 4: (1, 2,
 sim = L.Sim(kind, ft, nb, ny, 25, B)
 sim.task_attach(task, 0, 0, 0)
 sim.task_reset()
+# optional 5th argument: steps of warm-up in ONE launch first (another kernel name), so that the profiled launches are steady-state steps
+if len(sys.argv) > 5 and int(sys.argv[5]) > 0:
+    sim.task_rollout(int(sys.argv[5]))
 torch.cuda.synchronize()
 if mode == "step":
     for _ in range(n):

@@ -41,11 +41,17 @@ find $OUT/ssl_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/
 head -6 $OUT/ssl_tasks_1M_kernel_stats.csv
 tools/prof_kernel.sh $OUT/sd_epl 1048576 2 "ssl_epl_kernel" > $OUT/sd_epl.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c -d $OUT/sd_epl/$c -- python tools/prof_target.py 1048576 step 12 2 > $OUT/sd_epl/$c.log 2>&1
+  rocprofv3 --pmc $c -d $OUT/sd_epl/$c -- python tools/prof_target.py 1048576 step 12 2 200 > $OUT/sd_epl/$c.log 2>&1
   python tools/rocpd_summary.py $(find $OUT/sd_epl/$c -name "*.db" | head -1) 2>&1 | grep -E "ssl_epl_kernel" | grep -v "^rsx" > $OUT/sd_epl/$c.txt
 done
 cat $OUT/sd_epl/*.txt > $OUT/static_defenders_epl_counters_1M.txt
 cut -c1-130 $OUT/static_defenders_epl_counters_1M.txt
+# SSL 11v11 scrimmage: 32 lanes per env against four lanes per env over the batch sizes; SQ counters of the four-lane kernel at 262 144 envs
+python tools/quick_scrim.py 2>&1 | grep -v amdgpu > $OUT/scrimmage_layouts.txt
+cat $OUT/scrimmage_layouts.txt
+tools/prof_kernel.sh $OUT/quad 262144 6 "ssl_quad_kernel" > $OUT/quad.log 2>&1
+cat $OUT/quad/*.txt > $OUT/scrimmage_quad_counters_262144.txt
+cut -c1-130 $OUT/scrimmage_quad_counters_262144.txt
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
 # batched hooks: no host <-> device copy inside step()
 rocprofv3 --memory-copy-trace --kernel-trace --stats --output-format csv -d $OUT/hooks -- python tools/hooks_nocopy.py > $OUT/hooks.log 2>&1
