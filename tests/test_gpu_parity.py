@@ -701,7 +701,7 @@ def test_ssl_env_per_lane_long_run_with_contacts(oracle_mod, monkeypatch, task, 
 
 @pytest.mark.parametrize("task,kind,ft,nb,ny,adim", EPL_TASKS, ids=EPL_IDS)
 def test_large_batch_switches_layout_and_agrees(monkeypatch, task, kind, ft, nb, ny, adim):
-    """At 131 072 envs the library picks the one-lane-per-env kernel by itself; forcing the 8-lane
+    """At 131 072 envs (above every layout threshold) the library picks the one-lane-per-env kernel by itself; forcing the 8-lane
     kernel on the same seeds must give the same buffers (full size, a few hundred resets)."""
     import torch
     L = _lib()
