@@ -612,12 +612,14 @@ def test_quad_layout_is_bit_identical(oracle_mod, monkeypatch, task):
     assert np.array_equal(outs["quad"], outs["lanes"], equal_nan=True)
 
 
-def test_scrimmage_large_batch_switches_to_the_quad_layout_and_agrees(monkeypatch):
+@pytest.mark.parametrize("B,n_step,n_roll", [(32768, 40, 0), (98304, 12, 18)], ids=["32768-steps", "98304-steps-and-a-multi-step-call"])
+def test_scrimmage_large_batch_switches_to_the_quad_layout_and_agrees(monkeypatch, B, n_step, n_roll):
     """from 32 768 envs the spread scrimmage task picks the four-lanes-per-env kernel by itself; forcing the 32-lane kernel on
-    the same seeds gives the same buffers (full size, resets included)"""
+    the same seeds gives the same buffers (full size, resets included).  From 98 304 envs a multi-step call
+    (rsx_task_rollout) on such a handle is issued as single-step launches of that kernel: same results as the 32-lane
+    kernel's one launch."""
     import torch
     L = _lib()
-    B = 32768
     outs = []
     for layout in (None, "lanes"):
         if layout:
@@ -628,7 +630,9 @@ def test_scrimmage_large_batch_switches_to_the_quad_layout_and_agrees(monkeypatc
         sim.task_attach(6, 2025, 0, 25)
         tens = sim.task_tensors()
         sim.task_reset()
-        sim.task_step_n(40)
+        sim.task_step_n(n_step)
+        if n_roll:
+            sim.task_rollout(n_roll)
         torch.cuda.synchronize()
         outs.append((tens["obs"].clone(), tens["reward"].clone(), sim.state_tensor().clone(), sim.read_metrics()))
         sim.close()
