@@ -6,11 +6,13 @@ import numpy as np, torch
 from rsoccer_amd import _lib as L
 B = int(os.environ.get("B", 4096))
 NS = 20
-nb = ((B + 7) // 8 + 7) // 8 * 8
+G = 64 // int(os.environ.get("LANES", 8))   # envs per wave (LANES=32 for the 11v11 task)
+nb = ((B + G - 1) // G + 7) // 8 * 8
 dbg = torch.zeros(NS * nb, dtype=torch.int64, device="cuda")
 torch.cuda.synchronize()
 L.load().rsx_dbg_set(ctypes.c_void_p(dbg.data_ptr()))
-CFG = {"vss": (0, 0, 3, 3, 1), "sd": (1, 2, 1, 6, 2), "drib": (1, 2, 1, 4, 3), "cont": (1, 2, 1, 1, 4), "pass": (1, 2, 2, 0, 5)}[os.environ.get("CFG", "vss")]
+CFG = {"vss": (0, 0, 3, 3, 1), "sd": (1, 2, 1, 6, 2), "drib": (1, 2, 1, 4, 3), "cont": (1, 2, 1, 1, 4), "pass": (1, 2, 2, 0, 5),
+       "scrim": (1, 1, 11, 11, 6), "scrimC": (1, 1, 11, 11, 7)}[os.environ.get("CFG", "vss")]
 sim = L.Sim(CFG[0], CFG[1], CFG[2], CFG[3], 25, B); sim.task_attach(CFG[4], 0, 0, 0); sim.task_reset()
 s = torch.cuda.current_stream().cuda_stream
 sim.task_step_n(500, s); torch.cuda.synchronize()
