@@ -217,7 +217,8 @@ int rsx_task_step(rsx_sim* h, const float* actions_dev, void* stream);
  * node vs back-to-back eager launches — and is not offered.) */
 int rsx_task_step_n(rsx_sim* h, int n, void* stream);
 /* n consecutive random-action steps inside ONE launch (state stays in registers between
- * steps; obs / reward / done buffers hold the values of the last step). */
+ * steps; obs / reward / done buffers hold the values of the last step).  Same results as n single steps; the
+ * library may issue it that way where that is faster (SSL 11v11 handles of >= 98 304 envs do). */
 int rsx_task_rollout(rsx_sim* h, int n, void* stream);
 
 /* Debugging aid: number of non-finite floats in the state rows and, with a task attached, in the

@@ -191,7 +191,7 @@ def test_task_random_actions_bitexact(oracle_mod, task, kind, ft, nb, ny, B, ste
 
 @pytest.mark.parametrize("task,kind,ft,nb,ny,B,steps,max_steps", TASKS)
 def test_task_fed_actions_and_modes_bitexact(oracle_mod, task, kind, ft, nb, ny, B, steps, max_steps):
-    """Host-chosen actions; step_n (hipGraph) and rollout (one launch) agree with single steps."""
+    """Host-chosen actions; step_n (n launches from C) and rollout (one launch) agree with single steps."""
     import torch
     L = _lib()
     O = oracle_mod
