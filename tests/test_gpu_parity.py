@@ -855,6 +855,41 @@ def test_other_time_steps_bitexact(oracle_mod, ts_ms):
         sim.close()
 
 
+@pytest.mark.parametrize("task", [6, 7], ids=["spread", "crowded"])
+def test_scrimmage_checkpoint_resume_across_the_quad_and_lane_layouts(monkeypatch, task):
+    """The 11v11 task: a run saved under the four-lanes-per-env kernel continues under the 32-lane kernel (and the other
+    way round) exactly as the uninterrupted run — ragged batch, TimeLimit resets, single-step and multi-step calls."""
+    import torch
+    L = _lib()
+    B, seed, base = 83, 99, 5
+
+    def snapshot(sim, tens):
+        torch.cuda.synchronize()
+        return np.concatenate([sim.get_state_full().ravel()] + [tens[k].cpu().numpy().astype(np.float64).ravel()
+                              for k in ("obs", "reward", "terminated", "truncated", "final_obs", "steps")]
+                              + [sim.read_metrics().astype(np.float64)])
+
+    def make(layout):
+        monkeypatch.setenv("RSX_LAYOUT", layout)
+        sim = L.Sim(1, 1, 11, 11, 25, B)
+        sim.task_attach(task, seed, base, 30)
+        return sim, sim.task_tensors()
+
+    for first, second in (("quad", "lanes"), ("lanes", "quad")):
+        a, ta = make(first)
+        a.task_reset()
+        a.task_step_n(41); a.task_rollout(7); a.task_step_n(2)
+        blob = a.task_checkpoint()
+        a.task_step_n(25); a.task_rollout(9); a.task_step(None)
+        want = snapshot(a, ta)
+        a.close()
+        b, tb = make(second)
+        b.task_restore(blob)
+        b.task_step_n(25); b.task_rollout(9); b.task_step(None)
+        assert np.array_equal(snapshot(b, tb), want, equal_nan=True), (first, second)
+        b.close()
+
+
 @pytest.mark.parametrize("task,kind,ft,nb,ny,adim", EPL_TASKS, ids=EPL_IDS)
 def test_checkpoint_resume_is_bit_identical_across_handles_and_layouts(monkeypatch, task, kind, ft, nb, ny, adim):
     """rsx_task_checkpoint_save / _load: a run interrupted after 70 steps continues in a NEW handle (stepped by the
