@@ -16,6 +16,10 @@
 #pragma once
 #include "rsx_kernels.hpp"
 
+#ifndef RSX_QUAD_HOT_SLOTS
+#define RSX_QUAD_HOT_SLOTS 5   // of 6 robot slots with a partner somewhere in the wave: skip the screening pass in the next sub-step (7 = never)
+#endif
+
 namespace rsx {
 
 constexpr int Q_N = 22;        // robots
@@ -151,6 +155,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 
     // ---- physics ----
     ball_step_friction(P, ball);
+    bool hot = false;      // wave-uniform: the previous sub-step found (nearly) every robot slot in contact somewhere in the wave
     unsigned irbits = 0;   // infrared flags of this lane's robots (bit m), refreshed by the first sweep of every sub-step
     for (int sub = 0; sub < P.n_sub; ++sub) {
         // A: actuation + integration
@@ -179,8 +184,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
             // per robot of mine: does it touch anything?  rmin[i] = its smallest squared distance to my other robots and to the
             // robots of the next two lanes; cmin[j] = the smallest distance of the NEXT lane's robot j to mine (that lane does
             // not test backwards: it receives the flag); one robot of the other lanes at a time (two DPP temporaries)
+            unsigned tf = 0, nf = 0;   // bit i: my robot i is closer than two radii to something / is near the ball
+            if (!hot) {
             float rmin[R];
-            unsigned nf = 0, cf = 0;   // bit j: my robot j is near the ball / the next lane's robot j is within two radii of one of mine
+            unsigned cf = 0;   // bit j: the next lane's robot j is within two radii of one of mine
 #pragma unroll
             for (int i = 0; i < R; ++i) rmin[i] = 1.0e30f;
 #pragma unroll
@@ -198,12 +205,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                 nf = (nf + nf) + (unsigned)(ball_low & (dist2(bx, by, r[j].x, r[j].y) < NEAR2));
                 __builtin_amdgcn_sched_barrier(0);
             }
-            unsigned tf = 0;   // bit i: my robot i is closer than two radii to something
 #pragma unroll
             for (int i = R - 1; i >= 0; --i) tf = (tf + tf) + (unsigned)(rmin[i] < K::rs_rr2);
             tf |= qdpp_u<Q_PREV>(cf);          // what the previous lane found about my robots
+            } else {
+                // a wave whose previous sub-step had nearly every robot slot in contact (a scrum): the screening above would
+                // flag them all again — every real robot goes to the exact partner test below instead (an empty set = no walk)
+                tf = p == 3 ? 0xFu : 0x3Fu;
+#pragma unroll
+                for (int j = R - 1; j >= 0; --j) nf = (nf + nf) + (unsigned)(ball_low & (dist2(bx, by, r[j].x, r[j].y) < NEAR2));
+            }
             if (!active) { tf = 0; nf = 0; }
-            if (!__any((tf | nf) != 0)) break;
+            if (!__any((tf | nf) != 0)) { if (sweep == 0) hot = false; break; }
 
             // ---- some env of the wave has a contact: snapshot -> LDS; then robot slot by robot slot (only the slots that
             // are flagged in some env of the wave): partner set, walk, the robot's side of its ball contact ----
@@ -245,6 +258,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                     const unsigned sh6 = 6u * (unsigned)p;
                     todo[i] = ((tf >> i) & 1u) ? (((rel << sh6) | (rel >> (24u - sh6))) & 0xFFFFFFu) : 0u;
                 }
+            }
+            if (sweep == 0) {   // how many robot slots really have a partner somewhere in the wave decides the next sub-step's mode
+                int slots = 0;
+#pragma unroll
+                for (int i = 0; i < R; ++i) slots += __any(todo[i] != 0u) ? 1 : 0;
+                hot = slots >= RSX_QUAD_HOT_SLOTS;
             }
 #pragma unroll
             for (int i = 0; i < R; ++i) {   // each robot of the lane: its robot partners in index order, then the ball
