@@ -57,7 +57,7 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define RSX_QUAD_MIN_ENVS 32768
 #endif
 #ifndef RSX_QUAD_MIN_ENVS_CROWDED
-#define RSX_QUAD_MIN_ENVS_CROWDED 262144
+#define RSX_QUAD_MIN_ENVS_CROWDED 131072
 #endif
 // from this batch on a multi-step call (rsx_task_rollout) on a four-lane handle is issued as single-step launches
 #ifndef RSX_QUAD_ROLLOUT_MIN_ENVS
