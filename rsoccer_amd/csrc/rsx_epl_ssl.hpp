@@ -21,6 +21,10 @@
 #pragma once
 #include "rsx_epl_common.hpp"
 
+#ifndef RSX_SD_STEP_WAVES
+#define RSX_SD_STEP_WAVES 4   // waves per SIMD the 1v6 single-step kernel is compiled for (128 VGPRs, 20 B of scratch outside the sub-step loop: 262 144 envs 51 -> 47 us; the multi-step kernel stays at 3: at 4 it spills inside the loop)
+#endif
+
 namespace rsx {
 
 template <int N>
@@ -42,7 +46,7 @@ template <> struct SeplTask<RSX_TASK_SSL_PASS_ENDURANCE> { static constexpr int 
 // occupancy target (waves per SIMD): the 1v6 kernel holds 7 robots in registers (3-4 measured best); the smaller
 // tasks fit 128 VGPRs (4 waves) without spilling — 6 and 8 waves spill and measured 1.4x / 2.3x slower, 3 the same
 template <int TASK, int MODE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SeplTask<TASK>::WMIN, SeplTask<TASK>::WMAX)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((TASK == RSX_TASK_SSL_STATIC_DEFENDERS && MODE == MODE_STEP) ? RSX_SD_STEP_WAVES : SeplTask<TASK>::WMIN, SeplTask<TASK>::WMAX)))
 void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
     constexpr int KIND = RSX_KIND_SSL, N = SeplTask<TASK>::N, NBLUE = SeplTask<TASK>::NBLUE, OD = SeplTask<TASK>::OD,
                   NCMD = SeplTask<TASK>::NCMD, RS = 11, NB1 = N + 1;
@@ -91,16 +95,18 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
         for (int f = 0; f < 5; ++f) rawb[f] = io.ld(S, f);
         rawb[5] = io.ld(S, P.state_dim);
         rawb[6] = io.ld(S, P.state_dim + 1);
-        steps = __float_as_int(io.ld(A, ROW_STEPS));
-        episode = __float_as_uint(io.ld(A, ROW_EPISODE));
+        if (!STEP) {   // single-step launches fetch the episode bookkeeping after the physics (nothing before needs it)
+            steps = __float_as_int(io.ld(A, ROW_STEPS));
+            episode = __float_as_uint(io.ld(A, ROW_EPISODE));
 #pragma unroll
-        for (int i = 0; i < ID; ++i) info[i] = io.ld(A, ROW_INFO + i);
-        ep_ret = io.ld(A, ROW_EP_RET);
-        if (HAS_TS) prev_pot = io.ld(A, ROW_PREV_POT);
+            for (int i = 0; i < ID; ++i) info[i] = io.ld(A, ROW_INFO + i);
+            ep_ret = io.ld(A, ROW_EP_RET);
+            if (HAS_TS) prev_pot = io.ld(A, ROW_PREV_POT);
+        }
     }
-    const bool counts_steps = blockIdx.x == 0 && lane == 0;   // metrics[0]: see task_step_kernel
+    const bool counts_steps = blockIdx.x == 0 && lane == 0;   // metrics[0]: see task_step_kernel (single-step: read-modify-write at the end)
     unsigned long long steps_before = 0;
-    if (counts_steps) steps_before = bufs.metrics[0];
+    if (!STEP && counts_steps) steps_before = bufs.metrics[0];
     const bool fed = MODE == MODE_STEP && bufs.actions != nullptr;
     float act[5] = {0, 0, 0, 0, 0};
     if (fed) {
@@ -126,16 +132,16 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
     RSX_STAMP(2);   // development builds (-DRSX_TIMING, tools/exp_timeline_epl.py): cycle stamps of wave 0's lane 0 per block
 
     for (int it = 0; it < n_steps; ++it) {
-        const bool first_step = steps == 0;
+        bool first_step = steps == 0;
         const uint32_t t = P.tick_base + (uint32_t)it;   // see task_step_kernel
-        if (first_step) {
+        if (!STEP && first_step) {
 #pragma unroll
             for (int i = 0; i < 10; ++i) info[i] = 0.0f;
             ep_ret = 0.0f;
         }
-        const float last_bx = ball.x, last_by = ball.y;        // the reference's last_frame (pre-step)
-        const float last_rx = r[0].x, last_ry = r[0].y;
-        const float obs_ts = prev_pot;   // the task scalar as this step's observation sees it
+        float last_bx = ball.x, last_by = ball.y;        // the reference's last_frame (pre-step); single-step launches
+        float last_rx = r[0].x, last_ry = r[0].y;        // read these four from the (not yet overwritten) rows after the physics
+        float obs_ts = prev_pot;   // the task scalar as this step's observation sees it
 
         // ---- action -> commands: only blue 0 is driven by the agent ----
         {
@@ -319,15 +325,40 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
         RSX_STAMP(8);
 
         // ---- wire-format values, observation, reward ----
+        if (STEP) {   // episode bookkeeping, cumulative terms and the pre-step positions: fetched now (the rows still hold the pre-step state)
+            steps = __float_as_int(io.ld(A, ROW_STEPS));
+            episode = __float_as_uint(io.ld(A, ROW_EPISODE));
+#pragma unroll
+            for (int i = 0; i < ID; ++i) info[i] = io.ld(A, ROW_INFO + i);
+            ep_ret = io.ld(A, ROW_EP_RET);
+            if (HAS_TS) { prev_pot = io.ld(A, ROW_PREV_POT); obs_ts = prev_pot; }
+            last_bx = io.ld(S, 0); last_by = io.ld(S, 1);
+            last_rx = io.ld(S, 5); last_ry = io.ld(S, 6);
+            first_step = steps == 0;
+            if (first_step) {
+#pragma unroll
+                for (int i = 0; i < 10; ++i) info[i] = 0.0f;
+                ep_ret = 0.0f;
+            }
+        }
         float ob[OD];   // this env's observation, in registers
+        float w0[4] = {0, 0, 0, 0};   // robot 0's wheel speeds (reward terms)
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             const float wd = r[k].om * K::rad2deg;
             wdeg[k] = wd;
             wheel_speeds<KIND>(P, r[k], wheels[k]);   // from the carried (c, s) and the unrounded rate, like the other layout
+            if (k == 0) { w0[0] = wheels[0][0]; w0[1] = wheels[0][1]; w0[2] = wheels[0][2]; w0[3] = wheels[0][3]; }
             r[k].om = wd * K::deg2rad;
             sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
             write_obs_nb<KIND, TASK>(P, ob, k, NBLUE, true, false, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, wd, r[k].ir, obs_ts);
+            if (STEP && live) {   // wire format, robot by robot (an env that resets below writes its rows again)
+                io.st_robot(5 + RS * k, r[k].x, r[k].y, r[k].th, r[k].vx, r[k].vy, wd);
+                io.st(S, 5 + RS * k + 6, r[k].ir ? 1.0f : 0.0f);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) io.st(S, 5 + RS * k + 7 + i, wheels[k][i]);
+            }
+            if (STEP) __builtin_amdgcn_sched_barrier(0);
         }
         RSX_STAMP(9);
         ball.z = (K::r_ball + ball.z) - K::r_ball;
@@ -338,7 +369,7 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
             xr[0] = r[0].x; xr[1] = r[0].y;
             if (TASK == RSX_TASK_SSL_STATIC_DEFENDERS || TASK == RSX_TASK_SSL_CONTESTED) {
                 xr[6] = last_rx; xr[7] = last_ry;
-                xr[8] = wheels[0][0]; xr[9] = wheels[0][1]; xr[10] = wheels[0][2]; xr[11] = wheels[0][3];
+                xr[8] = w0[0]; xr[9] = w0[1]; xr[10] = w0[2]; xr[11] = w0[3];
             }
 #pragma unroll
             for (int k = 1; k < N; ++k) {
@@ -373,12 +404,18 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
                 if (trunc && !term) atomicAdd(&ms[6], 1ull);
                 // placement: the task's reset (place_env: sequential, Philox draws), poses through this lane's
                 // column of the (now idle) contact sums
-                place_env<TASK, 1, false>(P, N, env_id, episode, lane, sh.A, nullptr);
+                // (env id and lane re-derived here: an opaque copy keeps the first Philox round of the step's draws — same counter
+                // word — and the lane index from staying alive across the physics for this rare path)
+                uint32_t eo_r = eo;
+                asm volatile("" : "+v"(eo_r));
+                const uint32_t env_id_r = P.env_id_base + (eo_r >> 2);
+                const int lane_r = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // = lane (64-thread workgroups)
+                place_env<TASK, 1, false>(P, N, env_id_r, episode, lane_r, sh.A, nullptr);
                 steps = 0;
                 if (HAS_TS) prev_pot = 0.0f;
                 float4 np[NB1];
 #pragma unroll
-                for (int k = 0; k < NB1; ++k) np[k] = sh.A[k * 64 + lane];
+                for (int k = 0; k < NB1; ++k) np[k] = sh.A[k * 64 + lane_r];
                 wave_sync();   // the scratch is the contact sums again from here on
 #pragma unroll
                 for (int k = 0; k < N; ++k) {
@@ -390,6 +427,11 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
                     for (int i = 0; i < 4; ++i) wheels[k][i] = 0.0f;
                     sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
                     write_obs_nb<KIND, TASK>(P, ob, k, NBLUE, true, false, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, 0.0f, 0, 0.0f);
+                    if (STEP) {   // (ended implies live)
+                        io.st_robot(5 + RS * k, r[k].x, r[k].y, r[k].th, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) io.st(S, 5 + RS * k + 6 + i, 0.0f);
+                    }
                 }
                 ball = Body{};
                 ball.x = np[N].x; ball.y = np[N].y;
@@ -405,6 +447,7 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
     if (live) {
 #pragma unroll
         for (int k = 0; k < N; ++k) {
+            if (STEP) break;   // stored robot by robot above
             io.st_robot(5 + RS * k, r[k].x, r[k].y, r[k].th, r[k].vx, r[k].vy, wdeg[k]);
             io.st(S, 5 + RS * k + 6, r[k].ir ? 1.0f : 0.0f);
 #pragma unroll
@@ -418,7 +461,7 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
         io.st(A, ROW_EP_RET, ep_ret);
         if (HAS_TS) io.st(A, ROW_PREV_POT, prev_pot);
     }
-    if (counts_steps) bufs.metrics[0] = steps_before + (unsigned long long)P.num_envs * (unsigned long long)n_steps;
+    if (counts_steps) bufs.metrics[0] = (STEP ? bufs.metrics[0] : steps_before) + (unsigned long long)P.num_envs * (unsigned long long)n_steps;
     RSX_STAMP(12);
 #ifdef RSX_TIMING
     __builtin_amdgcn_s_waitcnt(0x0F70);
