@@ -446,8 +446,7 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
     // ---- store (wire format: degrees, deg/s, infrared, wheel speeds) ----
     if (live) {
 #pragma unroll
-        for (int k = 0; k < N; ++k) {
-            if (STEP) break;   // stored robot by robot above
+        for (int k = 0; k < (STEP ? 0 : N); ++k) {   // (single-step launches stored them robot by robot above)
             io.st_robot(5 + RS * k, r[k].x, r[k].y, r[k].th, r[k].vx, r[k].vy, wdeg[k]);
             io.st(S, 5 + RS * k + 6, r[k].ir ? 1.0f : 0.0f);
 #pragma unroll
