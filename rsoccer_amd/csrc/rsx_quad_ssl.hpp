@@ -16,6 +16,9 @@
 #pragma once
 #include "rsx_kernels.hpp"
 
+#ifndef RSX_QUAD_WAVES
+#define RSX_QUAD_WAVES 3   // waves per SIMD the kernel is compiled for
+#endif
 #ifndef RSX_QUAD_HOT_SLOTS
 #define RSX_QUAD_HOT_SLOTS 5   // of 6 robot slots with a partner somewhere in the wave: skip the screening pass in the next sub-step (7 = never)
 #endif
@@ -48,7 +51,7 @@ constexpr int Q_PREV = 0x93;   // quad_perm:[3,0,1,2]: lane p reads lane p - 1
 constexpr int Q_L3 = 0xFF;     // quad_perm:[3,3,3,3]: the ball lane's value in all four lanes
 
 template <int MODE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void ssl_quad_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAVES, RSX_QUAD_WAVES))) void ssl_quad_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
     static_assert(MODE == MODE_STEP, "single-step launches");
     constexpr int KIND = RSX_KIND_SSL, TASK = RSX_TASK_SSL_SCRIMMAGE, N = Q_N, R = Q_R, RS = 11;
     using K = KC<KIND>;
