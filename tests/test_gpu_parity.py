@@ -855,6 +855,108 @@ def test_other_time_steps_bitexact(oracle_mod, ts_ms):
         sim.close()
 
 
+@pytest.mark.parametrize("layout", ["lanes", "quad"])
+def test_scrimmage_wall_and_goal_contacts_in_both_layouts(oracle_mod, monkeypatch, layout):
+    """The SSL kernels skip the wall clamp in waves with no body near a wall (near_walls, rsx_body.hpp).  Here the bodies
+    START at the walls: robots lined up along the touch lines, the goal lines, inside the goal mouths and behind the
+    goals, the ball in a corner / a goal / mid-field, fed commands that push them outwards — the CPU oracle's bits for
+    80 steps in the 32-lane and the four-lane kernel (ragged batch: envs without any body near a wall share waves
+    with envs full of them)."""
+    import torch
+    L = _lib()
+    O = oracle_mod
+    monkeypatch.setenv("RSX_LAYOUT", layout)
+    kind, ft, nb, ny, B = 1, 1, 11, 11, 37
+    sim = L.Sim(kind, ft, nb, ny, 25, B)
+    sim.task_attach(6, 5, 0, 0)
+    f = sim.get_field_params()
+    hl, hw, gd, ghw = f["length"] / 2, f["width"] / 2, f["goal_depth"], f["goal_width"] / 2
+    rng = np.random.default_rng(8)
+    ball = np.zeros((B, 4)); rob = np.zeros((B, 22, 3))
+    for e in range(B):
+        if e % 3 == 2:      # an env far from every wall
+            gx, gy = np.meshgrid(np.linspace(-2.5, 2.5, 6), np.linspace(-1.5, 1.5, 4))
+            rob[e, :, :2] = np.stack([gx.ravel(), gy.ravel()], 1)[:22]
+            ball[e, :2] = (0.3, 0.2)
+        else:
+            for k in range(22):
+                side = 1.0 if k % 2 else -1.0
+                if k < 8:    rob[e, k, :2] = (-4.5 + 1.2 * k, side * (hw + 0.2))                 # along the touch lines (inside the margin)
+                elif k < 14: rob[e, k, :2] = (side * (hl + 0.15), -3.0 + 1.1 * (k - 8) + 1.2)      # on the goal lines, outside the mouth
+                elif k < 18: rob[e, k, :2] = (side * (hl + 0.05 * (k - 13)), (k - 15.5) * 0.25)   # in the goal mouths
+                else:        rob[e, k, :2] = (side * (hl + gd + 0.12), (k - 19.5) * 0.8)          # behind the goals
+            ball[e] = [(hl + 0.1, ghw - 0.03, 1.0, 1.5), (hl - 0.02, hw - 0.02, 2.0, 2.0)][e % 2] if e % 3 == 0 else (-(hl + gd - 0.03), 0.1, -3.0, 0.4)
+        rob[e, :, 2] = rng.uniform(-180, 180, 22)
+        rob[e, :, :2] += rng.uniform(-0.01, 0.01, (22, 2))
+    refs = _mk_oracles(O, kind, ft, nb, ny, B)
+    for e, r in enumerate(refs):
+        r.task_attach(6, 5, e, 0)
+        r.task_reset()
+        r.task_reset_to(ball[e], rob[e, :11], rob[e, 11:])
+    sim.task_reset()
+    sim.task_reset_to(ball, rob[:, :11], rob[:, 11:])
+    tens = sim.task_tensors()
+    for t in range(80):
+        a = rng.uniform(-1, 1, tuple(tens["actions"].shape)).astype(np.float32)
+        a.reshape(B, 22, 4)[:, :, 0] = np.abs(a.reshape(B, 22, 4)[:, :, 0])      # keep driving forwards (headings are random: half of them outwards)
+        tens["actions"].copy_(torch.from_numpy(a))
+        sim.task_step(tens["actions"].data_ptr())
+        for e, r in enumerate(refs):
+            r.task_step(a[e])
+        if t % 8 == 7:
+            _cmp_task(sim, refs, tens, t)
+    st = sim.get_state_full()
+    assert np.abs(st[:, 5::11][:, :22]).max() <= hl + gd + 0.35 + 1e-4     # nobody left the playable region
+    sim.close()
+
+
+@pytest.mark.parametrize("layout", ["lanes", "epl"])
+def test_static_defenders_wall_contacts_in_both_layouts(oracle_mod, monkeypatch, layout):
+    """The same for SSLStaticDefenders-v0 (8 lanes per env / one lane per env): the agent driven into the walls and the
+    goal, defenders parked on the walls, the ball shot into corners, along walls and into the goal mouth."""
+    import torch
+    L = _lib()
+    O = oracle_mod
+    monkeypatch.setenv("RSX_LAYOUT", layout)
+    kind, ft, nb, ny, B = 1, 2, 1, 6, 70
+    sim = L.Sim(kind, ft, nb, ny, 25, B)
+    sim.task_attach(2, 9, 0, 0)
+    f = sim.get_field_params()
+    hl, hw, gd, ghw = f["length"] / 2, f["width"] / 2, f["goal_depth"], f["goal_width"] / 2
+    rng = np.random.default_rng(12)
+    ball = np.zeros((B, 4)); rob = np.zeros((B, 7, 3))
+    for e in range(B):
+        if e % 4 == 3:      # far from every wall
+            rob[e, :, :2] = [(-1.0 + 0.4 * k, -0.6 + 0.2 * k) for k in range(7)]
+            ball[e] = (0.2, 0.5, 0.5, -0.5)
+        else:
+            sx = 1.0 if e % 2 else -1.0
+            rob[e, 0, :2] = [(sx * (hl + 0.1), 0.1), (sx * (hl - 0.3), hw + 0.15), (sx * (hl + gd - 0.02), -0.2)][e % 3]
+            for k in range(1, 7):
+                rob[e, k, :2] = [(sx * (hl + 0.2), -1.6 + 0.55 * k), (-2.0 + 0.7 * k, -sx * (hw + 0.2))][k % 2]
+            ball[e] = [(sx * (hl - 0.05), hw - 0.05, sx * 2.5, 2.0), (sx * (hl + 0.05), ghw - 0.04, sx * 1.0, 1.0), (0.0, -(hw + 0.2), 1.0, -2.0)][e % 3]
+        rob[e, :, 2] = rng.uniform(-180, 180, 7)
+        rob[e, :, :2] += rng.uniform(-0.01, 0.01, (7, 2))
+    refs = _mk_oracles(O, kind, ft, nb, ny, B)
+    for e, r in enumerate(refs):
+        r.task_attach(2, 9, e, 0)
+        r.task_reset()
+        r.task_reset_to(ball[e], rob[e, :1], rob[e, 1:])
+    sim.task_reset()
+    sim.task_reset_to(ball, rob[:, :1], rob[:, 1:])
+    tens = sim.task_tensors()
+    for t in range(60):
+        a = rng.uniform(-1, 1, tuple(tens["actions"].shape)).astype(np.float32)
+        a[:, 0] = np.abs(a[:, 0])
+        tens["actions"].copy_(torch.from_numpy(a))
+        sim.task_step(tens["actions"].data_ptr())
+        for e, r in enumerate(refs):
+            r.task_step(a[e])
+        if t % 6 == 5:
+            _cmp_task(sim, refs, tens, t)
+    sim.close()
+
+
 @pytest.mark.parametrize("task", [6, 7], ids=["spread", "crowded"])
 def test_scrimmage_checkpoint_resume_across_the_quad_and_lane_layouts(monkeypatch, task):
     """The 11v11 task: a run saved under the four-lanes-per-env kernel continues under the 32-lane kernel (and the other
