@@ -22,6 +22,10 @@ static int step_per_xcd(const Params& P, const dim3& grid) {
     return (zig && (P.tick_base & 1u)) ? -per : per;
 }
 
+#ifndef RSX_SD_LEAN_MAX_ENVS
+#define RSX_SD_LEAN_MAX_ENVS 786432
+#endif
+
 static unsigned epl_lds_pad() {
     static const unsigned pad = std::getenv("RSX_EPL_LDS_PAD") ? (unsigned)std::atoi(std::getenv("RSX_EPL_LDS_PAD")) : 0u;
     return pad;
@@ -45,9 +49,21 @@ static void launch_ssl_epl_t(bool rollout, const Params& P, const Buffers& b, in
     if (rollout)
         hipLaunchKernelGGL((ssl_epl_kernel<TASK, MODE_ROLLOUT>), grid, dim3(64), 0, s, b.state, b.aux, b.actions, b.flags,
                            P.num_envs, P.state_dim, (int)(grid.x >> 3), n_steps, P, b);
-    else
-        hipLaunchKernelGGL((ssl_epl_kernel<TASK, MODE_STEP>), grid, dim3(64), 0, s, b.state, b.aux, b.actions, b.flags,
-                           P.num_envs, P.state_dim, step_per_xcd(P, grid), n_steps, P, b);
+    else {
+        // the lean single-step form (rsx_epl_ssl.hpp): 1v6 below RSX_SD_LEAN_MAX_ENVS (occupancy-bound there: 262 144 envs 52 -> 47 us;
+        // at 1 M envs, bandwidth-bound, the classic form is 4-7 % faster), contested possession always (-5 %); measured equal
+        // or worse for dribbling and pass endurance (episodes of a few steps: most waves store the robot rows twice)
+        const char* const fe = std::getenv("RSX_EPL_LEAN");   // 0 / 1: tests and A/B runs (read per launch: tests switch it inside one process)
+        const int force = fe ? std::atoi(fe) : -1;
+        const bool lean = force >= 0 ? force != 0
+                                     : TASK == RSX_TASK_SSL_CONTESTED || (TASK == RSX_TASK_SSL_STATIC_DEFENDERS && P.num_envs < RSX_SD_LEAN_MAX_ENVS);
+        if (lean && (TASK == RSX_TASK_SSL_CONTESTED || TASK == RSX_TASK_SSL_STATIC_DEFENDERS))
+            hipLaunchKernelGGL((ssl_epl_kernel<TASK, MODE_STEP, (TASK == RSX_TASK_SSL_CONTESTED || TASK == RSX_TASK_SSL_STATIC_DEFENDERS)>), grid, dim3(64), 0, s,
+                               b.state, b.aux, b.actions, b.flags, P.num_envs, P.state_dim, step_per_xcd(P, grid), n_steps, P, b);
+        else
+            hipLaunchKernelGGL((ssl_epl_kernel<TASK, MODE_STEP>), grid, dim3(64), 0, s, b.state, b.aux, b.actions, b.flags,
+                               P.num_envs, P.state_dim, step_per_xcd(P, grid), n_steps, P, b);
+    }
 }
 
 void launch_ssl_quad(const Params& P, const Buffers& b, hipStream_t s) {   // SSL 11v11 scrimmage, four lanes per env, single-step launches

@@ -22,7 +22,7 @@
 #include "rsx_epl_common.hpp"
 
 #ifndef RSX_SD_STEP_WAVES
-#define RSX_SD_STEP_WAVES 4   // waves per SIMD the 1v6 single-step kernel is compiled for (128 VGPRs, 20 B of scratch outside the sub-step loop: 262 144 envs 51 -> 47 us; the multi-step kernel stays at 3: at 4 it spills inside the loop)
+#define RSX_SD_STEP_WAVES 4   // waves per SIMD the LEAN 1v6 single-step kernel is compiled for (128 VGPRs, no scratch: 262 144 envs 51 -> 47 us)
 #endif
 
 namespace rsx {
@@ -45,8 +45,8 @@ template <> struct SeplTask<RSX_TASK_SSL_PASS_ENDURANCE> { static constexpr int 
 
 // occupancy target (waves per SIMD): the 1v6 kernel holds 7 robots in registers (3-4 measured best); the smaller
 // tasks fit 128 VGPRs (4 waves) without spilling — 6 and 8 waves spill and measured 1.4x / 2.3x slower, 3 the same
-template <int TASK, int MODE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((TASK == RSX_TASK_SSL_STATIC_DEFENDERS && MODE == MODE_STEP) ? RSX_SD_STEP_WAVES : SeplTask<TASK>::WMIN, SeplTask<TASK>::WMAX)))
+template <int TASK, int MODE, bool LEAN = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((TASK == RSX_TASK_SSL_STATIC_DEFENDERS && LEAN) ? RSX_SD_STEP_WAVES : SeplTask<TASK>::WMIN, SeplTask<TASK>::WMAX)))
 void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
     constexpr int KIND = RSX_KIND_SSL, N = SeplTask<TASK>::N, NBLUE = SeplTask<TASK>::NBLUE, OD = SeplTask<TASK>::OD,
                   NCMD = SeplTask<TASK>::NCMD, RS = 11, NB1 = N + 1;
@@ -55,6 +55,11 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
     using T = TC<TASK>;
     constexpr int ID = T::info_dim, AD = T::act_dim;
     constexpr bool STEP = MODE == MODE_STEP;
+    static_assert(STEP || !LEAN, "the lean form is a single-step form");
+    // LEAN (chosen by the launcher per task and batch): episode bookkeeping and the pre-step positions are fetched AFTER the
+    // physics, robot rows are stored robot by robot while the observation is assembled — 151 -> 128 VGPRs for 1v6 (4 waves per
+    // SIMD), at the price of a second set of row stores in the lanes that reset and of loads nothing can hide behind
+    constexpr bool LATE = LEAN;
     Params P = P_; P.num_envs = hp_num_envs; P.state_dim = hp_state_dim;
     Buffers bufs = bufs_; bufs.state = hp_state; bufs.aux = hp_aux; bufs.actions = hp_in; bufs.flags = hp_flags;
     const int n_steps = MODE == MODE_ROLLOUT ? hp_n_steps : 1;
@@ -62,11 +67,14 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
     const int lane = threadIdx.x;
     const int tile = tile_of_block_zigzag(hp_per_xcd);
     const int e_raw = tile * 64 + lane;
-    const bool live = e_raw < P.num_envs;
+    int live_i = e_raw < P.num_envs ? 1 : 0;
+    asm volatile("" : "+v"(live_i));   // decided here: one flag through the step, not the index it is made of
+    const bool live = live_i != 0;
     const int e = live ? e_raw : P.num_envs - 1;   // lanes beyond the batch shadow its last env (loads valid and unconditional; stores, counters masked)
     const size_t B = (size_t)P.num_envs;
     const uint32_t env_id = P.env_id_base + (uint32_t)e;
-    const EplIO io(bufs.state, bufs.aux, P.num_envs, e);   // this lane's column of the [rows][B] arrays (rsx_epl_common.hpp)
+    EplIO io(bufs.state, bufs.aux, P.num_envs, e);   // this lane's column of the [rows][B] arrays (rsx_epl_common.hpp)
+    asm volatile("" : "+v"(io.eo));   // THE per-lane offset of the step: everything later derives from it, not from the env index
     const uint32_t eo = io.eo;
     const __amdgpu_buffer_rsrc_t S = io.S, A = io.A;
 
@@ -95,7 +103,7 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
         for (int f = 0; f < 5; ++f) rawb[f] = io.ld(S, f);
         rawb[5] = io.ld(S, P.state_dim);
         rawb[6] = io.ld(S, P.state_dim + 1);
-        if (!STEP) {   // single-step launches fetch the episode bookkeeping after the physics (nothing before needs it)
+        if (!LATE) {   // the lean form fetches the episode bookkeeping after the physics (nothing before needs it)
             steps = __float_as_int(io.ld(A, ROW_STEPS));
             episode = __float_as_uint(io.ld(A, ROW_EPISODE));
 #pragma unroll
@@ -104,9 +112,9 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
             if (HAS_TS) prev_pot = io.ld(A, ROW_PREV_POT);
         }
     }
-    const bool counts_steps = blockIdx.x == 0 && lane == 0;   // metrics[0]: see task_step_kernel (single-step: read-modify-write at the end)
+    const bool counts_steps = blockIdx.x == 0 && lane == 0;   // metrics[0]: see task_step_kernel (single-step: read-modify-write at the end, lane re-derived there)
     unsigned long long steps_before = 0;
-    if (!STEP && counts_steps) steps_before = bufs.metrics[0];
+    if (!LATE && counts_steps) steps_before = bufs.metrics[0];
     const bool fed = MODE == MODE_STEP && bufs.actions != nullptr;
     float act[5] = {0, 0, 0, 0, 0};
     if (fed) {
@@ -134,7 +142,7 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
     for (int it = 0; it < n_steps; ++it) {
         bool first_step = steps == 0;
         const uint32_t t = P.tick_base + (uint32_t)it;   // see task_step_kernel
-        if (!STEP && first_step) {
+        if (!LATE && first_step) {
 #pragma unroll
             for (int i = 0; i < 10; ++i) info[i] = 0.0f;
             ep_ret = 0.0f;
@@ -213,11 +221,12 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
                 if (sub == 0 && sweep == 0) RSX_STAMP(5);
                 if (!__any((touching | near) != 0)) break;
                 const bool first = sweep == 0;
-                epl_zero_sums(sh.c, lane);
+                const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // = lane, re-derived: the index is not held across the sub-steps for this path
+                epl_zero_sums(sh.c, ln);
                 wave_sync();
                 deep = false;
                 // robot-robot pairs, in pair order: every body receives its partners in index order (rsx_epl_common.hpp)
-                epl_walk_pairs<KIND, N, false>(r, ball, sh.c, lane, touching, deep);
+                epl_walk_pairs<KIND, N, false>(r, ball, sh.c, ln, touching, deep);
                 // robot-ball, robot by robot (the ball sums the robots' records in robot order): kicker mouth
                 // (flat face at dck) or body circle; n points robot -> ball.  Mirrors ssl_sweep.
                 unsigned rb_touch = 0;   // robots that touch the ball in this sweep
@@ -251,9 +260,9 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
                     if (touch) {
                         rb_touch |= 1u << k;
                         deep |= pen > K::pen2;
-                        float a0 = sh.c.acc[0][k][lane], a1 = sh.c.acc[1][k][lane], a2 = sh.c.acc[2][k][lane], a3 = sh.c.acc[3][k][lane];
-                        float b0 = sh.c.acc[0][N][lane], b1 = sh.c.acc[1][N][lane], b2 = sh.c.acc[2][N][lane], b3 = sh.c.acc[3][N][lane];
-                        float bw = sh.c.accw[lane];
+                        float a0 = sh.c.acc[0][k][ln], a1 = sh.c.acc[1][k][ln], a2 = sh.c.acc[2][k][ln], a3 = sh.c.acc[3][k][ln];
+                        float b0 = sh.c.acc[0][N][ln], b1 = sh.c.acc[1][N][ln], b2 = sh.c.acc[2][N][ln], b3 = sh.c.acc[3][N][ln];
+                        float bw = sh.c.accw[ln];
                         const float dvx = ball.vx - o.vx, dvy = ball.vy - o.vy;
                         float vn = fma_(dvx, nx, dvy * ny);
                         if (vn < 0.0f) {
@@ -273,9 +282,9 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
                         a2 = fma_(-pc, nx, a2); a3 = fma_(-pc, ny, a3);
                         float pb = K::beta * pen * K::w_rb_b;
                         b2 = b2 + pb * nx; b3 = b3 + pb * ny;
-                        sh.c.acc[0][k][lane] = a0; sh.c.acc[1][k][lane] = a1; sh.c.acc[2][k][lane] = a2; sh.c.acc[3][k][lane] = a3;
-                        sh.c.acc[0][N][lane] = b0; sh.c.acc[1][N][lane] = b1; sh.c.acc[2][N][lane] = b2; sh.c.acc[3][N][lane] = b3;
-                        sh.c.accw[lane] = bw;
+                        sh.c.acc[0][k][ln] = a0; sh.c.acc[1][k][ln] = a1; sh.c.acc[2][k][ln] = a2; sh.c.acc[3][k][ln] = a3;
+                        sh.c.acc[0][N][ln] = b0; sh.c.acc[1][N][ln] = b1; sh.c.acc[2][N][ln] = b2; sh.c.acc[3][N][ln] = b3;
+                        sh.c.accw[ln] = bw;
                     }
                     if (first) {
                         const bool ir = mouth && pen > -K::ir_tol;
@@ -299,7 +308,7 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
                     }
                 }
                 wave_sync();
-                epl_apply_sums<N>(r, ball, sh.c, lane, [&](int k) {   // only a body that touched something is updated
+                epl_apply_sums<N>(r, ball, sh.c, ln, [&](int k) {   // only a body that touched something is updated
                     return k == N ? rb_touch != 0 : ((touching & epl_pair_mask<N>(k)) | (rb_touch & (1u << k))) != 0;
                 });
                 wave_sync();
@@ -325,7 +334,7 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
         RSX_STAMP(8);
 
         // ---- wire-format values, observation, reward ----
-        if (STEP) {   // episode bookkeeping, cumulative terms and the pre-step positions: fetched now (the rows still hold the pre-step state)
+        if (LATE) {   // episode bookkeeping, cumulative terms and the pre-step positions: fetched now (the rows still hold the pre-step state)
             steps = __float_as_int(io.ld(A, ROW_STEPS));
             episode = __float_as_uint(io.ld(A, ROW_EPISODE));
 #pragma unroll
@@ -352,13 +361,13 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
             r[k].om = wd * K::deg2rad;
             sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
             write_obs_nb<KIND, TASK>(P, ob, k, NBLUE, true, false, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, wd, r[k].ir, obs_ts);
-            if (STEP && live) {   // wire format, robot by robot (an env that resets below writes its rows again)
+            if (LATE && live) {   // wire format, robot by robot (an env that resets below writes its rows again)
                 io.st_robot(5 + RS * k, r[k].x, r[k].y, r[k].th, r[k].vx, r[k].vy, wd);
                 io.st(S, 5 + RS * k + 6, r[k].ir ? 1.0f : 0.0f);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) io.st(S, 5 + RS * k + 7 + i, wheels[k][i]);
             }
-            if (STEP) __builtin_amdgcn_sched_barrier(0);
+            if (LATE) __builtin_amdgcn_sched_barrier(0);
         }
         RSX_STAMP(9);
         ball.z = (K::r_ball + ball.z) - K::r_ball;
@@ -427,7 +436,7 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
                     for (int i = 0; i < 4; ++i) wheels[k][i] = 0.0f;
                     sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
                     write_obs_nb<KIND, TASK>(P, ob, k, NBLUE, true, false, r[k].x, r[k].y, r[k].vx, r[k].vy, r[k].s, r[k].c, 0.0f, 0, 0.0f);
-                    if (STEP) {   // (ended implies live)
+                    if (LATE) {   // (ended implies live)
                         io.st_robot(5 + RS * k, r[k].x, r[k].y, r[k].th, 0.0f, 0.0f, 0.0f);
 #pragma unroll
                         for (int i = 0; i < 5; ++i) io.st(S, 5 + RS * k + 6 + i, 0.0f);
@@ -446,7 +455,7 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
     // ---- store (wire format: degrees, deg/s, infrared, wheel speeds) ----
     if (live) {
 #pragma unroll
-        for (int k = 0; k < (STEP ? 0 : N); ++k) {   // (single-step launches stored them robot by robot above)
+        for (int k = 0; k < (LATE ? 0 : N); ++k) {   // (the lean form stored them robot by robot above)
             io.st_robot(5 + RS * k, r[k].x, r[k].y, r[k].th, r[k].vx, r[k].vy, wdeg[k]);
             io.st(S, 5 + RS * k + 6, r[k].ir ? 1.0f : 0.0f);
 #pragma unroll
@@ -460,7 +469,10 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
         io.st(A, ROW_EP_RET, ep_ret);
         if (HAS_TS) io.st(A, ROW_PREV_POT, prev_pot);
     }
-    if (counts_steps) bufs.metrics[0] = (STEP ? bufs.metrics[0] : steps_before) + (unsigned long long)P.num_envs * (unsigned long long)n_steps;
+    if (LATE) {
+        if (blockIdx.x == 0 && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u)
+            bufs.metrics[0] = bufs.metrics[0] + (unsigned long long)P.num_envs;
+    } else if (counts_steps) bufs.metrics[0] = steps_before + (unsigned long long)P.num_envs * (unsigned long long)n_steps;
     RSX_STAMP(12);
 #ifdef RSX_TIMING
     __builtin_amdgcn_s_waitcnt(0x0F70);

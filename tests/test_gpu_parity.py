@@ -506,8 +506,9 @@ EPL_TASKS = [(1, 0, 0, 3, 3, 2), (2, 1, 2, 1, 6, 5), (3, 1, 2, 1, 4, 4), (4, 1, 
 EPL_IDS = ["vss-v0", "static-defenders", "dribbling", "contested", "pass-endurance"]
 
 
+@pytest.mark.parametrize("lean", [None, "0"], ids=["default-form", "classic-form"])
 @pytest.mark.parametrize("task,kind,ft,nb,ny,adim", EPL_TASKS, ids=EPL_IDS)
-def test_env_per_lane_layout_is_bit_identical(oracle_mod, monkeypatch, task, kind, ft, nb, ny, adim):
+def test_env_per_lane_layout_is_bit_identical(oracle_mod, monkeypatch, task, kind, ft, nb, ny, adim, lean):
     """Large batches of the five registered tasks are stepped by second kernels (one lane per env,
     rsx_epl.hpp / rsx_epl_ssl.hpp).  Forced on a small ragged batch here: they must agree bit for bit
     with the CPU oracle and with the 8-lanes-per-env kernel — fed and random actions (kicks, dribbler),
@@ -519,6 +520,8 @@ def test_env_per_lane_layout_is_bit_identical(oracle_mod, monkeypatch, task, kin
     rng = np.random.default_rng(5)
     outs = {}
     refs = None
+    if lean is not None:   # the SSL single-step kernels have two forms of their epilogue (rsx_epl.hip picks by task and batch)
+        monkeypatch.setenv("RSX_EPL_LEAN", lean)
     for layout in ("epl", "lanes"):
         monkeypatch.setenv("RSX_LAYOUT", layout)
         sim = L.Sim(kind, ft, nb, ny, 25, B)
