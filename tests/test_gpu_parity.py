@@ -644,17 +644,22 @@ def test_scrimmage_large_batch_switches_to_the_quad_layout_and_agrees(monkeypatc
     assert np.array_equal(outs[0][3], outs[1][3]) and outs[0][3][1] >= B
 
 
-@pytest.mark.parametrize("task,kind,ft,nb,ny,B,steps", [(1, 0, 0, 3, 3, 512, 3000), (2, 1, 2, 1, 6, 384, 2000),
-                                                       (5, 1, 2, 2, 0, 256, 1500)])
-def test_long_horizon_bitexact(oracle_mod, task, kind, ft, nb, ny, B, steps):
+@pytest.mark.parametrize("task,kind,ft,nb,ny,B,steps,layout", [(1, 0, 0, 3, 3, 512, 3000, None), (2, 1, 2, 1, 6, 384, 2000, None),
+                                                              (5, 1, 2, 2, 0, 256, 1500, None), (1, 0, 0, 3, 3, 448, 2500, "epl"),
+                                                              (6, 1, 1, 11, 11, 72, 1500, "quad"), (7, 1, 1, 11, 11, 40, 1500, "quad")],
+                         ids=["vss", "static-defenders", "pass-endurance", "vss-one-lane", "scrimmage-four-lanes", "scrimmage-crowded-four-lanes"])
+def test_long_horizon_bitexact(oracle_mod, monkeypatch, task, kind, ft, nb, ny, B, steps, layout):
     """Millions of env-steps against the oracle (OpenMP over envs): thousands of contacts, kicks,
     resets and TimeLimit truncations; the state is compared every 500 steps — any divergence in a
-    chaotic system persists, so agreement at the checkpoints means agreement throughout."""
+    chaotic system persists, so agreement at the checkpoints means agreement throughout.  The large-batch kernels
+    (one lane per env, four lanes per env) are forced on small batches for their cases."""
     import torch
     L = _lib()
     O = oracle_mod
     O.set_threads(min(16, os.cpu_count() or 1))
     seed = 20260928
+    if layout:
+        monkeypatch.setenv("RSX_LAYOUT", layout)
     sim = L.Sim(kind, ft, nb, ny, 25, B)
     sim.task_attach(task, seed, 0, 0)
     tens = sim.task_tensors()
