@@ -155,6 +155,12 @@ int rsx_step(rsx_sim* h, const double* cmds, void* stream);
 /* get_state() — rsim.py:105,158; out [B][state_dim] host f64 */
 int rsx_get_state(rsx_sim* h, double* out, void* stream);
 
+/* step(cmds) followed by get_state() — rsim.py:102,105 / :155,158 are always called as a pair (RSim*.send_commands,
+ * RSim*.get_frame): one FFI crossing instead of two.  Handles of at most 64 envs (the robosim-shaped single-env
+ * objects) run rsx_step / rsx_step_state without any copy: the kernel reads the commands from, and mirrors the new
+ * state into, pinned host memory — one launch and one synchronisation per step. */
+int rsx_step_state(rsx_sim* h, const double* cmds, double* state_out, void* stream);
+
 /* full-state restore (checkpoint/resume, also used by parity tests): state
  * [B][state_dim + RSX_STATE_EXTRA_ROWS] host f64 = get_state() layout + ball vertical velocity
  * + ball spin. rsx_get_state_full is its inverse. */
@@ -192,10 +198,19 @@ int rsx_step_dev_random(rsx_sim* h, int n, uint64_t seed, uint32_t first_tick, v
  * max_episode_steps <= 0 selects the registry value (1200 / 1000 / 4800 / 1200 / 1200; scrimmage 1200). */
 /* Random streams: placement draws are keyed by (seed, global env id, episode, index); the per-step draws
  * (random actions, OU noise) by (seed, global env id, number of fused steps the handle has taken since
- * attach) — a run is reproducible from its seed and its sequence of calls. */
+ * attach) — a run is reproducible from its seed and its sequence of calls.
+ * Limits (both are 32-bit words of the Philox counter, and both are checked, never wrapped):
+ *   - env_id_base + num_envs <= 2^32, else RSX_ERR_ARG;
+ *   - a handle takes at most 2^32 - 1 fused steps (rsx_task_step / _step_n / _rollout; about 11 h at 10^5 calls/s);
+ *     the call that would exceed it returns RSX_ERR_STATE and changes nothing.  The counter is part of the checkpoint. */
 int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base,
                     int max_episode_steps);
 int rsx_task_view_get(rsx_sim* h, rsx_task_view* out);
+/* Which tile layout steps this handle's envs (chosen at attach from task and batch size; results are identical in all):
+ * "8-lanes-per-env" / "16-..." / "32-..." / "64-...", "32-lanes-per-env-large-batch", "one-lane-per-env",
+ * "four-lanes-per-env".  NUL-terminated into out[n] — for profiles and benchmark lines, so that nothing outside the
+ * library restates its thresholds. */
+int rsx_task_layout(rsx_sim* h, char* out, size_t n);
 
 /* reset(): new random placement for every env (vss_gym.py:194-233, static_defenders.py:214-254),
  * episode counters cleared, obs written. */

@@ -6,11 +6,39 @@ Same five-method surface as the reference adapters (rsoccer_gym/Simulators/rsim.
 :mod:`rsoccer_amd.robosim` (HIP) unless another module with the robosim surface is injected
 through ``backend`` (the tests inject a CPU stand-in; the product never does).
 """
+from collections.abc import Sequence
 from typing import List
 
 import numpy as np
 
 from rsoccer_amd.Entities import Field, Frame, FrameSSL, FrameVSS, Robot
+
+
+class CommandRows(Sequence):
+    """The commands of one step as the ``[n_robots, C]`` float64 array ``robosim.step()`` takes — what a task that
+    computes its commands in array form hands to ``send_commands`` instead of a ``List[Robot]`` (no per-robot record,
+    no re-packing).  Read as a sequence it IS that list: the ``Robot`` records are built on first use by ``to_robot``
+    (``row index, row -> Robot``), so ``sent_commands[0].v_wheel0`` keeps working for code written against the
+    reference."""
+
+    def __init__(self, rows, to_robot):
+        self.rows = rows
+        self._to_robot = to_robot
+        self._robots = None
+
+    def _list(self):
+        if self._robots is None:
+            self._robots = [self._to_robot(k, row) for k, row in enumerate(self.rows)]
+        return self._robots
+
+    def __len__(self):
+        return len(self.rows)
+
+    def __getitem__(self, i):
+        return self._list()[i]
+
+    def __iter__(self):
+        return iter(self._list())
 
 
 class RSim:
@@ -43,6 +71,9 @@ class RSim:
         del sim
 
     def send_commands(self, commands: List[Robot]):
+        if type(commands) is CommandRows:      # already in wire format
+            self.simulator.step(commands.rows)
+            return
         rows = np.zeros((self.n_robots_blue + self.n_robots_yellow, self._n_cmd), dtype=np.float64)
         for cmd in commands:
             self._fill_row(rows[self.n_robots_blue + cmd.id if cmd.yellow else cmd.id], cmd)

@@ -23,3 +23,35 @@ class OrnsteinUhlenbeckAction:
 
     def __repr__(self):
         return f"OrnsteinUhlenbeckActionNoise(mu={self.mu}, sigma={self.sigma})"
+
+
+class OrnsteinUhlenbeckBank:
+    """Several :class:`OrnsteinUhlenbeckAction` processes of the same shape advanced by ONE draw and three array
+    operations per step.  Same numbers as sampling them one after the other: numpy's global generator hands out its
+    normals sequentially, so ``normal(size=(k, n))`` is the concatenation of k draws of size n, and every element sees
+    the same float64 operations in the same order (``x + theta (mu - x) dt + sigma sqrt(dt) N``).  The processes stay
+    the owners of their state (``x_prev``): it is read before and written after every bank step, so sampling one of
+    them by hand in between, or resetting it, is honoured."""
+
+    def __init__(self, processes):
+        self.processes = list(processes)
+        p = self.processes[0]
+        if any(q.theta != p.theta or q.dt != p.dt or q.mu.shape != p.mu.shape for q in self.processes):
+            raise ValueError("the bank needs processes of one shape, theta and dt")
+        self.theta, self.dt = p.theta, p.dt
+        self.mu = np.stack([np.asarray(q.mu, dtype=np.float64) for q in self.processes])
+        self.shock = np.stack([q.sigma * np.sqrt(q.dt) for q in self.processes])   # float64, as in sample()
+        self._x = np.zeros(self.mu.shape, dtype=np.float64)
+        self._rows = [None] * len(self.processes)
+
+    def sample(self):
+        """advance every process; returns the [k, n] array of their new values (row i is also processes[i].x_prev)"""
+        x, rows = self._x, self._rows
+        for i, q in enumerate(self.processes):
+            if q.x_prev is not rows[i]:          # reset, or sampled by hand, since the last bank step
+                x[i] = q.x_prev
+        new = x + self.theta * (self.mu - x) * self.dt + self.shock * np.random.normal(size=self.mu.shape)
+        self._x = new
+        for i, q in enumerate(self.processes):
+            rows[i] = q.x_prev = new[i]
+        return new

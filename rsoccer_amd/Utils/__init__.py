@@ -1,4 +1,4 @@
-from .Utils import OrnsteinUhlenbeckAction
+from .Utils import OrnsteinUhlenbeckAction, OrnsteinUhlenbeckBank
 from .kdtree import KDTree
 
-__all__ = ["OrnsteinUhlenbeckAction", "KDTree"]
+__all__ = ["OrnsteinUhlenbeckAction", "OrnsteinUhlenbeckBank", "KDTree"]

@@ -30,10 +30,10 @@ METRIC_NAMES = ("env_steps", "episodes", "goals_for", "goals_against", "return_s
 # every symbol include/rsx.h declares (tests check the library exports each one)
 SYMBOLS = (
     "rsx_abi_version", "rsx_last_error", "rsx_device_count", "rsx_create", "rsx_destroy",
-    "rsx_get_field_params", "rsx_reset", "rsx_step", "rsx_get_state", "rsx_set_state",
+    "rsx_get_field_params", "rsx_reset", "rsx_step", "rsx_get_state", "rsx_step_state", "rsx_set_state",
     "rsx_get_state_full", "rsx_dev_view_get", "rsx_step_dev", "rsx_step_dev_random", "rsx_step_dev_flip", "rsx_state_buffers",
     "rsx_reset_dev", "rsx_task_attach",
-    "rsx_task_view_get", "rsx_task_reset", "rsx_task_reset_to", "rsx_task_step",
+    "rsx_task_view_get", "rsx_task_layout", "rsx_task_reset", "rsx_task_reset_to", "rsx_task_step",
     "rsx_task_step_n", "rsx_task_rollout", "rsx_read_metrics", "rsx_metrics_fold", "rsx_check_finite",
     "rsx_task_checkpoint_size", "rsx_task_checkpoint_save", "rsx_task_checkpoint_load",
 )
@@ -83,6 +83,8 @@ def load():
     lib.rsx_reset.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.rsx_step.argtypes = [vp, vp, vp]
     lib.rsx_get_state.argtypes = [vp, vp, vp]
+    lib.rsx_step_state.argtypes = [vp, vp, vp, vp]
+    lib.rsx_task_layout.argtypes = [vp, C.c_char_p, C.c_size_t]
     lib.rsx_set_state.argtypes = [vp, vp, vp]
     lib.rsx_get_state_full.argtypes = [vp, vp, vp]
     lib.rsx_dev_view_get.argtypes = [vp, C.POINTER(DevView)]
@@ -206,6 +208,16 @@ class Sim:
         cmds = _f64(cmds, (self.num_envs, self.n_robots, self.cmd_dim))
         _chk(self._lib.rsx_step(self._h, _ptr(cmds), self._stream(stream)))
 
+    def step_state(self, cmds):
+        """step(cmds) + get_state() in one crossing (rsx_step_state, null stream): returns the [B, state_dim] float64
+        state.  ``cmds`` must be a C-contiguous float64 array of B * n_robots * cmd_dim values — the lean path of the
+        robosim-shaped single-env objects (no conversions, no per-call stream object)."""
+        out = np.empty((self.num_envs, self.state_dim), dtype=np.float64)
+        rc = self._lib.rsx_step_state(self._h, cmds.ctypes.data, out.ctypes.data, None)
+        if rc:
+            _chk(rc)
+        return out
+
     def get_state(self, stream=None):
         out = np.empty((self.num_envs, self.state_dim), dtype=np.float64)
         _chk(self._lib.rsx_get_state(self._h, _ptr(out), self._stream(stream)))
@@ -286,6 +298,12 @@ class Sim:
         self.task = task
         self.obs_dim, self.act_dim, self.info_dim = t.obs_dim, t.act_dim, t.info_dim
         self.max_episode_steps = t.max_episode_steps
+
+    def task_layout(self):
+        """which tile layout steps this handle (rsx_task_layout): '8-lanes-per-env', 'one-lane-per-env', ..."""
+        buf = C.create_string_buffer(64)
+        _chk(self._lib.rsx_task_layout(self._h, buf, 64))
+        return buf.value.decode()
 
     def task_tensors(self):
         t, B = self._tview, self.num_envs

@@ -66,6 +66,11 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #ifndef RSX_EPL_MIN_ENVS_SSL
 #define RSX_EPL_MIN_ENVS_SSL 65536
 #endif
+// largest batch whose host-format step (rsx_step / rsx_step_state) lets the kernel read the commands from, and mirror the
+// state into, pinned host memory (one launch + one synchronisation; PCIe latency instead of two copy engines' worth of it)
+#ifndef RSX_ZERO_COPY_MAX_ENVS
+#define RSX_ZERO_COPY_MAX_ENVS 64
+#endif
 
 struct rsx_sim {
     Params P;
@@ -95,6 +100,8 @@ struct rsx_sim {
     // handing out raw device pointers (rsx_dev_view_get) switches the shortcut off for good.
     float* pin_cmds = nullptr;
     float* pin_state = nullptr;
+    float* pin_cmds_dev = nullptr;            // the same two buffers as the device sees them (zero-copy path of small batches)
+    float* pin_state_dev = nullptr;
     bool host_state_valid = false;
     bool host_state_cache = true;
     bool task_ready = false;   // a reset has opened the first episode
@@ -171,9 +178,12 @@ void pick_variant(rsx_sim* h) {
                                                        (P).num_envs, (P).state_dim, (int)(grid.x >> 3), (n), (P), (b))
 
 template <int KIND>
-void launch_sim_k(const rsx_sim* h, const Params& P_, float* state_out, int rand_tick, hipStream_t s) {
+void launch_sim_k(const rsx_sim* h, const Params& P_, float* state_out, int rand_tick, hipStream_t s,
+                  const float* cmds_src, float* mirror) {
     const dim3 grid = grid_for(h);
-    const Buffers b = buffers_of(h, nullptr);
+    Buffers b = buffers_of(h, nullptr);
+    if (cmds_src) b.cmds = cmds_src;                      // commands straight from pinned host memory (small batches)
+    b.flags = reinterpret_cast<uint8_t*>(mirror);         // the raw step's fourth pointer slot: second copy of the new state, or null
     if (KIND == RSX_KIND_VSS && h->NR == 6 && h->L == 8) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 8, (KIND == RSX_KIND_VSS ? 6 : 0)>), P_, b); return; }
     if (KIND == RSX_KIND_VSS && h->NR == 10) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 16, (KIND == RSX_KIND_VSS ? 10 : 0)>), P_, b); return; }
     if (KIND == RSX_KIND_SSL && h->NR == 7 && h->L == 8) { RSX_LAUNCH_SIM((sim_step_kernel<KIND, 8, (KIND == RSX_KIND_SSL ? 7 : 0)>), P_, b); return; }
@@ -189,12 +199,13 @@ void launch_sim_k(const rsx_sim* h, const Params& P_, float* state_out, int rand
 
 // state_out: where the new state is written (nullptr = in place)
 // rand_tick >= 0: commands drawn in the kernel with Philox key `seed` (rsx_step_dev_random)
-void launch_sim(const rsx_sim* h, hipStream_t s, float* state_out = nullptr, int rand_tick = -1, uint64_t seed = 0) {
+void launch_sim(const rsx_sim* h, hipStream_t s, float* state_out = nullptr, int rand_tick = -1, uint64_t seed = 0,
+                const float* cmds_src = nullptr, float* mirror = nullptr) {
     if (!state_out) state_out = h->d_state;
     Params P = h->P;
     if (rand_tick >= 0) { P.key0 = (uint32_t)seed; P.key1 = (uint32_t)(seed >> 32); P.env_id_base = 0; }
-    if (h->P.kind == RSX_KIND_VSS) launch_sim_k<RSX_KIND_VSS>(h, P, state_out, rand_tick, s);
-    else launch_sim_k<RSX_KIND_SSL>(h, P, state_out, rand_tick, s);
+    if (h->P.kind == RSX_KIND_VSS) launch_sim_k<RSX_KIND_VSS>(h, P, state_out, rand_tick, s, cmds_src, mirror);
+    else launch_sim_k<RSX_KIND_SSL>(h, P, state_out, rand_tick, s, cmds_src, mirror);
 }
 
 // teleport of rsim.py:52-75 from device arrays: one thread per env, rows are coalesced across threads
@@ -452,6 +463,16 @@ int rsx_create(rsx_sim** out, int kind, int field_type, int n_blue, int n_yellow
     if ((e = hipMemset(h->d_cmds, 0, cbytes)) != hipSuccess) return bail(e, "hipMemset(cmds)");
     if ((e = hipHostMalloc((void**)&h->pin_cmds, cbytes ? cbytes : 4, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc(cmds)");
     if ((e = hipHostMalloc((void**)&h->pin_state, sbytes, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc(state)");
+    if (num_envs <= RSX_ZERO_COPY_MAX_ENVS && !std::getenv("RSX_NO_ZERO_COPY")) {
+        // small batches (the robosim-shaped single-env objects): the raw step reads its commands from, and mirrors the
+        // new state into, the pinned host buffers directly — if the device can address them
+        void *dc = nullptr, *ds = nullptr;
+        if (hipHostGetDevicePointer(&dc, h->pin_cmds, 0) == hipSuccess && hipHostGetDevicePointer(&ds, h->pin_state, 0) == hipSuccess) {
+            h->pin_cmds_dev = (float*)dc; h->pin_state_dev = (float*)ds;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     // the adapter's dummy line-up, rsim.py:20-24
     std::vector<float> soa((size_t)(h->P.state_dim + X_ROWS) * B, 0.0f);
     for (size_t i = 0; i < B; ++i) {
@@ -505,11 +526,16 @@ int rsx_step(rsx_sim* h, const double* cmds, void* stream) {
     for (size_t e = 0; e < B; ++e)
         for (size_t j = 0; j < NC; ++j) h->pin_cmds[j * B + e] = (float)cmds[e * NC + j];
     h->host_state_valid = false;
-    HIP_TRY(hipMemcpyAsync(h->d_cmds, h->pin_cmds, NC * B * sizeof(float), hipMemcpyHostToDevice, s));
-    launch_sim(h, s);
-    HIP_TRY(hipGetLastError());
-    if (h->host_state_cache)
-        HIP_TRY(hipMemcpyAsync(h->pin_state, h->d_state, (size_t)(P.state_dim + X_ROWS) * B * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (h->pin_cmds_dev) {   // small batch: no copies, the kernel talks to the pinned buffers
+        launch_sim(h, s, nullptr, -1, 0, h->pin_cmds_dev, h->host_state_cache ? h->pin_state_dev : nullptr);
+        HIP_TRY(hipGetLastError());
+    } else {
+        HIP_TRY(hipMemcpyAsync(h->d_cmds, h->pin_cmds, NC * B * sizeof(float), hipMemcpyHostToDevice, s));
+        launch_sim(h, s);
+        HIP_TRY(hipGetLastError());
+        if (h->host_state_cache)
+            HIP_TRY(hipMemcpyAsync(h->pin_state, h->d_state, (size_t)(P.state_dim + X_ROWS) * B * sizeof(float), hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(hipStreamSynchronize(s));
     h->host_state_valid = h->host_state_cache;
     return RSX_OK;
@@ -532,6 +558,12 @@ int rsx_get_state(rsx_sim* h, double* out, void* stream) {
     RSX_ENTER(h);
     if (!out) return fail(RSX_ERR_ARG, "out is null");
     return get_state_impl(h, out, h->P.state_dim, (hipStream_t)stream);
+}
+
+int rsx_step_state(rsx_sim* h, const double* cmds, double* state_out, void* stream) {
+    if (!state_out) return fail(RSX_ERR_ARG, "state_out is null");
+    if (int rc = rsx_step(h, cmds, stream)) return rc;
+    return rsx_get_state(h, state_out, stream);
 }
 
 int rsx_get_state_full(rsx_sim* h, double* out, void* stream) {
@@ -621,6 +653,9 @@ int rsx_reset_dev(rsx_sim* h, const float* ball_dev, const float* blue_dev, cons
 int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, int max_episode_steps) {
     RSX_ENTER(h);
     if (h->P.task != RSX_TASK_NONE) return fail(RSX_ERR_STATE, "a task is already attached");
+    // global env ids are 32-bit words of the Philox counter: the whole range of this handle has to fit
+    if (env_id_base > 0xFFFFFFFFull || env_id_base + (uint64_t)h->P.num_envs > 0x100000000ull)
+        return fail(RSX_ERR_ARG, "env_id_base + num_envs exceeds 2^32 (global env ids are 32-bit)");
     Params P = h->P;
     if (derive_task(task, seed, env_id_base, max_episode_steps, h->M, P))
         return fail(RSX_ERR_ARG, "task does not match the simulator (VSS_V0: VSS, n_blue >= 1; STATIC_DEFENDERS: SSL 1vN; DRIBBLING: SSL 1v4; CONTESTED: SSL 1v1; PASS_ENDURANCE: SSL 2v0; SCRIMMAGE: SSL)");
@@ -660,7 +695,8 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
         const size_t rows = (size_t)std::max(P.state_dim + X_ROWS, aux_rows(P.n_robots));
         const bool fits = rows * (size_t)P.num_envs * sizeof(float) < ((size_t)1 << 31) && P.n_sub > 0 && P.n_blue == 11;
         // measured crossovers: the spread line-up from 32 768 envs, the crowded one (contacts in every
-        // sub-step: the six robots of a lane are walked one after the other) only from 262 144
+        // sub-step: the six robots of a lane are walked one after the other) only from 131 072 (RSX_QUAD_MIN_ENVS_CROWDED);
+        // multi-step calls on a crowded handle stay with the 32-lane kernel (rsx_task_rollout)
         const int quad_min = task == RSX_TASK_SSL_SCRIMMAGE ? RSX_QUAD_MIN_ENVS : RSX_QUAD_MIN_ENVS_CROWDED;
         h->quad = fits && (lay ? std::strcmp(lay, "quad") == 0 : (quad_min > 0 && P.num_envs >= quad_min));
     }
@@ -677,6 +713,15 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
     }
     h->task_ready = false;
     HIP_TRY(hipDeviceSynchronize());   // null-stream memsets done before any caller stream steps
+    return RSX_OK;
+}
+
+int rsx_task_layout(rsx_sim* h, char* out, size_t n) {
+    if (!h || !out || n == 0) return fail(RSX_ERR_ARG, "null argument");
+    if (h->P.task == RSX_TASK_NONE) return fail(RSX_ERR_STATE, "no task attached (rsx_task_attach)");
+    const char* name = h->epl ? "one-lane-per-env" : h->quad ? "four-lanes-per-env" : h->big ? "32-lanes-per-env-large-batch"
+                     : h->L == 8 ? "8-lanes-per-env" : h->L == 16 ? "16-lanes-per-env" : h->L == 32 ? "32-lanes-per-env" : "64-lanes-per-env";
+    std::snprintf(out, n, "%s", name);
     return RSX_OK;
 }
 
@@ -719,9 +764,15 @@ int rsx_task_reset_to(rsx_sim* h, const double* ball, const double* blue, const 
     return RSX_OK;
 }
 
+// The handle's step counter keys the per-step random draws and is one 32-bit word of the Philox counter: a handle that
+// has taken 2^32 - 1 fused steps refuses further ones instead of silently replaying its random streams.
+#define RSX_NEED_TICKS(h, n) do { if ((uint64_t)(h)->tick + (uint64_t)(n) > 0xFFFFFFFFull) \
+    return fail(RSX_ERR_STATE, "step counter exhausted: a handle takes at most 2^32 - 1 fused steps (it keys the per-step random draws); attach a fresh handle with another seed"); } while (0)
+
 int rsx_task_step(rsx_sim* h, const float* actions_dev, void* stream) {
     RSX_ENTER_TASK(h);
     RSX_NEED_RESET(h);
+    RSX_NEED_TICKS(h, 1);
     h->P.tick_base = h->tick++;
     launch_task(h, actions_dev, 1, MODE_STEP, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
@@ -732,6 +783,7 @@ int rsx_task_step_n(rsx_sim* h, int n, void* stream) {
     RSX_ENTER_TASK(h);
     RSX_NEED_RESET(h);
     if (n < 1) return fail(RSX_ERR_ARG, "n must be >= 1");
+    RSX_NEED_TICKS(h, n);
     for (int i = 0; i < n; ++i) { h->P.tick_base = h->tick++; launch_task(h, nullptr, 1, MODE_STEP, (hipStream_t)stream); }
     HIP_TRY(hipGetLastError());
     return debug_finite(h, (hipStream_t)stream, "rsx_task_step_n");
@@ -741,6 +793,7 @@ int rsx_task_rollout(rsx_sim* h, int n, void* stream) {
     RSX_ENTER_TASK(h);
     RSX_NEED_RESET(h);
     if (n < 0) return fail(RSX_ERR_ARG, "n must be >= 0");  // 0 = load + store only (profiling)
+    RSX_NEED_TICKS(h, n);
     if (h->quad && n >= 1 && h->P.task == RSX_TASK_SSL_SCRIMMAGE && h->P.num_envs >= RSX_QUAD_ROLLOUT_MIN_ENVS) {
         // 11v11 (spread line-up) at large batches: n launches of the four-lanes-per-env kernel beat one launch of the
         // 32-lane kernel (262 144 envs: 200 vs 282 us per step; crowded: 367 vs 347, left alone); same steps, same results

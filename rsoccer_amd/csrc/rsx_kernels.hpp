@@ -660,7 +660,10 @@ __global__ __launch_bounds__(64) void sim_step_kernel(RSX_HOT_ARGS, const Params
     Params P = P_; P.num_envs = hp_num_envs; P.state_dim = hp_state_dim;
     Buffers bufs = bufs_; bufs.state = hp_state; bufs.cmds = hp_in;   // hp_in: the command buffer
     float* const state_out = hp_aux;   // this kernel's second pointer slot: where the new state goes (== hp_state: in place)
-    (void)hp_flags;
+    // fourth pointer slot: a second copy of the new state, or nullptr.  The host-format calls of small batches
+    // (rsx_step / rsx_step_state: the robosim-shaped single-env path) hand in pinned host memory here and read their
+    // commands from pinned host memory too: one launch + one synchronisation per step instead of copy, launch, copy
+    float* const mirror = reinterpret_cast<float*>(hp_flags);
     using K = KC<KIND>;
     constexpr int G = 64 / L;
     constexpr int CD = ModelD<KIND>::cmd_dim;
@@ -700,6 +703,7 @@ __global__ __launch_bounds__(64) void sim_step_kernel(RSX_HOT_ARGS, const Params
         if (KIND == RSX_KIND_SSL) wheel_speeds<KIND>(P, o, w);
     }
     store_body<KIND>(P, state_out, e, b, is_robot, is_ball, o, od, wd, w, P.n_sub != 0 || state_out != hp_state);
+    if (mirror) store_body<KIND>(P, mirror, e, b, is_robot, is_ball, o, od, wd, w, true);
 }
 
 // =============================================================================================

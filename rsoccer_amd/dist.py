@@ -59,6 +59,15 @@ def allreduce_metrics(metrics, device=None):
     return t.cpu().numpy()
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
 def device_tag(device_index):
     """'cuda:3 pci 0000:c5:00.0 <name>' of a visible device — for the per-rank diagnostics of a multi-GPU run."""
     try:
@@ -94,17 +103,41 @@ class MetricsCollective:
         self.reason = None
         self.rccl_ranks = 0
         self.group = None   # RCCL group when it works
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        # a failing RCCL collective must end in the probe's timeout, not in torch's watchdog tearing the process down
-        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
-        os.environ.setdefault("TORCH_NCCL_ENABLE_MONITORING", "0")
+        # The control plane is a gloo group that THIS object owns.  When the caller already runs a process group (of any
+        # backend: an RCCL world would reject the CPU tensors used below) it gets a second, dedicated gloo group over the
+        # same ranks; otherwise the world is initialised here (and torn down in close(), which never touches a group
+        # this object did not make).
+        self._owns_world = False
+        self._made_groups = []
         if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                if world > 1:
+                    raise RuntimeError("MetricsCollective: MASTER_PORT is not set (a fixed default would collide when two "
+                                       "runs share a node); launch the ranks with torchrun / `bench.py --gpus N`, which "
+                                       "pick a free port, or export one")
+                os.environ["MASTER_PORT"] = str(_free_port())
             dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=max(60.0, 4 * timeout_s)))
-        self.ctl = dist.group.WORLD
+            self._owns_world = True
+            self.ctl = dist.group.WORLD
+        else:
+            self.ctl = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=max(60.0, 4 * timeout_s)))
+            self._made_groups.append(self.ctl)
         ok, why = 0, None
         if prefer == "nccl":
-            ok, why = self._probe_rccl(timeout_s, simulate_failure)
+            # a failing RCCL collective must end in the probe's timeout, not in torch's watchdog tearing the process
+            # down: the two switches are read when the group is made, so they are set for the probe only and restored
+            saved = {k: os.environ.get(k) for k in ("TORCH_NCCL_ASYNC_ERROR_HANDLING", "TORCH_NCCL_ENABLE_MONITORING")}
+            for k in saved:
+                os.environ.setdefault(k, "0")
+            try:
+                ok, why = self._probe_rccl(timeout_s, simulate_failure)
+            finally:
+                for k, v in saved.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
         else:
             why = f"not requested (prefer={prefer})"
         flags = torch.tensor([ok, 1 - ok], dtype=torch.int64)
@@ -127,6 +160,16 @@ class MetricsCollective:
         torch, dist = self.torch, self.dist
         sim = simulate_failure is not None and (str(simulate_failure) == "all" or str(simulate_failure) == str(self.rank))
         result = {}
+        # dist.new_group is a collective: either every rank enters it or none does.  The ranks therefore agree over
+        # the control plane FIRST whether all of them can try at all (a device is visible, no all-rank simulated
+        # failure) — a rank that cannot would otherwise leave the others inside new_group until the timeout.
+        can = 1 if (torch.cuda.is_available() and not (sim and str(simulate_failure) == "all")) else 0
+        agree = torch.tensor([can], dtype=torch.int64)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN, group=self.ctl)
+        if int(agree[0]) == 0:
+            why = ("simulated (--simulate-rccl-failure)" if sim else "no HIP device visible") if not can else "another rank cannot use RCCL"
+            self.log(f"RCCL not attempted: {why}")
+            return 0, why
 
         def attempt():
             try:
@@ -166,6 +209,7 @@ class MetricsCollective:
             return 0, "simulated (--simulate-rccl-failure)"
         if "group" in result:
             self.group = result["group"]
+            self._made_groups.append(self.group)
             return 1, None
         self.log(f"RCCL unavailable: {result.get('error')}")
         return 0, result.get("error", "unknown error")
@@ -196,8 +240,22 @@ class MetricsCollective:
             self.dist.barrier(group=self.ctl)
 
     def close(self):
+        """Leaves the process as it was found: the groups made here are destroyed, the world only if this object
+        initialised it."""
         try:
             self.dist.barrier(group=self.ctl)
-            self.dist.destroy_process_group()
         except Exception:   # noqa: BLE001
             pass
+        for g in reversed(self._made_groups):
+            try:
+                self.dist.destroy_process_group(g)
+            except Exception:   # noqa: BLE001
+                pass
+        self._made_groups = []
+        self.group = None
+        if self._owns_world:
+            try:
+                self.dist.destroy_process_group()
+            except Exception:   # noqa: BLE001
+                pass
+            self._owns_world = False

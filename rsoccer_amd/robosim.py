@@ -22,21 +22,35 @@ class _Sim:
                              int(time_step_ms), 1, device_id)
         self.n_robots_blue = int(n_robots_blue)
         self.n_robots_yellow = int(n_robots_yellow)
+        self._n_cmd = self._sim.n_robots * self._sim.cmd_dim
+        self._state = None   # the state the last step() brought home, until get_state() hands it out
         self.reset(np.asarray(ball_pos, dtype=np.float64),
                    np.asarray(blue_robots_pos, dtype=np.float64),
                    np.asarray(yellow_robots_pos, dtype=np.float64))
 
     def step(self, commands):
-        """commands: float64 [n_robots, 2] (VSS) or [n_robots, 8] (SSL)."""
-        self._sim.step(np.asarray(commands, dtype=np.float64))
+        """commands: float64 [n_robots, 2] (VSS) or [n_robots, 8] (SSL).  The new state comes home in the same call
+        (rsx_step_state: the reference always follows step() with get_state(), rsim.py:102,105)."""
+        c = commands
+        if not (type(c) is np.ndarray and c.dtype == np.float64 and c.flags.c_contiguous and c.size == self._n_cmd):
+            c = np.ascontiguousarray(commands, dtype=np.float64)
+            if c.size != self._n_cmd:
+                raise ValueError(f"expected {self._n_cmd} command values, got {c.shape}")
+        self._state = self._sim.step_state(c)[0]
 
     def get_state(self):
-        return self._sim.get_state()[0]
+        s = self._state
+        if s is None:
+            s = self._sim.get_state()[0]
+        else:
+            self._state = None    # handed out once: every call returns a fresh array, like robosim
+        return s
 
     def reset(self, ball_pos, blue_robots_pos, yellow_robots_pos):
         nb, ny = self.n_robots_blue, self.n_robots_yellow
         blue = np.asarray(blue_robots_pos, dtype=np.float64).reshape(nb, 3) if nb else None
         yellow = np.asarray(yellow_robots_pos, dtype=np.float64).reshape(ny, 3) if ny else None
+        self._state = None
         self._sim.reset(np.asarray(ball_pos, dtype=np.float64).reshape(1, 4), blue, yellow)
 
     def get_field_params(self):

@@ -40,3 +40,33 @@ def blue_observation(env, robot, with_velocity=True):
         out += [env.norm_v(robot.v_x), env.norm_v(robot.v_y)]
     out.append(env.norm_w(robot.v_theta))
     return out
+
+
+def observation_entries(n_blue, n_yellow, with_velocity=True, infrared="flag", lead=0):
+    """``(state index, kind)`` per observation slot of the SSL hardware-challenge layouts (static_defenders.py:90-112,
+    dribbling.py:76-104, contested_possession.py:78-104, pass_endurance.py:77-91) for ``VSSBaseEnv._observation_plan``:
+    ``lead`` task-specific leading slots (filled by the task), ball x, y, v_x, v_y, then per blue robot x, y, sin, cos
+    [, v_x, v_y], v_theta, infrared and per yellow robot x, y.  SSL robots are 11 values wide in the state vector."""
+    entries = [(0, "const")] * lead + [(0, "pos"), (1, "pos"), (3, "v"), (4, "v")]
+    for i in range(n_blue):
+        b = 5 + 11 * i
+        entries += [(b, "pos"), (b + 1, "pos"), (b + 2, "sin"), (b + 2, "cos")]
+        if with_velocity:
+            entries += [(b + 3, "v"), (b + 4, "v")]
+        entries += [(b + 5, "w"), (b + 6, infrared)]
+    for i in range(n_yellow):
+        b = 5 + 11 * (n_blue + i)
+        entries += [(b, "pos"), (b + 1, "pos")]
+    return entries
+
+
+def observe(env, lead_value=None, **layout):
+    """the task's observation from the state vector behind ``env.frame`` (plan cached on the env, rebuilt when a task
+    changes its speed limits); frames assembled by hand fall back to ``None`` (the caller then walks the records)"""
+    state = env.frame.state
+    if state is None:
+        return None
+    plan = env.__dict__.get("_obs_plan")
+    if plan is None or plan["key"] != (env.max_pos, env.max_v, env.max_w):
+        plan = env._obs_plan = env._observation_plan(observation_entries(env.n_robots_blue, env.n_robots_yellow, **layout))
+    return env._observe(plan, state, lead_value)

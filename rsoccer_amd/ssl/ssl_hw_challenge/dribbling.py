@@ -36,6 +36,9 @@ class SSLHWDribblingEnv(SSLBaseEnv):
         return super().reset(seed=seed, options=options)
 
     def _frame_to_observations(self):
+        fast = _shared.observe(self, lead_value=((self.checkpoints_count / 6) * 2) - 1, infrared="sflag", lead=1)
+        if fast is not None:
+            return fast
         f = self.frame
         obs = [((self.checkpoints_count / 6) * 2) - 1,
                self.norm_pos(f.ball.x), self.norm_pos(f.ball.y), self.norm_v(f.ball.v_x), self.norm_v(f.ball.v_y)]

@@ -51,6 +51,9 @@ class SSLPassEnduranceEnv(SSLBaseEnv):
         return observation, reward, terminated, truncated, self.reward_shaping_total
 
     def _frame_to_observations(self):
+        fast = _shared.observe(self, with_velocity=False)
+        if fast is not None:
+            return fast
         f = self.frame
         obs = [self.norm_pos(f.ball.x), self.norm_pos(f.ball.y), self.norm_v(f.ball.v_x), self.norm_v(f.ball.v_y)]
         for i in range(self.n_robots_blue):

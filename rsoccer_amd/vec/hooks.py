@@ -92,7 +92,7 @@ class _VecBaseEnv:
         self.commands = self.sim.cmds_tensor().view(n, self.sim.cmd_dim, self.num_envs)
         self.last_frame = None
         self.steps = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
-        self._device_placement = None   # whether _get_initial_positions() returns device tensors (known after the first call)
+        self._device_placement = None   # whether _get_initial_positions() returns device tensors (learnt in _place())
 
     def _stream(self):
         return self._torch.cuda.current_stream(self.device).cuda_stream
@@ -101,7 +101,8 @@ class _VecBaseEnv:
         """teleport the envs selected by env_mask ([B] bool device tensor, host array or None = all)"""
         torch = self._torch
         ball, blue, yellow = self._get_initial_positions()
-        if isinstance(ball, torch.Tensor):     # device placement: stream-ordered, no host copy, no sync
+        self._device_placement = isinstance(ball, torch.Tensor)   # learnt from the value at hand: no extra call of the hook
+        if self._device_placement:             # device placement: stream-ordered, no host copy, no sync
             m = None if env_mask is None else torch.as_tensor(env_mask, device=self.device)
             self.sim.reset_dev(ball, blue, yellow, m, self._stream())
         else:                                  # host arrays (robosim.reset format): PCIe + synchronisation
@@ -127,9 +128,14 @@ class _VecBaseEnv:
         if self.auto_reset:
             ended = done | truncated
             info["final_obs"] = obs.clone()     # the hook may hand out a buffer it reuses
-            if self._device_placement is None:  # decided once: what the subclass' placement hook returns
-                self._device_placement = isinstance(self._get_initial_positions()[0], torch.Tensor)
-            if self._device_placement:
+            if self._device_placement is None:
+                # step() before any reset(): not yet known what the placement hook returns.  One placement of the
+                # ended envs tells (the hook is never called just to look at its return type: a user's hook draws
+                # from its own random stream)
+                self._place(ended)
+                self.steps.masked_fill_(ended, 0)
+                obs = torch.where(ended[:, None], self._frame_to_observations(), obs)
+            elif self._device_placement:
                 # device placement: stream-ordered and masked on the device, no host round trip — every step
                 self._place(ended)
                 self.steps.masked_fill_(ended, 0)

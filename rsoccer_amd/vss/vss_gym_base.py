@@ -106,6 +106,38 @@ class VSSBaseEnv(gym.Env):
         """the Frame holding the start poses of an episode (reset)"""
         raise NotImplementedError
 
+    # ---- observations in array form ----
+    def _observation_plan(self, entries):
+        """Compiles an observation layout into index / scale arrays for :meth:`_observe`.  ``entries``: one
+        ``(state index, kind)`` per observation slot, kind in ``pos | v | w`` (normalised like norm_pos / norm_v /
+        norm_w), ``sin | cos`` (of the heading in degrees at that index), ``flag`` (1 if non-zero else 0), ``sflag`` (1 if non-zero
+        else -1), ``const`` (0: a slot the task fills itself)."""
+        idx = np.array([i for i, _ in entries], dtype=np.intp)
+        kinds = [k for _, k in entries]
+        scale = {"pos": self.max_pos, "v": self.max_v, "w": self.max_w}
+        den = np.array([scale.get(k, 1.0) for k in kinds], dtype=np.float64)
+        pick = lambda kind: np.array([n for n, k in enumerate(kinds) if k == kind], dtype=np.intp)
+        return {"idx": idx, "den": den, "sin": pick("sin"), "cos": pick("cos"), "flag": pick("flag"),
+                "sflag": pick("sflag"), "const": pick("const"), "key": (self.max_pos, self.max_v, self.max_w)}
+
+    def _observe(self, plan, state, lead=None):
+        """the float32 observation vector of ``state`` — per slot exactly what the reference's scalar hooks compute
+        (``np.clip(value / max, -1.2, 1.2)``, ``np.sin(np.deg2rad(theta))``), in a handful of array operations"""
+        raw = state[plan["idx"]]
+        out = raw / plan["den"]
+        np.maximum(out, -self.NORM_BOUNDS, out=out)     # np.clip's two ufuncs, without its Python dispatch
+        np.minimum(out, self.NORM_BOUNDS, out=out)
+        if len(plan["sin"]):
+            out[plan["sin"]] = np.sin(np.deg2rad(raw[plan["sin"]]))
+            out[plan["cos"]] = np.cos(np.deg2rad(raw[plan["cos"]]))
+        if len(plan["flag"]):
+            out[plan["flag"]] = raw[plan["flag"]] != 0
+        if len(plan["sflag"]):
+            out[plan["sflag"]] = np.where(raw[plan["sflag"]] != 0, 1.0, -1.0)
+        if len(plan["const"]):
+            out[plan["const"]] = 0.0 if lead is None else lead
+        return out.astype(np.float32)
+
     # ---- normalisation helpers ----
     def norm_pos(self, pos):
         return np.clip(pos / self.max_pos, -self.NORM_BOUNDS, self.NORM_BOUNDS)

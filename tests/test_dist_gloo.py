@@ -80,3 +80,52 @@ def test_allreduce_is_identity_without_a_process_group():
     from rsoccer_amd.dist import allreduce_metrics
     m = np.arange(8, dtype=np.int64)
     assert np.array_equal(allreduce_metrics(m), m)
+
+
+def _collective_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from rsoccer_amd import dist as rdist
+    env_before = {k: os.environ.get(k) for k in ("TORCH_NCCL_ASYNC_ERROR_HANDLING", "TORCH_NCCL_ENABLE_MONITORING")}
+    # the caller's own world, made before the collective exists
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    coll = rdist.MetricsCollective(rank, world, device=None, prefer="nccl", timeout_s=5.0)   # no GPU here: degrades
+    assert coll.ctl is not dist.group.WORLD and coll.backend == "gloo" and "rccl failed" in coll.describe()
+    t = torch.arange(8, dtype=torch.int64) * (rank + 1)
+    coll.all_reduce(t)
+    coll.barrier()
+    coll.close()
+    assert dist.is_initialized()                      # close() left the caller's world alone ...
+    u = torch.ones(1)
+    dist.all_reduce(u)                                # ... and it still works
+    env_after = {k: os.environ.get(k) for k in env_before}
+    np.save(os.path.join(out, f"coll{rank}.npy"), np.concatenate([t.numpy(), [int(u[0])], [int(env_before == env_after)]]))
+    dist.destroy_process_group()
+
+
+def test_metrics_collective_uses_its_own_groups(tmp_path):
+    """MetricsCollective inside a process that already runs torch.distributed — it makes a dedicated gloo
+    control group, degrades without RCCL after agreeing over that group, destroys only what it made and leaves the
+    NCCL environment switches as it found them."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_collective_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        v = np.load(tmp_path / f"coll{r}.npy")
+        assert np.array_equal(v[:8], np.arange(8) * 3) and v[8] == 2 and v[9] == 1
+
+
+def test_metrics_collective_needs_a_port_for_several_ranks(monkeypatch):
+    from rsoccer_amd import dist as rdist
+    for k in ("MASTER_PORT", "MASTER_ADDR"):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(RuntimeError, match="MASTER_PORT"):
+        rdist.MetricsCollective(0, 2, prefer="gloo")
+    coll = rdist.MetricsCollective(0, 1, prefer="gloo")   # one rank: a free port is picked
+    assert coll.backend == "gloo" and coll.describe() == "gloo"
+    coll.close()
+    import torch.distributed as dist
+    assert not dist.is_initialized()

@@ -304,6 +304,9 @@ def test_full_size_soak_invariants(task, kind, ft, nb, ny, B, steps):
     assert np.array_equal(out[0], out[1])
 
 
+RR_WORST_CM, RR_P99_CM = 4.5, 2.0   # measured envelope of the scrum below (MI355X: see the assertion message)
+
+
 def test_crowded_11v11_full_size_contact_invariants():
     """BASELINE.json configs[3] at its full size: 1024 envs x 22 robots on the division-A field, all of
     them chasing the ball (a 22-robot scrum: the worst case for the all-pairs contact sweeps), random
@@ -329,6 +332,7 @@ def test_crowded_11v11_full_size_contact_invariants():
     gen = torch.Generator(device="cuda"); gen.manual_seed(9)
     f = sim.get_field_params()
     worst_rr = worst_rb = 0.0
+    samples = []   # deepest robot-robot overlap of every env, every fifth step
     eye = torch.eye(N, device="cuda", dtype=torch.bool)[:, :, None]
     for t in range(1000):
         x, y, th = st[rows], st[rows + 1], torch.deg2rad(st[rows + 2])
@@ -345,7 +349,7 @@ def test_crowded_11v11_full_size_contact_invariants():
         if t % 5 == 4:
             x, y = st[rows], st[rows + 1]
             d = torch.hypot(x[:, None] - x[None], y[:, None] - y[None]).masked_fill(eye, 9.0)
-            worst_rr = max(worst_rr, 0.18 - d.min().item())
+            samples.append(0.18 - d.amin(dim=(0, 1)))
             low = st[2] < 0.15
             db = torch.hypot(x - st[0][None], y - st[1][None]).min(0).values
             worst_rb = max(worst_rb, ((0.073 + 0.0215) - db)[low].max().item())
@@ -355,7 +359,21 @@ def test_crowded_11v11_full_size_contact_invariants():
     xs = np.concatenate([full[:, 0:1]] + [full[:, 5 + 11 * k: 6 + 11 * k] for k in range(N)], 1)
     ys = np.concatenate([full[:, 1:2]] + [full[:, 6 + 11 * k: 7 + 11 * k] for k in range(N)], 1)
     assert np.abs(xs).max() <= f["length"] / 2 + f["goal_depth"] + 0.35 and np.abs(ys).max() <= f["width"] / 2 + 0.35
-    assert 0.005 < worst_rr < 0.06, worst_rr          # it IS a scrum, and nothing tunnels
+    over = torch.stack(samples).clamp_min(0.0).flatten()
+    worst_rr = over.max().item()
+    p99 = torch.quantile(over.float(), 0.99).item()
+    if os.environ.get("RSX_PRINT_ENVELOPE"):
+        print(f"crowded 11v11 envelope: worst robot-robot overlap {worst_rr * 100:.2f} cm, p99 {p99 * 100:.2f} cm, "
+              f"worst ball-in-kicker {worst_rb * 100:.2f} cm")
+    # The bounds are the MEASURED envelope of the frozen model, not a tuning target: a change that makes
+    # the jam behaviour worse has to fail here.  Why centimetres at all: every sample deeper than 2.5 cm is a pile that
+    # the robots' own push holds against a goal's back wall or the boundary wall — phase C clamps bodies into the field
+    # AFTER the contact phase of the sub-step, which puts a robot the pile squeezed over the line back into its
+    # neighbour; more Jacobi sweeps or projection passes do not remove it (profiles/r03_jam_experiment.txt).
+    msg = (f"worst robot-robot overlap {worst_rr * 100:.2f} cm (bound %s), p99 {p99 * 100:.2f} cm (bound %s): the wall-pile "
+           "residual of the contact model grew — see DESIGN.md 4") % (RR_WORST_CM, RR_P99_CM)
+    assert 0.005 < worst_rr < RR_WORST_CM / 100.0, msg      # it IS a scrum, and nothing tunnels
+    assert p99 < RR_P99_CM / 100.0, msg
     assert worst_rb < 0.04, worst_rb
     sim.close()
 
@@ -765,6 +783,28 @@ def test_api_errors_are_reported_not_crashed():
     with pytest.raises(L.RsxError, match="does not match"):
         ssl.task_attach(3, 0, 0, 0)           # dribbling needs 1v4
     ssl.close()
+    # the two 32-bit words of the Philox counter that a caller can overrun are range-checked, not wrapped (rsx.h)
+    sim = L.Sim(0, 0, 3, 3, 25, 8)
+    with pytest.raises(L.RsxError, match=r"exceeds 2\^32"):
+        sim.task_attach(1, 0, 2 ** 32 - 4, 0)            # global env ids 2^32 - 4 .. 2^32 + 3
+    with pytest.raises(L.RsxError, match=r"exceeds 2\^32"):
+        sim.task_attach(1, 0, 2 ** 40, 0)
+    sim.task_attach(1, 0, 2 ** 32 - 8, 0)                # the last eight ids are fine
+    sim.task_reset()
+    sim.task_step_n(3)
+    blob = sim.task_checkpoint().copy()
+    assert int(blob[76:80].view(np.uint32)[0]) == 3      # the handle's step counter in the checkpoint header
+    blob[76:80] = np.array([0xFFFFFFFD], dtype=np.uint32).view(np.uint8)
+    sim.task_restore(blob)
+    before = sim.get_state_full()
+    for call in (lambda: sim.task_step_n(3), lambda: sim.task_rollout(3)):
+        with pytest.raises(L.RsxError, match="step counter exhausted"):
+            call()                                       # 2^32 - 3 + 3 steps would wrap the counter
+    assert np.array_equal(before, sim.get_state_full())  # a refused call changes nothing
+    sim.task_step_n(2)                                   # the last two steps a handle can take
+    with pytest.raises(L.RsxError, match="step counter exhausted"):
+        sim.task_step(None)
+    sim.close()
 
 
 def test_api_calls_leave_the_current_device_alone():
