@@ -48,7 +48,7 @@ METRIC = "env-steps/sec (whole node), VSS-v0 3v3 @4096 envs, 1/2/4/8 GPU + CPU r
 ALLREDUCE_EVERY = 100           # steps between metrics all-reduces
 STEADY_STEPS, STEADY_WARMUP = 2000, 200
 SWEEP_ENVS = (65536, 1048576, 4194304)
-EPL_MIN_ENVS = 98304            # rsx_api.hip: batches from here on use the one-lane-per-env kernel
+HBM_ACHIEVABLE_GBS = 6290.0     # MI355X_MICROARCH.md: what a streaming kernel reaches of the 8 TB/s
 
 
 def usable_cores():
@@ -142,19 +142,59 @@ def cpu_baseline(envs, budget_s=12.0, single_s=1.5):
                     "engine is not in /root/reference and cannot be built or run here"}
 
 
-def kernel_name(envs, mode):
-    lay = os.environ.get("RSX_LAYOUT")
-    epl = lay == "epl" or (lay != "lanes" and envs >= EPL_MIN_ENVS)
-    if epl:
+def kernel_name(layout, mode):
+    """kernel symbol of a VSS-v0 3v3 handle from the layout the LIBRARY reports (rsx_task_layout): no threshold is
+    restated here"""
+    if layout == "one-lane-per-env":
         return "rsx::vss_epl_kernel<0>" if mode == "step" else "rsx::vss_epl_rollout_kernel"
-    return "rsx::task_step_kernel<0, 8, 1, 6, %d>" % (0 if mode == "step" else 3)
+    lanes = {"8-lanes-per-env": 8, "16-lanes-per-env": 16, "32-lanes-per-env": 32, "64-lanes-per-env": 64}.get(layout, 8)
+    return "rsx::task_step_kernel<0, %d, 1, 6, %d>" % (lanes, 0 if mode == "step" else 3)
 
 
-def roofline_of(envs, launch_us, units_per_launch, mode, traffic=None, traffic_source=None):
+_LEG_TRAFFIC = None
+
+
+def leg_traffic(leg):
+    """(bytes per launch, source) of a large-batch leg from the newest profiles/r*_leg_traffic.json (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE passes of tools/prof_leg_traffic.sh: the counters need their own runs), or (None, None)"""
+    global _LEG_TRAFFIC
+    if _LEG_TRAFFIC is None:
+        import glob
+        import re
+        _LEG_TRAFFIC = ({}, None)
+        files = glob.glob(os.path.join(ROOT, "profiles", "r*_leg_traffic.json"))
+        files.sort(key=lambda f: int(re.search(r"r(\d+)_", os.path.basename(f)).group(1)), reverse=True)
+        for f in files:
+            try:
+                _LEG_TRAFFIC = (json.load(open(f)).get("legs", {}), os.path.relpath(f, ROOT))
+                break
+            except Exception:
+                continue
+    legs, src = _LEG_TRAFFIC
+    rec = legs.get(leg)
+    if not rec or not rec.get("bytes_per_launch"):
+        return None, None
+    return rec["bytes_per_launch"], src
+
+
+def with_traffic(rec, leg, us_per_launch):
+    """adds the counter traffic of a leg and what it means in bandwidth: traffic / time against the ~6.29 TB/s a
+    streaming kernel reaches (the roofline fraction beside it is SURVEY's algorithmic bytes against the nominal 8)"""
+    t, src = leg_traffic(leg)
+    rec["traffic"] = t
+    if t:
+        rec["traffic_source"] = src + " (separate rocprofv3 --pmc passes of this leg, not measured in this run)"
+        rec["traffic_over_algorithmic"] = t / (rec["algorithmic_bytes_per_env_step"] * rec["envs"]) if rec.get("algorithmic_bytes_per_env_step") else None
+        rec["real_tb_per_s"] = t / (us_per_launch * 1e-6) / 1e12
+        rec["real_frac_of_achievable"] = t / (us_per_launch * 1e-6) / 1e9 / HBM_ACHIEVABLE_GBS
+    return rec
+
+
+def roofline_of(envs, launch_us, units_per_launch, mode, traffic=None, traffic_source=None, layout="8-lanes-per-env"):
     achieved = ALGO_BYTES_PER_ENV_STEP * units_per_launch / (launch_us * 1e-6) / 1e9
     r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-         "kernel": kernel_name(envs, mode), "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
+         "kernel": kernel_name(layout, mode), "layout": layout, "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
          "avg_launch_us": launch_us}
     if traffic_source:
         r["traffic_source"] = traffic_source
@@ -173,26 +213,16 @@ def rank_logger(rank, world, tag=""):
 
 
 def efficiency_vs_n1(value, world):
-    """value / (N x the N=1 value) when the N=1 figure is known: RSX_BENCH_N1_VALUE, else the newest profiles/r*_bench.json"""
-    n1, src = None, None
-    if os.environ.get("RSX_BENCH_N1_VALUE"):
-        try:
-            n1, src = float(os.environ["RSX_BENCH_N1_VALUE"]), "RSX_BENCH_N1_VALUE"
-        except ValueError:
-            pass
-    if n1 is None:
-        import glob
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_driver_flags.json")), reverse=True):
-            try:
-                d = json.load(open(path))
-                if d.get("n_gpus") == 1 and d.get("value"):
-                    n1, src = float(d["value"]), os.path.relpath(path, ROOT)
-                    break
-            except Exception:
-                continue
+    """value / (N x the N=1 value) — only when the caller supplies the single-GPU value of the SAME build and box
+    (RSX_BENCH_N1_VALUE); a figure read from a checked-in profile would mix runs.  The driver computes scaling
+    efficiency itself from its own N = 1, 2, 4, 8 runs."""
+    try:
+        n1 = float(os.environ["RSX_BENCH_N1_VALUE"])
+    except (KeyError, ValueError):
+        return None
     if not n1 or world < 1:
         return None
-    return {"efficiency_vs_n1": value / (world * n1), "n1_value": n1, "n1_source": src}
+    return {"efficiency_vs_n1": value / (world * n1), "n1_value": n1, "n1_source": "RSX_BENCH_N1_VALUE"}
 
 
 def dry_run(args, rank, world):
@@ -281,6 +311,7 @@ def main():
     sim = L.Sim(L.KIND_VSS, 0, 3, 3, 25, B, dev)
     sim.task_attach(L.TASK_VSS_V0, seed=0, env_id_base=rank * B, max_episode_steps=0)
     tens = sim.task_tensors()
+    layout = sim.task_layout()
     stream = torch.cuda.current_stream().cuda_stream
     sim.task_reset(stream)
     mbuf = torch.zeros(L.N_METRICS, dtype=torch.int64, device=coll.buffer_device() if coll else "cpu")
@@ -367,7 +398,9 @@ def main():
         units_per_launch = B if args.mode == "step" else B * K
         traffic, tsrc = None, None
         import glob
-        for tp in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
+        import re
+        for tp in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True,
+                         key=lambda f: int(re.search(r"r(\d+)_", os.path.basename(f)).group(1))):   # newest ROUND first (r10 after r9)
             if B == 4096 and args.mode == "step":   # the counters were collected on this configuration
                 try:
                     traffic = json.load(open(tp)).get("bytes_per_launch")
@@ -390,17 +423,27 @@ def main():
                                   "whose sources are not part of the reference tree"},
             "episodes": int(metrics[1]), "env_steps_counted": int(metrics[0]),
         }
+        # One measurement window for `value`, `ms_per_step` and `roofline`: a timed region of fewer than 200 launches (the
+        # driver's --steps 20 is 0.2 ms of wall clock: +-10 % from run to run) is reported beside the steady leg, which
+        # then carries the headline figures; with >= 200 steps the timed region itself does.
+        if args.mode == "step" and steady is not None and K < 200:
+            line["value_timed_region"] = value
+            line["ms_per_step_timed_region"] = wall * 1e3 / K
+            line["value"] = world * B * STEADY_STEPS / steady[0]
+            line["ms_per_step"] = steady[0] * 1e3 / STEADY_STEPS
+            line["value_source"] = (f"steady leg ({STEADY_STEPS} per-step launches after {max(W + K, STEADY_WARMUP)}, same barrier + synchronize "
+                                    f"bracket); the {K}-step timed region the flags ask for is value_timed_region")
         # `roofline` is the dominant kernel's launch average over the STEADY leg (>= 2000 launches after >= 200: what a
         # rocprofv3 --kernel-trace --stats of this command averages over, profiles/); the short timed region of the
         # driver's flags (early-episode steps, a few launches) is kept beside it as frac_timed_region
         if args.mode == "step" and steady is not None:
             sd_us = steady[1] * 1e3 / STEADY_STEPS
-            line["roofline"] = roofline_of(B, sd_us, B, "step", traffic, tsrc)
+            line["roofline"] = roofline_of(B, sd_us, B, "step", traffic, tsrc, layout)
             line["roofline"]["source"] = f"steady leg: HIP-event average of {STEADY_STEPS} per-step launches after {max(W + K, STEADY_WARMUP)}"
             line["roofline"]["frac_timed_region"] = roofline_of(B, launch_us, units_per_launch, "step")["frac"]
             line["roofline"]["avg_launch_us_timed_region"] = launch_us
         else:
-            line["roofline"] = roofline_of(B, launch_us, units_per_launch, args.mode, traffic, tsrc)
+            line["roofline"] = roofline_of(B, launch_us, units_per_launch, args.mode, traffic, tsrc, layout)
             line["roofline"]["source"] = f"timed region: HIP-event average of {K if args.mode == 'step' else 1} launch(es) after {W} steps"
             if args.mode == "rollout":
                 line["roofline"]["notional"] = True
@@ -461,15 +504,18 @@ def sweep(L, torch, dev, timed, n=100, warm=30):
                 continue
             s = L.Sim(L.KIND_VSS, 0, 3, 3, 25, B, dev)
             s.task_attach(L.TASK_VSS_V0, seed=0, env_id_base=0, max_episode_steps=0)
+            lay = s.task_layout()
             s.task_reset(torch.cuda.current_stream().cuda_stream)
             w1, d1 = timed(s, n, warm, "step")
             w2, d2 = timed(s, n, 0, "rollout")
             s.close()
             del s
             torch.cuda.empty_cache()
-            out.append({"envs": B, "kernel": kernel_name(B, "step"),
-                        "step": {"us_per_step": d1 * 1e3 / n, "value": B * n / w1,
-                                 "roofline_frac": roofline_of(B, d1 * 1e3 / n, B, "step")["frac"]},
+            step = {"us_per_step": d1 * 1e3 / n, "value": B * n / w1, "envs": B,
+                    "algorithmic_bytes_per_env_step": ALGO_BYTES_PER_ENV_STEP,
+                    "roofline_frac": roofline_of(B, d1 * 1e3 / n, B, "step")["frac"]}
+            with_traffic(step, f"vss:{B}", d1 * 1e3 / n)
+            out.append({"envs": B, "kernel": kernel_name(lay, "step"), "layout": lay, "step": step,
                         "rollout": {"us_per_step": d2 * 1e3 / n, "value": B * n / w2, "notional": True,
                                     "roofline_frac": roofline_of(B, d2 * 1e3, B * n, "rollout")["frac"]},
                         "steps": n, "warmup": warm})
@@ -488,6 +534,8 @@ def other_configs(L, torch, dev, timed):
     cases = (("configs[2] SSLStaticDefenders-v0 1v6", 1, 2, 1, 6, L.TASK_SSL_STATIC_DEFENDERS, 2048, SD, 2000, 200),
              ("SSLStaticDefenders-v0 1v6, 262 144 envs (one-lane-per-env kernel)", 1, 2, 1, 6, L.TASK_SSL_STATIC_DEFENDERS, 262144, SD, 100, 30),
              ("SSLStaticDefenders-v0 1v6, 1 048 576 envs (one-lane-per-env kernel)", 1, 2, 1, 6, L.TASK_SSL_STATIC_DEFENDERS, 1048576, SD, 60, 20),
+             ("SSLStaticDefenders-v0 1v6, 4 194 304 envs (1.4 GB of state: beyond the 256 MB memory-side cache)", 1, 2, 1, 6,
+              L.TASK_SSL_STATIC_DEFENDERS, 4194304, SD, 30, 10),
              ("SSLDribbling-v0 1v4, 1 048 576 envs (one-lane-per-env kernel)", 1, 2, 1, 4, L.TASK_SSL_DRIBBLING, 1048576, ssl_bytes(5, 21), 60, 20),
              ("SSLContestedPossession-v0 1v1, 1 048 576 envs (one-lane-per-env kernel)", 1, 2, 1, 1, L.TASK_SSL_CONTESTED, 1048576, ssl_bytes(2, 14), 60, 20),
              ("SSLPassEndurance-v0 2v0, 1 048 576 envs (one-lane-per-env kernel)", 1, 2, 2, 0, L.TASK_SSL_PASS_ENDURANCE, 1048576, ssl_bytes(2, 16), 60, 20),
@@ -498,18 +546,30 @@ def other_configs(L, torch, dev, timed):
              ("SSL 11v11 scrimmage, crowded, 65 536 envs (32 lanes per env, large-batch build)", 1, 1, 11, 11, L.TASK_SSL_SCRIMMAGE_CROWDED, 65536, SC, 60, 20),
              ("SSL 11v11 scrimmage, spread, 262 144 envs (four lanes per env)", 1, 1, 11, 11, L.TASK_SSL_SCRIMMAGE, 262144, SC, 30, 10),
              ("SSL 11v11 scrimmage, crowded, 262 144 envs (four lanes per env)", 1, 1, 11, 11, L.TASK_SSL_SCRIMMAGE_CROWDED, 262144, SC, 30, 10))
+    LEG = {L.TASK_SSL_STATIC_DEFENDERS: "sd", L.TASK_SSL_DRIBBLING: "drib", L.TASK_SSL_CONTESTED: "cont",
+           L.TASK_SSL_PASS_ENDURANCE: "pass", L.TASK_SSL_SCRIMMAGE: "scrim", L.TASK_SSL_SCRIMMAGE_CROWDED: "scrimC"}
     out = []
     for name, kind, ft, nb, ny, task, B, bytes_, n, warm in cases:
         try:
+            free, _ = torch.cuda.mem_get_info()
+            if free < B * 1400:
+                out.append({"workload": name, "envs": B, "skipped": f"only {free >> 20} MiB free"})
+                continue
             s = L.Sim(kind, ft, nb, ny, 25, B, dev)
             s.task_attach(task, seed=0, env_id_base=0, max_episode_steps=0)
+            lay = s.task_layout()
             s.task_reset(torch.cuda.current_stream().cuda_stream)
             w, d = timed(s, n, warm, "step")
             s.close()
+            del s
+            torch.cuda.empty_cache()
             us = d * 1e3 / n
-            out.append({"workload": name, "envs": B, "us_per_step": us, "value": B * n / w, "unit": "env-steps/s",
-                        "algorithmic_bytes_per_env_step": bytes_, "roofline_frac": bytes_ * B / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                        "steps": n, "warmup": warm})
+            rec = {"workload": name, "envs": B, "layout": lay, "us_per_step": us, "value": B * n / w, "unit": "env-steps/s",
+                   "algorithmic_bytes_per_env_step": bytes_, "roofline_frac": bytes_ * B / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                   "steps": n, "warmup": warm}
+            if B >= 65536:
+                with_traffic(rec, f"{LEG[task]}:{B}", us)
+            out.append(rec)
         except Exception as ex:
             out.append({"workload": name, "envs": B, "error": repr(ex)})
     return out

@@ -134,6 +134,7 @@ int main(int argc, char** argv) {
         HK(hipDeviceSynchronize());
     }
 
+    void* hip_kernarg = nullptr;
     auto submit = [&](uint16_t header, void* kernarg, hsa_signal_t sig) {
         const uint64_t idx = hsa_queue_add_write_index_relaxed(q, 1);
         while (idx - hsa_queue_load_read_index_scacquire(q) >= q->size) {}
@@ -142,7 +143,7 @@ int main(int argc, char** argv) {
         pk->reserved0 = 0;
         pk->grid_size_x = 512 * 64; pk->grid_size_y = 1; pk->grid_size_z = 1;
         pk->private_segment_size = scratch; pk->group_segment_size = lds;
-        pk->kernel_object = kobj; pk->kernarg_address = kernarg; pk->reserved2 = 0;
+        pk->kernel_object = kobj; pk->kernarg_address = hip_kernarg ? hip_kernarg : kernarg; pk->reserved2 = 0;
         pk->completion_signal = sig;
         const uint16_t setup = (getenv("SETUP3") ? 3 : 1) << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
         __atomic_store_n((uint32_t*)pk, (uint32_t)header | ((uint32_t)setup << 16), __ATOMIC_RELEASE);
@@ -172,6 +173,7 @@ int main(int argc, char** argv) {
     CK(hsa_signal_create(1 << 30, 0, nullptr, &dummy));
     const bool every = getenv("EVERY_SIGNAL") != nullptr;
     const bool rot = getenv("ROTATE_KERNARG") != nullptr && !getenv("KERNARG_HOST");
+    if (hip_kernarg) printf("using the HIP runtime's kernarg block %p for every packet\n", hip_kernarg);
     auto run = [&](const char* name, uint16_t h, int sc1) {
         for (int rep = 0; rep < 2; ++rep) {
             hsa_signal_store_relaxed(done, 1);
@@ -244,7 +246,10 @@ int main(int argc, char** argv) {
             const uint64_t w = hsa_queue_load_write_index_relaxed(hq);
             for (uint64_t k = w > 8 ? w - 8 : 0; k < w; ++k) {
                 const hsa_kernel_dispatch_packet_t* d = (const hsa_kernel_dispatch_packet_t*)hq->base_address + (k & (hq->size - 1));
-                if (d->workgroup_size_x == 64 && d->grid_size_x == 32768 && d->kernel_object) kobj = d->kernel_object;
+                if (d->workgroup_size_x == 64 && d->grid_size_x == 32768 && d->kernel_object) {
+                    kobj = d->kernel_object;
+                    if (getenv("USE_HIP_KERNARG")) { hip_kernarg = d->kernarg_address; }
+                }
             }
         }
         printf("using the HIP runtime's kernel object %#lx\n", (unsigned long)kobj);
