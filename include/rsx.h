@@ -211,6 +211,13 @@ int rsx_task_view_get(rsx_sim* h, rsx_task_view* out);
  * "four-lanes-per-env".  NUL-terminated into out[n] — for profiles and benchmark lines, so that nothing outside the
  * library restates its thresholds. */
 int rsx_task_layout(rsx_sim* h, char* out, size_t n);
+/* Introspection of the placement cache (handles of VSS_V0 3v3 / STATIC_DEFENDERS 1v6 with at most 16 384 envs: every
+ * single-step launch carries helper workgroups that compute each env's NEXT episode's random placement ahead of time —
+ * a pure function of seed, global env id and episode — so that the wave that resets an env only copies it; results are
+ * those of the inline placement, bit for bit).  out[0] = resets served from the cache, out[1] = placed inline; both -1
+ * when the handle has no cache or the counters are off (set RSX_PCACHE_STATS=1 before rsx_task_attach; RSX_NO_PCACHE=1
+ * disables the cache).  Synchronises `stream`. */
+int rsx_task_placement_cache_stats(rsx_sim* h, int64_t out[2], void* stream);
 
 /* reset(): new random placement for every env (vss_gym.py:194-233, static_defenders.py:214-254),
  * episode counters cleared, obs written. */

@@ -33,7 +33,7 @@ SYMBOLS = (
     "rsx_get_field_params", "rsx_reset", "rsx_step", "rsx_get_state", "rsx_step_state", "rsx_set_state",
     "rsx_get_state_full", "rsx_dev_view_get", "rsx_step_dev", "rsx_step_dev_random", "rsx_step_dev_flip", "rsx_state_buffers",
     "rsx_reset_dev", "rsx_task_attach",
-    "rsx_task_view_get", "rsx_task_layout", "rsx_task_reset", "rsx_task_reset_to", "rsx_task_step",
+    "rsx_task_view_get", "rsx_task_layout", "rsx_task_placement_cache_stats", "rsx_task_reset", "rsx_task_reset_to", "rsx_task_step",
     "rsx_task_step_n", "rsx_task_rollout", "rsx_read_metrics", "rsx_metrics_fold", "rsx_check_finite",
     "rsx_task_checkpoint_size", "rsx_task_checkpoint_save", "rsx_task_checkpoint_load",
 )
@@ -85,6 +85,7 @@ def load():
     lib.rsx_get_state.argtypes = [vp, vp, vp]
     lib.rsx_step_state.argtypes = [vp, vp, vp, vp]
     lib.rsx_task_layout.argtypes = [vp, C.c_char_p, C.c_size_t]
+    lib.rsx_task_placement_cache_stats.argtypes = [vp, C.POINTER(C.c_int64), vp]
     lib.rsx_set_state.argtypes = [vp, vp, vp]
     lib.rsx_get_state_full.argtypes = [vp, vp, vp]
     lib.rsx_dev_view_get.argtypes = [vp, C.POINTER(DevView)]
@@ -304,6 +305,12 @@ class Sim:
         buf = C.create_string_buffer(64)
         _chk(self._lib.rsx_task_layout(self._h, buf, 64))
         return buf.value.decode()
+
+    def placement_cache_stats(self, stream=None):
+        """(resets served from the placement cache, resets placed inline), or (-1, -1) — rsx_task_placement_cache_stats"""
+        out = (C.c_int64 * 2)()
+        _chk(self._lib.rsx_task_placement_cache_stats(self._h, out, self._stream(stream)))
+        return int(out[0]), int(out[1])
 
     def task_tensors(self):
         t, B = self._tview, self.num_envs

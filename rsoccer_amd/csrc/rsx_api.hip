@@ -68,6 +68,11 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #endif
 // largest batch whose host-format step (rsx_step / rsx_step_state) lets the kernel read the commands from, and mirror the
 // state into, pinned host memory (one launch + one synchronisation; PCIe latency instead of two copy engines' worth of it)
+// largest batch whose single-step launches carry placement-helper workgroups (rsx_kernels.hpp: placement_helper): where a
+// launch is as long as its slowest wave and half of the SIMDs are idle anyway
+#ifndef RSX_PCACHE_MAX_ENVS
+#define RSX_PCACHE_MAX_ENVS 16384
+#endif
 #ifndef RSX_ZERO_COPY_MAX_ENVS
 #define RSX_ZERO_COPY_MAX_ENVS 64
 #endif
@@ -92,6 +97,8 @@ struct rsx_sim {
     uint8_t* d_flags = nullptr;
     unsigned long long* d_metrics = nullptr;
     unsigned long long* d_mslots = nullptr;   // [MSLOTS][RSX_METRICS] partial episode counters (metric_slot)
+    float* d_pcache = nullptr;                // placement cache of the latency-bound batches (rsx_kernels.hpp: placement_helper), or null
+    unsigned long long* d_pcstats = nullptr;  // [2] cache hits / inline placements (RSX_PCACHE_STATS=1)
     unsigned long long* d_check = nullptr;   // rsx_check_finite counter
     std::vector<float> h_f32;
     // host-format path: pinned staging; rsx_step() brings the new state back with its own
@@ -152,6 +159,7 @@ Buffers buffers_of(const rsx_sim* h, const float* actions) {
     Buffers b;
     b.state = h->d_state; b.aux = h->d_aux; b.obs = h->d_obs; b.final_obs = h->d_final_obs;
     b.flags = h->d_flags; b.cmds = h->d_cmds; b.actions = actions; b.metrics = h->d_metrics; b.mslots = h->d_mslots;
+    b.pcache = h->d_pcache; b.pcstats = h->d_pcstats;
 #ifdef RSX_TIMING
     b.dbg = g_dbg;
 #endif
@@ -176,6 +184,9 @@ void pick_variant(rsx_sim* h) {
                                                         (P).num_envs, (P).state_dim, (int)(grid.x >> 3), rand_tick, (P), (b))
 #define RSX_LAUNCH(kernel, P, b, n) hipLaunchKernelGGL((kernel), grid, dim3(64), 0, s, (b).state, (b).aux, (b).actions, (b).flags, \
                                                        (P).num_envs, (P).state_dim, (int)(grid.x >> 3), (n), (P), (b))
+// the same with `extra` helper workgroups behind the tile workgroups (the tile map still sees the tile grid)
+#define RSX_LAUNCH_X(kernel, P, b, n, extra) hipLaunchKernelGGL((kernel), dim3(grid.x + (unsigned)(extra)), dim3(64), 0, s, (b).state, (b).aux, (b).actions, \
+                                                                (b).flags, (P).num_envs, (P).state_dim, (int)(grid.x >> 3), (n), (P), (b))
 
 template <int KIND>
 void launch_sim_k(const rsx_sim* h, const Params& P_, float* state_out, int rand_tick, hipStream_t s,
@@ -236,7 +247,12 @@ void launch_task_m(const rsx_sim* h, const float* actions, int n_steps, hipStrea
         return;
     }
     const dim3 grid = grid_for(h);
-    if (NRS <= 7 && h->NR == NRS && h->L == 8) { RSX_LAUNCH((task_step_kernel<KIND, 8, TASK, (NRS <= 7 ? NRS : 0), MODE>), h->P, b, n_steps); return; }
+    if (NRS <= 7 && h->NR == NRS && h->L == 8) {
+        // single-step launches of a handle with a placement cache: ceil(B / 64) helper workgroups behind the tiles
+        const int helpers = (MODE == MODE_STEP && h->d_pcache) ? (h->P.num_envs + 63) / 64 : 0;
+        RSX_LAUNCH_X((task_step_kernel<KIND, 8, TASK, (NRS <= 7 ? NRS : 0), MODE>), h->P, b, n_steps, helpers);
+        return;
+    }
     if (NRS <= 7 && h->NR == NRS && h->L == 16) { RSX_LAUNCH((task_step_kernel<KIND, 16, TASK, (NRS <= 7 ? NRS : 0), MODE>), h->P, b, n_steps); return; }
     if (TASK == RSX_TASK_SSL_SCRIMMAGE && h->NR == 22 && h->L == 32) {   // 11v11: robot count known at compile time
         if (h->quad && MODE == MODE_STEP) { launch_ssl_quad(h->P, b, s); return; }
@@ -669,7 +685,12 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
     const size_t n_act = align_up(B * h->M.act_dim * sizeof(float));
     const size_t n_met = align_up(RSX_METRICS * sizeof(unsigned long long));
     const size_t n_slots = align_up((size_t)MSLOTS * RSX_METRICS * sizeof(unsigned long long));
-    const size_t total = n_aux + 2 * n_obs + n_flags + n_act + n_met + n_slots;
+    // placement cache: the two rejection-sampled tasks in their fixed-size 8-lane variants at latency-bound batches
+    const bool pc = !std::getenv("RSX_NO_PCACHE") && h->L == 8 && P.num_envs <= RSX_PCACHE_MAX_ENVS && P.n_sub > 0 &&
+                    ((task == RSX_TASK_VSS_V0 && h->NR == 6) || (task == RSX_TASK_SSL_STATIC_DEFENDERS && h->NR == 7));
+    const size_t n_pc = pc ? align_up((size_t)2 * (3 * (P.n_robots + 1) + 1) * B * sizeof(float)) : 0;
+    const size_t n_pcs = pc && std::getenv("RSX_PCACHE_STATS") ? align_up(2 * sizeof(unsigned long long)) : 0;
+    const size_t total = n_aux + 2 * n_obs + n_flags + n_act + n_met + n_slots + n_pc + n_pcs;
     HIP_TRY(hipMalloc((void**)&h->arena_task, total));
     HIP_TRY(hipMemset(h->arena_task, 0, total));
     char* p = h->arena_task;
@@ -679,7 +700,12 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
     h->d_flags = (uint8_t*)p; p += n_flags;
     h->d_actions = (float*)p; p += n_act;
     h->d_metrics = (unsigned long long*)p; p += n_met;
-    h->d_mslots = (unsigned long long*)p;
+    h->d_mslots = (unsigned long long*)p; p += n_slots;
+    if (n_pc) {
+        h->d_pcache = (float*)p; p += n_pc;
+        HIP_TRY(hipMemset(h->d_pcache, 0xFF, n_pc));   // tags 0xFFFFFFFF: no entry is valid yet
+    }
+    if (n_pcs) h->d_pcstats = (unsigned long long*)p;
     // episode ids start at 0xFFFFFFFF so that the first reset() opens episode 0
     HIP_TRY(hipMemset(h->d_aux + (size_t)ROW_EPISODE * B, 0xFF, B * sizeof(uint32_t)));
     h->P = P;
@@ -713,6 +739,16 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
     }
     h->task_ready = false;
     HIP_TRY(hipDeviceSynchronize());   // null-stream memsets done before any caller stream steps
+    return RSX_OK;
+}
+
+int rsx_task_placement_cache_stats(rsx_sim* h, int64_t out[2], void* stream) {
+    RSX_ENTER_TASK(h);
+    if (!out) return fail(RSX_ERR_ARG, "out is null");
+    out[0] = out[1] = -1;   // -1: no cache on this handle, or the counters are off (RSX_PCACHE_STATS=1 before rsx_task_attach)
+    if (!h->d_pcstats) return RSX_OK;
+    HIP_TRY(hipMemcpyAsync(out, h->d_pcstats, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return RSX_OK;
 }
 

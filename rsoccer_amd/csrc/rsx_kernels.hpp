@@ -62,6 +62,8 @@ struct Buffers {
     const float* actions;  // [B][act_dim] or nullptr = random
     unsigned long long* metrics;  // [RSX_METRICS]
     unsigned long long* mslots;   // [MSLOTS][RSX_METRICS]: per-block-group partial sums of the episode counters (see metric_slot)
+    float* pcache;                // placement cache (see placement_helper): [2][3 * (N + 1) + 1][B], or nullptr
+    unsigned long long* pcstats;  // [2] resets served from the cache / placed inline (nullptr unless RSX_PCACHE_STATS=1)
 #ifdef RSX_TIMING
     unsigned long long* dbg;      // [8][gridDim] s_memtime stamps (development builds only)
 #endif
@@ -92,6 +94,7 @@ struct Shared {
     float x0[64 / L][12];      // robot 0 -> reward lane exchange
     float stage[RSX_DIRECT_OBS_STAGE(L)];  // obs staging, [env][obs_dim], obs_dim <= 64 (only without RSX_DIRECT_OBS)
     float2 draws[64 / L][L < 16 ? 16 : L];  // placement: speculative Philox draws of an ended env
+    uint32_t ep[64];           // placement helper: the episode ids of the wave's 64 envs
 #ifdef RSX_TIMING
     unsigned long long* dbg;   // development builds: where the sub-step stamps go (nullptr = none)
 #endif
@@ -1187,6 +1190,71 @@ __device__ __forceinline__ StepDraw draw_for_step(const Params& P, const uint32_
     return d;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Placement cache (single-step launches of the rejection-sampled tasks at latency-bound batch sizes).
+//
+// A single-step launch lasts as long as its slowest wave, and with short episodes that wave is one that resets an
+// env: Philox blocks + rejection rounds are ~2.7 k cycles on top of a ~17 k cycle wave (1v6 at 2048 envs: 5.5 waves
+// per launch hold a reset).  But the placement of an env's NEXT episode is a pure function of (seed, global env id,
+// episode + 1): it can be computed at any time before it is needed, by anybody.  At these batches half of the chip's
+// SIMDs are idle, so every step launch carries ceil(B / 64) extra HELPER workgroups behind the tile workgroups: helper
+// w looks at envs [64 w, 64 w + 64) and, where the cached pose set is not the one of episode + 1, computes it with the
+// same code the reset path runs (place_predraw + place_env_parallel: same draws, same tests, same poses) — eight envs
+// at a time, far shorter than a step, never the slowest wave.  The resetting wave then only copies three floats per
+// body that it loaded with its state.
+//
+// Two buffers, alternating by step parity: launch t writes buffer (t & 1) and reads buffer ((t + 1) & 1), which
+// nobody writes during launch t — the only synchronisation is the kernel boundary.  An entry is tagged with the episode
+// id it was made for; a tag that does not match (first steps after a reset, two episode ends in consecutive steps, a
+// restored checkpoint) sends the env down the inline path, which stays as it was.  Layouts that do not use the cache
+// ignore it: it is derived data, not state (not part of a checkpoint).
+// Buffer: rows c * (N + 1) + b for c = x, y, theta and body b (ball = N), then the tag row; [rows][B] floats.
+// ---------------------------------------------------------------------------------------------
+template <int NB>
+__host__ __device__ constexpr int pcache_rows() { return 3 * NB + 1; }
+
+template <int KIND, int L, int TASK, int NR>
+__device__ __forceinline__ void placement_helper(const Params& P, const Buffers& bufs, const int helper, Shared<L>& sh) {
+    static_assert(L == 8 && NR > 0, "the placement cache serves the 8-lane kernels of the fixed team sizes");
+    constexpr int G = 64 / L, N = NR, NBD = N + 1;
+    const size_t B = (size_t)P.num_envs;
+    const int lane = threadIdx.x;
+    const int b = lane / G, g = lane % G;
+    float* const pw = bufs.pcache + (size_t)(P.tick_base & 1u) * (size_t)pcache_rows<NBD>() * B;
+    // one lane per env: which of this wave's 64 envs lack the poses of their next episode?
+    const int e0 = helper * 64 + lane;
+    uint32_t ep_next = 0;
+    bool stale = false;
+    if (e0 < P.num_envs) {
+        ep_next = __float_as_uint(bufs.aux[(size_t)ROW_EPISODE * B + e0]) + 1u;
+        stale = __float_as_uint(pw[(size_t)(3 * NBD) * B + e0]) != ep_next;
+    }
+    unsigned long long todo = __ballot(stale);
+    if (todo == 0) return;
+    sh.ep[lane] = ep_next;
+    wave_sync();
+    while (todo) {   // eight envs per round: env slot g takes the g-th stale env
+        unsigned long long mine = todo;
+        for (int i = 0; i < g; ++i) mine &= mine - 1;
+        const bool has = mine != 0;
+        const int idx = has ? (int)__builtin_ctzll(mine) : 0;
+        for (int i = 0; i < G && todo; ++i) todo &= todo - 1;
+        const int e = helper * 64 + idx;
+        const uint32_t env_id = P.env_id_base + (uint32_t)e;
+        const uint32_t episode = sh.ep[idx];
+        const bool is_robot = has && b < N, is_ball = has && b == N;
+        if (has) place_predraw<TASK, L>(P, env_id, episode, b, sh.draws[g]);
+        wave_sync();
+        float4 pz = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (has) pz = place_env_parallel<TASK, L, NR>(P, N, env_id, episode, b, g, is_robot, sh.A, sh.draws[g]);
+        if (is_robot || is_ball) {
+            pw[(size_t)(0 * NBD + b) * B + e] = pz.x; pw[(size_t)(1 * NBD + b) * B + e] = pz.y; pw[(size_t)(2 * NBD + b) * B + e] = pz.z;
+        }
+        if (is_ball) pw[(size_t)(3 * NBD) * B + e] = __uint_as_float(episode);
+        wave_sync();   // draws / A are rewritten by the next round
+    }
+}
+
 // MODE (compile-time, so the per-step launch carries no loop and none of the reset-only code):
 //   MODE_STEP    one step(action) per launch
 //   MODE_ROLLOUT n_steps random-action steps per launch (state stays in registers)
@@ -1219,6 +1287,14 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
     constexpr int ID = T::info_dim;
     constexpr int AD = T::act_dim;
     __shared__ Shared<L> sh;
+    // placement cache: single-step launches of the two rejection-sampled tasks in their fixed-size 8-lane variants
+    constexpr bool PC = MODE == MODE_STEP && L == 8 && ((TASK == RSX_TASK_VSS_V0 && NR == 6) || (TASK == RSX_TASK_SSL_STATIC_DEFENDERS && NR == 7));
+    if constexpr (PC) {
+        if (__builtin_expect(bufs.pcache != nullptr && (int)blockIdx.x >= hp_per_xcd * 8, 0)) {   // a helper workgroup (behind the tiles)
+            placement_helper<KIND, L, TASK, (PC ? NR : 1)>(P, bufs, (int)blockIdx.x - hp_per_xcd * 8, sh);
+            return;
+        }
+    }
     const int lane = threadIdx.x;
     const int b = lane / G, g = lane % G;
     const int tile = tile_of_block(HOT ? hp_per_xcd : (int)(gridDim.x >> 3));
@@ -1291,6 +1367,20 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
     } else if (fed && is_robot && b == 0) {
 #pragma unroll
         for (int i = 0; i < AD; ++i) act[i] = bufs.actions[(size_t)e * AD + i];
+    }
+
+    // placement cache: this body's pose in the env's next episode and the episode id it was made for, loaded with the state
+    float pcx = 0.0f, pcy = 0.0f, pcth = 0.0f;
+    uint32_t ptag = 0u;
+    bool pc_on = false;
+    if constexpr (PC) {
+        pc_on = bufs.pcache != nullptr;
+        if (pc_on && (is_robot || is_ball)) {
+            constexpr int NBD = (PC ? NR : 1) + 1;
+            const float* const pr = bufs.pcache + (size_t)((P.tick_base + 1u) & 1u) * (size_t)pcache_rows<NBD>() * B;
+            pcx = pr[(size_t)(0 * NBD + b) * B + e]; pcy = pr[(size_t)(1 * NBD + b) * B + e]; pcth = pr[(size_t)(2 * NBD + b) * B + e];
+            ptag = __float_as_uint(pr[(size_t)(3 * NBD) * B + e]);
+        }
     }
 
     // single-step launches: this step's random numbers, computed in the shadow of the loads
@@ -1478,8 +1568,14 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
                 }
             }
             RSX_STAMP(15);
-            if (ended) place_predraw<TASK, L>(P, env_id, episode, b, sh.draws[g]);
-            wave_sync();  // draws published; stage rows of ended envs are about to be overwritten
+            // an env whose next episode's poses were in the cache takes them from there; the others are placed here
+            const bool hit = PC && pc_on && ended && ptag == episode;
+            const bool place = ended && !hit;
+            const bool any_place = !PC || __any(place);
+            if (any_place) {
+                if (place) place_predraw<TASK, L>(P, env_id, episode, b, sh.draws[g]);
+                wave_sync();  // draws published; stage rows of ended envs are about to be overwritten
+            }
             RSX_STAMP(16);
             float4 pz = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             // A single-step launch waits for its slowest wave, which is one that resets an env:
@@ -1495,7 +1591,9 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
                                           P.sc_sy * ((float)(b / 6) - 1.5f) + P.sc_j * jy, 360.0f * u01(u.z), 0.0f);
                 }
             } else if ((TASK == RSX_TASK_VSS_V0 || TASK == RSX_TASK_SSL_STATIC_DEFENDERS) && MODE != MODE_ROLLOUT) {
-                if (ended) pz = place_env_parallel<TASK, L, NR>(P, N, env_id, episode, b, g, is_robot, sh.A, sh.draws[g]);
+                if (any_place && place) pz = place_env_parallel<TASK, L, NR>(P, N, env_id, episode, b, g, is_robot, sh.A, sh.draws[g]);
+                if (hit) pz = make_float4(pcx, pcy, pcth, 0.0f);
+                if (PC && pc_on && bufs.pcstats && ended && is_ball) atomicAdd(&bufs.pcstats[hit ? 0 : 1], 1ull);
             } else {
                 if (ended && is_ball) place_env<TASK, L>(P, N, env_id, episode, g, sh.A, sh.draws[g]);
                 wave_sync();

@@ -807,6 +807,46 @@ def test_api_errors_are_reported_not_crashed():
     sim.close()
 
 
+@pytest.mark.parametrize("task,kind,ft,nb,ny,max_steps", [(1, 0, 0, 3, 3, 9), (2, 1, 2, 1, 6, 6), (1, 0, 0, 3, 3, 1)])
+def test_placement_cache_serves_resets_bit_identically(oracle_mod, monkeypatch, task, kind, ft, nb, ny, max_steps):
+    """Latency-bound batches: helper workgroups of every step launch compute each env's next placement ahead of time
+    (rsx_kernels.hpp: placement_helper) and the resetting wave copies it.  Same poses as the inline placement — the run
+    equals the oracle's bit for bit — and the cache really is what served them (counters); an episode length of one
+    step (a reset in every launch: the entry is never ready in time) falls back to the inline path, also bit-exact."""
+    import torch
+    L = _lib()
+    monkeypatch.setenv("RSX_PCACHE_STATS", "1")
+    B, seed, base, steps = 37, 77, 4000, 64
+    sim = L.Sim(kind, ft, nb, ny, 25, B)
+    sim.task_attach(task, seed, base, max_steps)
+    assert sim.placement_cache_stats() == (0, 0)
+    tens = sim.task_tensors()
+    refs = _mk_oracles(oracle_mod, kind, ft, nb, ny, B)
+    for e, r in enumerate(refs):
+        r.task_attach(task, seed, base + e, max_steps)
+        r.task_reset()
+    sim.task_reset()
+    for t in range(steps):
+        sim.task_step(None)
+        for r in refs:
+            r.task_step(None)
+        if t % 7 == 6 or t == steps - 1:
+            _cmp_task(sim, refs, tens, t)
+    hits, inline = sim.placement_cache_stats()
+    episodes = int(sim.read_metrics()[1])
+    assert hits + inline == episodes and episodes >= B * (steps // max_steps) // 2
+    if max_steps == 1:
+        assert inline > 0                      # a reset in every launch: (nearly) every placement is computed in place
+    else:
+        assert hits >= 0.9 * episodes          # after the first two launches every reset finds its poses ready
+    sim.close()
+    monkeypatch.setenv("RSX_NO_PCACHE", "1")
+    off = L.Sim(kind, ft, nb, ny, 25, B)
+    off.task_attach(task, seed, base, max_steps)
+    assert off.placement_cache_stats() == (-1, -1)
+    off.close()
+
+
 def test_api_calls_leave_the_current_device_alone():
     """No C-ABI call may change the thread's current HIP device (= torch's current device), also not
     the destructor run by the garbage collector.  With a single device this pins the common case;
