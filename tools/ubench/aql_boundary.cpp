@@ -212,6 +212,21 @@ int main(int argc, char** argv) {
         Args a{p, bad, B, 0};
         size_t asz = sizeof(a);
         void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+        if (getenv("DUMP_PENDING")) {   // the HIP runtime's packets BEFORE the packet processor consumes (and invalidates) them
+            for (int k = 0; k < 200; ++k) HK(hipModuleLaunchKernel(fn, 512, 1, 1, 64, 1, 1, 0, s, nullptr, cfg));
+            for (int i = 0; i < g_nseen; ++i) {
+                hsa_queue_t* hq = g_seen[i];
+                const uint64_t w = hsa_queue_load_write_index_relaxed(hq), r = hsa_queue_load_read_index_relaxed(hq);
+                fprintf(stderr, "[queue %p: read index %lu, write index %lu]\n", (void*)hq, (unsigned long)r, (unsigned long)w);
+                for (uint64_t k = (w > 4 ? w - 4 : 0); k < w; ++k) {
+                    const uint32_t* d = (const uint32_t*)((const char*)hq->base_address + 64 * (k & (hq->size - 1)));
+                    fprintf(stderr, "  #%lu%s:", (unsigned long)k, k >= r ? " (pending)" : "");
+                    for (int j = 0; j < 16; ++j) fprintf(stderr, " %08x", d[j]);
+                    fprintf(stderr, "\n");
+                }
+            }
+            HK(hipStreamSynchronize(s));
+        }
         for (int rep = 0; rep < 2; ++rep) {
             HK(hipStreamSynchronize(s));
             auto t0 = std::chrono::steady_clock::now();
@@ -221,6 +236,13 @@ int main(int argc, char** argv) {
             if (rep) printf("%-58s %7.3f us per launch\n", "hipModuleLaunchKernel, one stream", us);
         }
     }
+    auto xcc_log = [&](const char* who) {
+        unsigned w[68];
+        HK(hipMemcpy(w, bad + 1100, sizeof(w), hipMemcpyDeviceToHost));
+        printf("  XCC of block 0 in the last launches (%s, ring of 64, %u launches so far):", who, w[0]);
+        for (int i = 0; i < 24; ++i) printf(" %u", w[4 + ((w[0] - 24 + i) & 63u)]);
+        printf("\n");
+    };
     auto placement = [&](const char* who) {   // HW_ID: wave [3:0] simd [5:4] pipe [7:6] cu [11:8] sh [12] se [15:13]
         std::vector<unsigned> w(2 * 512 + 32);
         HK(hipMemcpy(w.data(), bad, w.size() * 4, hipMemcpyDeviceToHost));
@@ -240,6 +262,7 @@ int main(int argc, char** argv) {
         printf("\n");
     };
     placement("last HIP launch");
+    xcc_log("HIP launches");
     if (getenv("USE_HIP_KOBJ")) {   // dispatch the copy of the kernel the HIP runtime loaded: its kernel object is in the packets it wrote
         for (int i = 0; i < g_nseen; ++i) {
             hsa_queue_t* hq = g_seen[i];
@@ -268,15 +291,34 @@ int main(int argc, char** argv) {
         }
     }
     const int A = HSA_FENCE_SCOPE_AGENT, S = HSA_FENCE_SCOPE_SYSTEM, N = HSA_FENCE_SCOPE_NONE;
+    if (getenv("LATE_QUEUE")) {   // a queue made AFTER the HIP runtime has created its stream's queue and run kernels
+        CK(hsa_queue_create(g_gpu, 4096, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &q));
+        printf("the packets below go to a queue created after the HIP launches: %p\n", (void*)q);
+    }
+    if (getenv("MANY_QUEUES")) {   // is the cost of a barrier a property of the QUEUE (which hardware pipe / slot it got)?
+        hsa_queue_t* q0 = q;
+        for (int i = 0; i < atoi(getenv("MANY_QUEUES")); ++i) {
+            hsa_queue_t* qi;
+            CK(hsa_queue_create(g_gpu, 4096, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &qi));
+            q = qi;
+            char name[96];
+            snprintf(name, sizeof name, "queue #%d (%p) barrier=1 agent/agent", i, (void*)qi);
+            run(name, hdr(1, A, A), 0);
+            xcc_log(name);
+        }
+        q = q0;
+    }
     run("AQL barrier=1 acquire=system release=system", hdr(1, S, S), 0);
     run("AQL barrier=1 acquire=agent  release=agent", hdr(1, A, A), 0);
     placement("last AQL launch");
+    xcc_log("AQL barrier=1 agent/agent");
     run("AQL barrier=1 acquire=agent  release=none", hdr(1, A, N), 0);
     run("AQL barrier=1 acquire=none   release=agent", hdr(1, N, A), 0);
     run("AQL barrier=1 acquire=none   release=none", hdr(1, N, N), 0);
     run("AQL barrier=1 acquire=none   release=none, nt loads", hdr(1, N, N), 1);
     run("AQL barrier=0 acquire=none   release=none (may overlap)", hdr(0, N, N), 0);
     run("AQL barrier=0 acquire=agent  release=agent (may overlap)", hdr(0, A, A), 0);
+    xcc_log("AQL barrier=0");
     unsigned nbad = 0;
     HK(hipMemcpy(&nbad, bad, 4, hipMemcpyDeviceToHost));
     float first = 0;

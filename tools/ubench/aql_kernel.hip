@@ -14,6 +14,7 @@ extern "C" __global__ __launch_bounds__(64) void rows_chain(float* p, unsigned* 
     unsigned hwid;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
     if (threadIdx.x == 0) { xcc_bad[32 + 2 * blockIdx.x] = hwid; xcc_bad[33 + 2 * blockIdx.x] = xcc; }   // where this wave ran
+    if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned n = atomicAdd(&xcc_bad[1100], 1u); xcc_bad[1104 + (n & 63u)] = xcc & 15u; }   // block 0's XCC, launch by launch
     float v[6];
     if (sc1_loads) {
 #pragma unroll
