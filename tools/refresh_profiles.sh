@@ -22,6 +22,8 @@ cat $OUT/hbm_traffic.json | head -12
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d $OUT/sq -- python tools/prof_target.py 4096 rollout 200 > $OUT/sq.log 2>&1
 python tools/rocpd_summary.py $(find $OUT/sq -name "*.db" | head -1) > $OUT/sq_counters_rollout200.txt 2>&1
 grep "task_step_kernel<0, 8, 1, 6, 3>" $OUT/sq_counters_rollout200.txt | head -12
+# counter traffic of every large-batch leg (bench.py reads profiles/rNN_leg_traffic.json)
+tools/prof_leg_traffic.sh $OUT > $OUT/leg_traffic.log 2>&1
 python tools/bench_configs.py $OUT/configs_and_sweep.md > $OUT/configs.log 2>&1
 cat $OUT/configs_and_sweep.md
 # the driver's own flags
