@@ -211,7 +211,7 @@ int rsx_task_view_get(rsx_sim* h, rsx_task_view* out);
  * "four-lanes-per-env".  NUL-terminated into out[n] — for profiles and benchmark lines, so that nothing outside the
  * library restates its thresholds. */
 int rsx_task_layout(rsx_sim* h, char* out, size_t n);
-/* Introspection of the placement cache (handles of VSS_V0 3v3 / STATIC_DEFENDERS 1v6 with at most 16 384 envs: every
+/* Introspection of the placement cache (handles of STATIC_DEFENDERS 1v6 with at most 16 384 envs: every
  * single-step launch carries helper workgroups that compute each env's NEXT episode's random placement ahead of time —
  * a pure function of seed, global env id and episode — so that the wave that resets an env only copies it; results are
  * those of the inline placement, bit for bit).  out[0] = resets served from the cache, out[1] = placed inline; both -1

@@ -685,9 +685,9 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
     const size_t n_act = align_up(B * h->M.act_dim * sizeof(float));
     const size_t n_met = align_up(RSX_METRICS * sizeof(unsigned long long));
     const size_t n_slots = align_up((size_t)MSLOTS * RSX_METRICS * sizeof(unsigned long long));
-    // placement cache: the two rejection-sampled tasks in their fixed-size 8-lane variants at latency-bound batches
+    // placement cache: static defenders 1v6 (short episodes: several resetting waves per launch) at latency-bound batches
     const bool pc = !std::getenv("RSX_NO_PCACHE") && h->L == 8 && P.num_envs <= RSX_PCACHE_MAX_ENVS && P.n_sub > 0 &&
-                    ((task == RSX_TASK_VSS_V0 && h->NR == 6) || (task == RSX_TASK_SSL_STATIC_DEFENDERS && h->NR == 7));
+                    task == RSX_TASK_SSL_STATIC_DEFENDERS && h->NR == 7;
     const size_t n_pc = pc ? align_up((size_t)2 * (3 * (P.n_robots + 1) + 1) * B * sizeof(float)) : 0;
     const size_t n_pcs = pc && std::getenv("RSX_PCACHE_STATS") ? align_up(2 * sizeof(unsigned long long)) : 0;
     const size_t total = n_aux + 2 * n_obs + n_flags + n_act + n_met + n_slots + n_pc + n_pcs;

@@ -807,7 +807,7 @@ def test_api_errors_are_reported_not_crashed():
     sim.close()
 
 
-@pytest.mark.parametrize("task,kind,ft,nb,ny,max_steps", [(1, 0, 0, 3, 3, 9), (2, 1, 2, 1, 6, 6), (1, 0, 0, 3, 3, 1)])
+@pytest.mark.parametrize("task,kind,ft,nb,ny,max_steps", [(2, 1, 2, 1, 6, 9), (2, 1, 2, 1, 6, 6), (2, 1, 2, 1, 6, 1)])
 def test_placement_cache_serves_resets_bit_identically(oracle_mod, monkeypatch, task, kind, ft, nb, ny, max_steps):
     """Latency-bound batches: helper workgroups of every step launch compute each env's next placement ahead of time
     (rsx_kernels.hpp: placement_helper) and the resetting wave copies it.  Same poses as the inline placement — the run
