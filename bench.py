@@ -248,7 +248,7 @@ def dry_run(args, rank, world):
         line = {"metric": METRIC, "dry_run": True, "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "env_steps_counted": int(m[0]), "env_id_bases_sum": int(m[7])}
         if coll:
-            line["collective"] = {"backend": coll.describe(), "ranks": world, "rccl_ranks": coll.rccl_ranks}
+            line["collective"] = {"backend": coll.describe(), "degraded": coll.reason is not None, "ranks": world, "rccl_ranks": coll.rccl_ranks}
         print(json.dumps(line), flush=True)
     if coll:
         coll.close()
@@ -449,6 +449,7 @@ def main():
                 line["roofline"]["notional"] = True
         if distributed:
             line["collective"] = {"backend": "gloo (shared device, test mode)" if share else coll.describe(),
+                                  "degraded": bool(coll.reason is not None and not share),   # RCCL was wanted and is not carrying the metrics
                                   "ranks": world, "rccl_ranks": coll.rccl_ranks, "devices": tags,
                                   "payload_bytes": 8 * L.N_METRICS, "every_steps": ALLREDUCE_EVERY,
                                   "allreduces_in_timed_region": (W + K) // ALLREDUCE_EVERY - W // ALLREDUCE_EVERY,
