@@ -78,6 +78,9 @@ struct Buffers {
 #ifndef RSX_PK_SWEEP
 #define RSX_PK_SWEEP 1
 #endif
+#ifndef RSX_ZB_BALLOT
+#define RSX_ZB_BALLOT 1
+#endif
 #define RSX_DIRECT_OBS_STAGE(L) (RSX_DIRECT_OBS ? 1 : (64 / (L)) * 64)
 
 template <int L>
@@ -399,10 +402,17 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
         // over the corrected snapshot for the envs in which some pair overlapped by more than pen2
         // (impacts at speed, jammed piles; resting contacts stay far below).  The second sweep is
         // the same loop body again: the instructions are in the cache (a separate copy never is) ----
+#if RSX_ZB_BALLOT
+        // is the env's ball low enough to be touched?  One ballot of the ball lanes' answer, each lane picks its env's bit
+        // (was: the height through LDS — a write, a dependent read and its wait in every sub-step)
+        const unsigned long long lowm = __ballot(is_ball && o.z < K::robot_h);
+        bool ball_low = ((lowm >> (N * G + g)) & 1ull) != 0;
+#else
         if (is_ball) sh.zb[g] = o.z;
+        bool ball_low = true;
+#endif
         bool active = is_robot || is_ball;   // lanes whose env takes part in the current sweep
         BallOverride bo{false, false, 0.0f, 0.0f, 0.0f};
-        bool ball_low = true;
         for (int sweep = 0;; ++sweep) {
             if (active) {
                 sh.A[lane] = make_float4(o.x, o.y, o.vx, o.vy);
@@ -412,7 +422,9 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
 #endif
             }
             wave_sync();
+#if !RSX_ZB_BALLOT
             if (sweep == 0) ball_low = sh.zb[g] < K::robot_h;
+#endif
             bool deep = false;   // this lane saw a deep contact
 
             if (KIND == RSX_KIND_VSS) {
