@@ -544,7 +544,7 @@ def other_configs(L, torch, dev, timed):
              ("configs[3] SSL 11v11 division-A, scrimmage task, crowded line-up (worst-case contacts)", 1, 1, 11, 11,
               L.TASK_SSL_SCRIMMAGE_CROWDED, 1024, SC, 1000, 100),
              ("SSL 11v11 scrimmage, spread, 65 536 envs (four lanes per env from 32 768 envs)", 1, 1, 11, 11, L.TASK_SSL_SCRIMMAGE, 65536, SC, 60, 20),
-             ("SSL 11v11 scrimmage, crowded, 65 536 envs (32 lanes per env, large-batch build)", 1, 1, 11, 11, L.TASK_SSL_SCRIMMAGE_CROWDED, 65536, SC, 60, 20),
+             ("SSL 11v11 scrimmage, crowded, 65 536 envs (four lanes per env from 65 536 envs)", 1, 1, 11, 11, L.TASK_SSL_SCRIMMAGE_CROWDED, 65536, SC, 60, 20),
              ("SSL 11v11 scrimmage, spread, 262 144 envs (four lanes per env)", 1, 1, 11, 11, L.TASK_SSL_SCRIMMAGE, 262144, SC, 30, 10),
              ("SSL 11v11 scrimmage, crowded, 262 144 envs (four lanes per env)", 1, 1, 11, 11, L.TASK_SSL_SCRIMMAGE_CROWDED, 262144, SC, 30, 10))
     LEG = {L.TASK_SSL_STATIC_DEFENDERS: "sd", L.TASK_SSL_DRIBBLING: "drib", L.TASK_SSL_CONTESTED: "cont",

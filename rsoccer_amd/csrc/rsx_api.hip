@@ -57,11 +57,14 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define RSX_QUAD_MIN_ENVS 32768
 #endif
 #ifndef RSX_QUAD_MIN_ENVS_CROWDED
-#define RSX_QUAD_MIN_ENVS_CROWDED 131072
+#define RSX_QUAD_MIN_ENVS_CROWDED 65536
 #endif
 // from this batch on a multi-step call (rsx_task_rollout) on a four-lane handle is issued as single-step launches
 #ifndef RSX_QUAD_ROLLOUT_MIN_ENVS
 #define RSX_QUAD_ROLLOUT_MIN_ENVS 98304
+#endif
+#ifndef RSX_QUAD_ROLLOUT_MIN_ENVS_CROWDED
+#define RSX_QUAD_ROLLOUT_MIN_ENVS_CROWDED 196608
 #endif
 #ifndef RSX_EPL_MIN_ENVS_SSL
 #define RSX_EPL_MIN_ENVS_SSL 65536
@@ -720,9 +723,9 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
         const char* lay = std::getenv("RSX_LAYOUT");
         const size_t rows = (size_t)std::max(P.state_dim + X_ROWS, aux_rows(P.n_robots));
         const bool fits = rows * (size_t)P.num_envs * sizeof(float) < ((size_t)1 << 31) && P.n_sub > 0 && P.n_blue == 11;
-        // measured crossovers: the spread line-up from 32 768 envs, the crowded one (contacts in every
-        // sub-step: the six robots of a lane are walked one after the other) only from 131 072 (RSX_QUAD_MIN_ENVS_CROWDED);
-        // multi-step calls on a crowded handle stay with the 32-lane kernel (rsx_task_rollout)
+        // measured crossovers (profiles/LABBOOK.md): the spread line-up from 32 768 envs, the crowded one (contacts in every
+        // sub-step: the six robots of a lane are walked one after the other) from 65 536 (RSX_QUAD_MIN_ENVS_CROWDED);
+        // multi-step calls on a crowded handle stay with the 32-lane kernel below 262 144 envs (rsx_task_rollout)
         const int quad_min = task == RSX_TASK_SSL_SCRIMMAGE ? RSX_QUAD_MIN_ENVS : RSX_QUAD_MIN_ENVS_CROWDED;
         h->quad = fits && (lay ? std::strcmp(lay, "quad") == 0 : (quad_min > 0 && P.num_envs >= quad_min));
     }
@@ -830,9 +833,9 @@ int rsx_task_rollout(rsx_sim* h, int n, void* stream) {
     RSX_NEED_RESET(h);
     if (n < 0) return fail(RSX_ERR_ARG, "n must be >= 0");  // 0 = load + store only (profiling)
     RSX_NEED_TICKS(h, n);
-    if (h->quad && n >= 1 && h->P.task == RSX_TASK_SSL_SCRIMMAGE && h->P.num_envs >= RSX_QUAD_ROLLOUT_MIN_ENVS) {
-        // 11v11 (spread line-up) at large batches: n launches of the four-lanes-per-env kernel beat one launch of the
-        // 32-lane kernel (262 144 envs: 200 vs 282 us per step; crowded: 367 vs 347, left alone); same steps, same results
+    if (h->quad && n >= 1 && h->P.num_envs >= (h->P.task == RSX_TASK_SSL_SCRIMMAGE ? RSX_QUAD_ROLLOUT_MIN_ENVS : RSX_QUAD_ROLLOUT_MIN_ENVS_CROWDED)) {
+        // 11v11 at large batches: n launches of the four-lanes-per-env kernel beat one launch of the 32-lane kernel
+        // (262 144 envs, us per step: spread 182 vs 275, crowded 298 vs 340; crowded 131 072: 161 vs 164); same steps, same results
         for (int i = 0; i < n; ++i) { h->P.tick_base = h->tick++; launch_task(h, nullptr, 1, MODE_STEP, (hipStream_t)stream); }
         HIP_TRY(hipGetLastError());
         return debug_finite(h, (hipStream_t)stream, "rsx_task_rollout");

@@ -83,3 +83,12 @@ void launch_ssl_epl(int task, bool rollout, const Params& P, const Buffers& b, i
 }
 
 }  // namespace rsx
+
+#ifdef RSX_QSTATS
+extern "C" __attribute__((visibility("default"))) int rsx_debug_qstats(unsigned long long* out, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(rsx::rsx_qstats), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rsx::rsx_qstats), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif

@@ -158,7 +158,7 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
 #pragma unroll
             for (int i = 0; i < AD; ++i) a[i] = fed ? act[i] : dr.v[i];
             float q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            ssl_agent_commands<TASK>(a, r[0].th, q);
+            ssl_agent_commands<TASK>(a, r[0].s, r[0].c, q);
             robot_targets<KIND>(P, r[0], q);
 #pragma unroll
             for (int k = 1; k < N; ++k) {

@@ -819,9 +819,11 @@ __device__ __forceinline__ float vss_wheel(float a) {
 }
 
 // Action of the agent (blue 0) of an SSL task -> its robot command q (robosim order: wheel speeds flag,
-// v_x, v_y, v_theta, kick_x, kick_z is q[5]..., dribbler q[7]); od = the robot's heading in degrees.
+// v_x, v_y, v_theta, kick_x, kick_z is q[5]..., dribbler q[7]); (sn, cs) = sine and cosine of the robot's heading: the
+// body's own (s, c), which every step start and end derive from the stored heading in degrees by sincos_f32 — the
+// reference evaluates sin / cos of that same float (static_defenders.py:128-131).
 template <int TASK>
-__device__ __forceinline__ void ssl_agent_commands(const float* a, float od, float* q) {
+__device__ __forceinline__ void ssl_agent_commands(const float* a, const float sn, const float cs, float* q) {
     using K = KC<RSX_KIND_SSL>;
     using T = TC<TASK>;
     if (TASK == RSX_TASK_SSL_PASS_ENDURANCE) {  // pass_endurance.py:106-130
@@ -830,8 +832,6 @@ __device__ __forceinline__ void ssl_agent_commands(const float* a, float od, flo
         q[5] = k * 5.0f;
         q[7] = a[2] > 0.0f ? 1.0f : 0.0f;
     } else {  // static_defenders.py:114-148, dribbling.py:106-135, contested_possession.py:106-137
-        float sn, cs;
-        sincos_f32(od * K::deg2rad, sn, cs);
         float gx = a[0] * T::max_v, gy = a[1] * T::max_v, vth = a[2] * 10.0f;
         float lx = gx * cs + gy * sn, ly = gy * cs - gx * sn;
         float nrm = sqrtf(lx * lx + ly * ly);
@@ -1475,7 +1475,7 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
                     float a[5] = {0, 0, 0, 0, 0};
 #pragma unroll
                     for (int i = 0; i < AD; ++i) a[i] = fed ? act[i] : dr.v[i];
-                    ssl_agent_commands<TASK>(a, od, q);
+                    ssl_agent_commands<TASK>(a, o.s, o.c, q);
                 }
                 if (TASK == RSX_TASK_SSL_PASS_ENDURANCE && is_robot && b == 1) q[7] = 1.0f;  // receiver: dribbler on
             }

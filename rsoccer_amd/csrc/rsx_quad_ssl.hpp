@@ -7,8 +7,9 @@
 // 6p .. 6p+5 in registers (lane 3: robots 18..21, its last two slots are ghosts at NaN positions that can touch
 // nothing, and the ball).  What it buys over 32 lanes per env (one body per lane, 9 lanes idle, every pair tested
 // from both sides through LDS): all lanes busy with robots, the per-step work (Philox block, targets, wheel speeds,
-// eleven row stores per robot) issued once for sixteen envs instead of two, pair tests on registers — the other
-// lanes' positions are DPP quad_perm operands of the subtraction, no LDS on the path without contacts.  What it costs:
+// eleven row stores per robot) issued once for sixteen envs instead of two, every robot pair of an env tested ONCE and on
+// registers — the other lanes' positions are DPP quad_perm reads, the result is one bit per pair that both robots' lanes
+// get (no LDS on the path without contacts).  What it costs:
 // a lane walks six robots one after the other, so it needs enough envs to fill the chip (the host picks it from
 // RSX_QUAD_MIN_ENVS on).  Results are bit-identical: per-body formulas are rsx_body.hpp's, every body sums its
 // partners in index order (robots, then the ball), the ball sums the robots' records in robot order, draws use the same
@@ -19,11 +20,25 @@
 #ifndef RSX_QUAD_WAVES
 #define RSX_QUAD_WAVES 3   // waves per SIMD the kernel is compiled for
 #endif
-#ifndef RSX_QUAD_HOT_SLOTS
-#define RSX_QUAD_HOT_SLOTS 5   // of 6 robot slots with a partner somewhere in the wave: skip the screening pass in the next sub-step (7 = never)
-#endif
 
 namespace rsx {
+
+#ifdef RSX_QSTATS   // development: what the contact path of a launch did (tools/exp_quad_stats.py)
+__device__ unsigned long long rsx_qstats[16];
+#define RSX_QS(I, V) do { if (lane == 0) atomicAdd(&rsx_qstats[I], (unsigned long long)(V)); } while (0)
+__device__ __forceinline__ unsigned qs_wave_max(unsigned v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o));
+    return v;
+}
+__device__ __forceinline__ unsigned qs_wave_sum(unsigned v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = v + (unsigned)__shfl_xor((int)v, o);
+    return v;
+}
+#else
+#define RSX_QS(I, V) do {} while (0)
+#endif
 
 constexpr int Q_N = 22;        // robots
 constexpr int Q_R = 6;         // robot slots per lane
@@ -158,7 +173,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
 
     // ---- physics ----
     ball_step_friction(P, ball);
-    bool hot = false;      // wave-uniform: the previous sub-step found (nearly) every robot slot in contact somewhere in the wave
     unsigned irbits = 0;   // infrared flags of this lane's robots (bit m), refreshed by the first sweep of every sub-step
     for (int sub = 0; sub < P.n_sub; ++sub) {
         // A: actuation + integration
@@ -166,15 +180,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
         for (int m = 0; m < R; ++m) { integrate_robot<KIND>(P, r[m]); __builtin_amdgcn_sched_barrier(0); }
         integrate_ball<KIND>(P, ball);
 
-        // B: contacts.  Fast path: the smallest squared distance of (my robots x my robots), (mine x the next lane's),
-        // (mine x the lane after that) — together the four lanes cover every robot pair — and of (mine x ball).
+        // B: contacts.  First the pair test — (my robots x my robots), (mine x the next lane's), (mine x half of the lane after
+        // that's): together the four lanes cover every robot pair of the env once — and (mine x ball); no LDS while nothing touches.
         const bool ball_low = qdpp_f<Q_L3>(ball.z) < K::robot_h;
         constexpr uint32_t T_RR = __builtin_bit_cast(uint32_t, K::rs_rr2) - 1u;
         constexpr float NEAR2 = 0.13f * 0.13f;   // > (dck_rb + ir_tol)^2 + half_kw^2 = 0.126^2 and > rs_rb^2 (rsx_epl_ssl.hpp)
         irbits = 0;
         BallOverride bo{false, false, 0.0f, 0.0f, 0.0f};
         bool deep_env = false;
+        RSX_QS(0, 1);
         for (int sweep = 0; sweep < 2; ++sweep) {
+            if (sweep == 1 && !__any(deep_env)) break;   // no env of the wave had a deep pair: no second pair test either
             const bool active = sweep == 0 || deep_env;
             auto dist2 = [](float xj, float yj, float xi, float yi) -> float {
                 const float dx = xj - xi, dy = yj - yi;
@@ -184,45 +200,81 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
             // happen here and at its other wave-uniform points, never inside a lane-divergent branch)
             const float bx = qdpp_f<Q_L3>(ball.x), by = qdpp_f<Q_L3>(ball.y);
             const float bvx = qdpp_f<Q_L3>(ball.vx), bvy = qdpp_f<Q_L3>(ball.vy), bom = qdpp_f<Q_L3>(ball.om);
-            // per robot of mine: does it touch anything?  rmin[i] = its smallest squared distance to my other robots and to the
-            // robots of the next two lanes; cmin[j] = the smallest distance of the NEXT lane's robot j to mine (that lane does
-            // not test backwards: it receives the flag); one robot of the other lanes at a time (two DPP temporaries)
             unsigned tf = 0, nf = 0;   // bit i: my robot i is closer than two radii to something / is near the ball
-            if (!hot) {
-            float rmin[R];
-            unsigned cf = 0;   // bit j: the next lane's robot j is within two radii of one of mine
+            // Every robot pair of the env ONCE, as one bit (the exact integer form of 0 < d2 < thr, rsx_kernels.hpp; d2 is the same
+            // float from either side: (xj - xi)^2 = (xi - xj)^2).  A lane tests its robots against the next lane's (36 pairs),
+            // against the lane after next's where i <= j (21: the other half is computed over there) and against each other (15).
+            // A compare feeds TWO shift registers (acc = 2 acc + bit: the carry-in of an add): the partner mask of my robot and the
+            // mask of the OTHER lane's robot over mine, which goes there packed six bits per robot through two DPP reads.
+            // rel[i]: bits 0..5 my own robots, 6..11 the next lane's, 12..17 the lane after next's, 18..23 the previous lane's
+            unsigned rel[R];
+            {
+                auto key = [](float xj, float yj, float xi, float yi) -> uint32_t {
+                    const float dx = xj - xi, dy = yj - yi;
+                    return __float_as_uint(fma_(dx, dx, dy * dy)) - 1u;
+                };
+                unsigned long long cdump;   // the (always clear) carry-out of the first add
+#define RSX_QPUSH2(A, B, U) asm("v_cmp_gt_u32_e32 vcc, %4, %3\n\tv_addc_co_u32_e64 %0, %2, %0, %0, vcc\n\tv_addc_co_u32_e32 %1, vcc, %1, %1, vcc" \
+                                : "+v"(A), "+v"(B), "=&s"(cdump) : "v"(U), "s"(T_RR) : "vcc")
 #pragma unroll
-            for (int i = 0; i < R; ++i) rmin[i] = 1.0e30f;
+                for (int i = 0; i < R; ++i) rel[i] = 0u;
+                unsigned cw0 = 0u, cw1 = 0u;   // the next lane's robots over mine: robot j in bits 6 j .. 6 j + 5 of cw0 (j < 5), robot 5 in cw1
 #pragma unroll
-            for (int j = R - 1; j >= 0; --j) {   // highest first: the flags are shifted in from the right
-                const float xn = qdpp_f<Q_NEXT>(r[j].x), yn = qdpp_f<Q_NEXT>(r[j].y), xd = qdpp_f<Q_DIAG>(r[j].x), yd = qdpp_f<Q_DIAG>(r[j].y);
-                float cn = 1.0e30f;
+                for (int j = R - 1; j >= 0; --j) {   // highest first: the bits are shifted in from the right
+                    const float xn = qdpp_f<Q_NEXT>(r[j].x), yn = qdpp_f<Q_NEXT>(r[j].y);
+                    unsigned cf = 0u;
 #pragma unroll
-                for (int i = 0; i < R; ++i) {
-                    const float dn = dist2(xn, yn, r[i].x, r[i].y);
-                    rmin[i] = fminf(rmin[i], fminf(dn, dist2(xd, yd, r[i].x, r[i].y)));
-                    cn = fminf(cn, dn);
-                    if (i < j) { const float di = dist2(r[j].x, r[j].y, r[i].x, r[i].y); rmin[i] = fminf(rmin[i], di); rmin[j] = fminf(rmin[j], di); }
+                    for (int i = R - 1; i >= 0; --i) { const uint32_t u = key(xn, yn, r[i].x, r[i].y); RSX_QPUSH2(rel[i], cf, u); }
+                    if (j == R - 1) cw1 = cf; else cw0 = (cw0 << 6) | cf;
+                    nf = (nf + nf) + (unsigned)(ball_low & (dist2(bx, by, r[j].x, r[j].y) < NEAR2));
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                cf = (cf + cf) + (unsigned)(cn < K::rs_rr2);
-                nf = (nf + nf) + (unsigned)(ball_low & (dist2(bx, by, r[j].x, r[j].y) < NEAR2));
-                __builtin_amdgcn_sched_barrier(0);
+                {   // what the previous lane found about my robots -> bits 18..23; mine x next -> bits 6..11
+                    const unsigned pw0 = qdpp_u<Q_PREV>(cw0), pw1 = qdpp_u<Q_PREV>(cw1);
+#pragma unroll
+                    for (int i = 0; i < R; ++i) rel[i] = (rel[i] << 6) | ((i == R - 1 ? pw1 : ((pw0 >> (6 * i)) & 63u)) << 18);
+                }
+                unsigned dw0 = 0u, dw1 = 0u;
+                unsigned dg[R];
+#pragma unroll
+                for (int i = 0; i < R; ++i) dg[i] = 0u;
+#pragma unroll
+                for (int j = R - 1; j >= 0; --j) {
+                    const float xd = qdpp_f<Q_DIAG>(r[j].x), yd = qdpp_f<Q_DIAG>(r[j].y);
+                    unsigned cd = 0u;
+#pragma unroll
+                    for (int i = j; i >= 0; --i) { const uint32_t u = key(xd, yd, r[i].x, r[i].y); RSX_QPUSH2(dg[i], cd, u); }
+                    if (j == R - 1) dw1 = cd; else dw0 = (dw0 << 6) | cd;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                {   // my robot i: its partners j >= i over there from my tests (pushed for j = 5 .. i: bit j sits at j - i), j <= i from theirs
+                    const unsigned ew0 = qdpp_u<Q_DIAG>(dw0), ew1 = qdpp_u<Q_DIAG>(dw1);
+#pragma unroll
+                    for (int i = 0; i < R; ++i) rel[i] |= ((dg[i] << i) | (i == R - 1 ? ew1 : ((ew0 >> (6 * i)) & 63u))) << 12;
+                }
+                unsigned own[R];
+#pragma unroll
+                for (int i = 0; i < R; ++i) own[i] = 0u;
+#pragma unroll
+                for (int j = R - 1; j >= 1; --j) {   // robot a receives its partners 5 .. a + 1 as the lower one of a pair, a zero for itself, then a - 1 .. 0
+                    own[j] = own[j] + own[j];
+#pragma unroll
+                    for (int i = j - 1; i >= 0; --i) { const uint32_t u = key(r[j].x, r[j].y, r[i].x, r[i].y); RSX_QPUSH2(own[j], own[i], u); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                own[0] = own[0] + own[0];
+#pragma unroll
+                for (int i = 0; i < R; ++i) rel[i] |= own[i];
+#undef RSX_QPUSH2
             }
 #pragma unroll
-            for (int i = R - 1; i >= 0; --i) tf = (tf + tf) + (unsigned)(rmin[i] < K::rs_rr2);
-            tf |= qdpp_u<Q_PREV>(cf);          // what the previous lane found about my robots
-            } else {
-                // a wave whose previous sub-step had nearly every robot slot in contact (a scrum): the screening above would
-                // flag them all again — every real robot goes to the exact partner test below instead (an empty set = no walk)
-                tf = p == 3 ? 0xFu : 0x3Fu;
-#pragma unroll
-                for (int j = R - 1; j >= 0; --j) nf = (nf + nf) + (unsigned)(ball_low & (dist2(bx, by, r[j].x, r[j].y) < NEAR2));
-            }
+            for (int i = R - 1; i >= 0; --i) tf = (tf + tf) + (unsigned)(rel[i] != 0u);
             if (!active) { tf = 0; nf = 0; }
-            if (!__any((tf | nf) != 0)) { if (sweep == 0) hot = false; break; }
+            if (!__any((tf | nf) != 0)) break;
+            RSX_QS(1, 1); if (sweep == 1) RSX_QS(11, 1);
 
             // ---- some env of the wave has a contact: snapshot -> LDS; then robot slot by robot slot (only the slots that
-            // are flagged in some env of the wave): partner set, walk, the robot's side of its ball contact ----
+            // are flagged in some env of the wave): walk, the robot's side of its ball contact ----
 #pragma unroll
             for (int m = 0; m < R; ++m) {
                 if (real(m)) {
@@ -232,45 +284,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
             }
             if (bl) { sh.A[N][q] = make_float4(ball.x, ball.y, ball.vx, ball.vy); sh.C[N][q] = make_float4(ball.om, 0.0f, 0.0f, 0.0f); }
             wave_sync();
-            auto key = [](float xj, float yj, float xi, float yi) -> uint32_t {   // exact integer form of 0 < d2 < thr (rsx_kernels.hpp)
-                const float dx = xj - xi, dy = yj - yi;
-                return __float_as_uint(fma_(dx, dx, dy * dy)) - 1u;
-            };
             const unsigned near = nf;
             bool deep = false;
             unsigned rb_touch = 0;   // my robots that touch the ball in this sweep
-            // partner sets first, from the snapshot positions (Jacobi: nothing has moved yet) — only for the robot slots
-            // that are flagged in some env of the wave.  Bit = robot index: pushed from the highest relative position down
-            // (previous lane's robots 5..0, the lane after the next, the next lane, my own), then rotated into place by 6 p
-            unsigned todo[R];
+            unsigned todo[R];   // partner sets (Jacobi: nothing has moved since the pair test)
+            {   // bit = robot index: the relative order rotated into place by 6 p
+                const unsigned sh6 = 6u * (unsigned)p;
 #pragma unroll
-            for (int i = 0; i < R; ++i) {
-                todo[i] = 0u;
-                if (__any((tf >> i) & 1u)) {
-                    unsigned rel = 0;
-#define RSX_QPUSH(X, Y, SELF)                                                                                            \
-                    _Pragma("unroll") for (int j = R - 1; j >= 0; --j) {                                                   \
-                        const uint32_t u = ((SELF) && j == i) ? 0xFFFFFFFFu : key((X), (Y), r[i].x, r[i].y);             \
-                        asm("v_cmp_gt_u32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(rel) : "v"(u), "s"(T_RR) : "vcc"); \
-                    }
-                    RSX_QPUSH(qdpp_f<Q_PREV>(r[j].x), qdpp_f<Q_PREV>(r[j].y), false)
-                    RSX_QPUSH(qdpp_f<Q_DIAG>(r[j].x), qdpp_f<Q_DIAG>(r[j].y), false)
-                    RSX_QPUSH(qdpp_f<Q_NEXT>(r[j].x), qdpp_f<Q_NEXT>(r[j].y), false)
-                    RSX_QPUSH(r[j].x, r[j].y, true)
-#undef RSX_QPUSH
-                    const unsigned sh6 = 6u * (unsigned)p;
-                    todo[i] = ((tf >> i) & 1u) ? (((rel << sh6) | (rel >> (24u - sh6))) & 0xFFFFFFu) : 0u;
-                }
+                for (int i = 0; i < R; ++i) todo[i] = active ? (((rel[i] << sh6) | (rel[i] >> (24u - sh6))) & 0xFFFFFFu) : 0u;
             }
-            if (sweep == 0) {   // how many robot slots really have a partner somewhere in the wave decides the next sub-step's mode
-                int slots = 0;
+#ifdef RSX_QSTATS
+            {
+                unsigned tot = 0, trips = 0;
 #pragma unroll
-                for (int i = 0; i < R; ++i) slots += __any(todo[i] != 0u) ? 1 : 0;
-                hot = slots >= RSX_QUAD_HOT_SLOTS;
+                for (int i = 0; i < R; ++i) { const unsigned c = (unsigned)__builtin_popcount(todo[i]); tot += c; trips += qs_wave_max(c); }
+                const unsigned flat = qs_wave_max(tot), all = qs_wave_sum(tot);
+                RSX_QS(5, trips); RSX_QS(6, all); RSX_QS(9, flat);
+                const unsigned nn = qs_wave_sum((unsigned)__builtin_popcount(near));
+                RSX_QS(12, nn);
             }
+#endif
 #pragma unroll
             for (int i = 0; i < R; ++i) {   // each robot of the lane: its robot partners in index order, then the ball
                 if (__any(((tf | near) >> i) & 1u)) {
+                    RSX_QS(4, 1);
                     const unsigned todo_i = todo[i];
                     float avx = 0.0f, avy = 0.0f, apx = 0.0f, apy = 0.0f, unused = 0.0f;
                     unsigned td = todo_i;
@@ -328,6 +365,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
             const unsigned n1 = qdpp_u<Q_NEXT>(near), n2 = qdpp_u<Q_DIAG>(near), n3 = qdpp_u<Q_PREV>(near);   // lane 3 reads lanes 0, 1, 2
             unsigned nb = bl ? (n1 | (n2 << 6) | (n3 << 12) | (near << 18)) : 0u;
             if (__any(nb != 0)) {
+                RSX_QS(7, 1);
+#ifdef RSX_QSTATS
+                { const unsigned mx = qs_wave_max((unsigned)__builtin_popcount(nb)); RSX_QS(8, mx); }
+#endif
                 float b0 = 0.0f, b1 = 0.0f, b2 = 0.0f, b3 = 0.0f, bw = 0.0f;
                 bool got = false;
                 while (nb) {
