@@ -46,11 +46,13 @@ constexpr int Q_ENVS = 16;     // envs per wave
 constexpr int Q_OD = 2 + 2 * Q_N;   // observation width of the scrimmage task
 
 struct QuadShared {
-    // snapshot of a contact sweep, slot = body index (0..21 robots, 22 ball), column = env of the wave:
-    // A = (x, y, vx, vy), C = (yaw rate | ball spin, cos, sin, kick speed); read by index on the contact path only
-    float4 A[Q_N + 1][Q_ENVS];
-    float4 C[Q_N + 1][Q_ENVS];
+    // snapshot of a contact sweep, slot = robot index, column = env of the wave: A = (x, y, vx, vy), W = yaw rate, CS = (cos, sin)
+    // of the heading; read by index on the contact path only.  9856 bytes: sixteen waves of it fit a CU's 160 KB.
+    float4 A[Q_N][Q_ENVS];
+    float W[Q_N][Q_ENVS];
+    float2 CS[Q_N][Q_ENVS];
 };
+static_assert(sizeof(QuadShared) <= 10240, "four waves per SIMD");
 
 template <int CTRL>
 __device__ __forceinline__ float qdpp_f(float v) {   // the same register of another lane of the quad (a DPP operand)
@@ -183,7 +185,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
         // B: contacts.  First the pair test — (my robots x my robots), (mine x the next lane's), (mine x half of the lane after
         // that's): together the four lanes cover every robot pair of the env once — and (mine x ball); no LDS while nothing touches.
         const bool ball_low = qdpp_f<Q_L3>(ball.z) < K::robot_h;
-        constexpr uint32_t T_RR = __builtin_bit_cast(uint32_t, K::rs_rr2) - 1u;
         constexpr float NEAR2 = 0.13f * 0.13f;   // > (dck_rb + ir_tol)^2 + half_kw^2 = 0.126^2 and > rs_rb^2 (rsx_epl_ssl.hpp)
         irbits = 0;
         BallOverride bo{false, false, 0.0f, 0.0f, 0.0f};
@@ -201,21 +202,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
             const float bx = qdpp_f<Q_L3>(ball.x), by = qdpp_f<Q_L3>(ball.y);
             const float bvx = qdpp_f<Q_L3>(ball.vx), bvy = qdpp_f<Q_L3>(ball.vy), bom = qdpp_f<Q_L3>(ball.om);
             unsigned tf = 0, nf = 0;   // bit i: my robot i is closer than two radii to something / is near the ball
-            // Every robot pair of the env ONCE, as one bit (the exact integer form of 0 < d2 < thr, rsx_kernels.hpp; d2 is the same
-            // float from either side: (xj - xi)^2 = (xi - xj)^2).  A lane tests its robots against the next lane's (36 pairs),
+            // Every robot pair of the env ONCE, as one bit: d2 < (2 r)^2 (d2 is the same float from either side: (xj - xi)^2 =
+            // (xi - xj)^2; NaN — a ghost slot — compares false; a pair at distance exactly 0, which the model does not count as
+            // touching, is dropped where the partners are walked).  A lane tests its robots against the next lane's (36 pairs),
             // against the lane after next's where i <= j (21: the other half is computed over there) and against each other (15).
             // A compare feeds TWO shift registers (acc = 2 acc + bit: the carry-in of an add): the partner mask of my robot and the
             // mask of the OTHER lane's robot over mine, which goes there packed six bits per robot through two DPP reads.
             // rel[i]: bits 0..5 my own robots, 6..11 the next lane's, 12..17 the lane after next's, 18..23 the previous lane's
+#ifdef RSX_QSTATS
+            if (sub == 0 && sweep == 0) {   // how often is every pair of the wave far enough apart that no contact can occur in this step?
+                float mn = 1.0e30f;
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const float xn = qdpp_f<Q_NEXT>(r[j].x), yn = qdpp_f<Q_NEXT>(r[j].y), xd = qdpp_f<Q_DIAG>(r[j].x), yd = qdpp_f<Q_DIAG>(r[j].y);
+#pragma unroll
+                    for (int i = 0; i < R; ++i) {
+                        const float a = dist2(xn, yn, r[i].x, r[i].y), b = dist2(xd, yd, r[i].x, r[i].y);
+                        if (a < mn) mn = a;
+                        if (b < mn) mn = b;
+                        if (i < j) { const float c = dist2(r[j].x, r[j].y, r[i].x, r[i].y); if (c < mn) mn = c; }
+                    }
+                }
+                const float wmn = __uint_as_float(~qs_wave_max(~__float_as_uint(mn)));   // min of non-negative floats
+                RSX_QS(13, wmn > 0.26f * 0.26f); RSX_QS(14, wmn > 0.30f * 0.30f); RSX_QS(15, wmn > 0.34f * 0.34f);
+            }
+#endif
             unsigned rel[R];
             {
-                auto key = [](float xj, float yj, float xi, float yi) -> uint32_t {
+                auto key = [](float xj, float yj, float xi, float yi) -> float {
                     const float dx = xj - xi, dy = yj - yi;
-                    return __float_as_uint(fma_(dx, dx, dy * dy)) - 1u;
+                    return fma_(dx, dx, dy * dy);
                 };
                 unsigned long long cdump;   // the (always clear) carry-out of the first add
-#define RSX_QPUSH2(A, B, U) asm("v_cmp_gt_u32_e32 vcc, %4, %3\n\tv_addc_co_u32_e64 %0, %2, %0, %0, vcc\n\tv_addc_co_u32_e32 %1, vcc, %1, %1, vcc" \
-                                : "+v"(A), "+v"(B), "=&s"(cdump) : "v"(U), "s"(T_RR) : "vcc")
+#define RSX_QPUSH2(A, B, U) asm("v_cmp_gt_f32_e32 vcc, %4, %3\n\tv_addc_co_u32_e64 %0, %2, %0, %0, vcc\n\tv_addc_co_u32_e32 %1, vcc, %1, %1, vcc" \
+                                : "+v"(A), "+v"(B), "=&s"(cdump) : "v"(U), "s"(K::rs_rr2) : "vcc")
 #pragma unroll
                 for (int i = 0; i < R; ++i) rel[i] = 0u;
                 unsigned cw0 = 0u, cw1 = 0u;   // the next lane's robots over mine: robot j in bits 6 j .. 6 j + 5 of cw0 (j < 5), robot 5 in cw1
@@ -224,7 +244,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
                     const float xn = qdpp_f<Q_NEXT>(r[j].x), yn = qdpp_f<Q_NEXT>(r[j].y);
                     unsigned cf = 0u;
 #pragma unroll
-                    for (int i = R - 1; i >= 0; --i) { const uint32_t u = key(xn, yn, r[i].x, r[i].y); RSX_QPUSH2(rel[i], cf, u); }
+                    for (int i = R - 1; i >= 0; --i) { const float u = key(xn, yn, r[i].x, r[i].y); RSX_QPUSH2(rel[i], cf, u); }
                     if (j == R - 1) cw1 = cf; else cw0 = (cw0 << 6) | cf;
                     nf = (nf + nf) + (unsigned)(ball_low & (dist2(bx, by, r[j].x, r[j].y) < NEAR2));
                     __builtin_amdgcn_sched_barrier(0);
@@ -243,7 +263,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
                     const float xd = qdpp_f<Q_DIAG>(r[j].x), yd = qdpp_f<Q_DIAG>(r[j].y);
                     unsigned cd = 0u;
 #pragma unroll
-                    for (int i = j; i >= 0; --i) { const uint32_t u = key(xd, yd, r[i].x, r[i].y); RSX_QPUSH2(dg[i], cd, u); }
+                    for (int i = j; i >= 0; --i) { const float u = key(xd, yd, r[i].x, r[i].y); RSX_QPUSH2(dg[i], cd, u); }
                     if (j == R - 1) dw1 = cd; else dw0 = (dw0 << 6) | cd;
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -259,7 +279,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
                 for (int j = R - 1; j >= 1; --j) {   // robot a receives its partners 5 .. a + 1 as the lower one of a pair, a zero for itself, then a - 1 .. 0
                     own[j] = own[j] + own[j];
 #pragma unroll
-                    for (int i = j - 1; i >= 0; --i) { const uint32_t u = key(r[j].x, r[j].y, r[i].x, r[i].y); RSX_QPUSH2(own[j], own[i], u); }
+                    for (int i = j - 1; i >= 0; --i) { const float u = key(r[j].x, r[j].y, r[i].x, r[i].y); RSX_QPUSH2(own[j], own[i], u); }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 own[0] = own[0] + own[0];
@@ -279,10 +299,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
             for (int m = 0; m < R; ++m) {
                 if (real(m)) {
                     sh.A[R * p + m][q] = make_float4(r[m].x, r[m].y, r[m].vx, r[m].vy);
-                    sh.C[R * p + m][q] = make_float4(r[m].om, r[m].c, r[m].s, ((kickbits >> m) & 1u) ? 5.0f : 0.0f);
+                    sh.W[R * p + m][q] = r[m].om;
+                    sh.CS[R * p + m][q] = make_float2(r[m].c, r[m].s);
                 }
             }
-            if (bl) { sh.A[N][q] = make_float4(ball.x, ball.y, ball.vx, ball.vy); sh.C[N][q] = make_float4(ball.om, 0.0f, 0.0f, 0.0f); }
             wave_sync();
             const unsigned near = nf;
             bool deep = false;
@@ -311,14 +331,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
                     const unsigned todo_i = todo[i];
                     float avx = 0.0f, avy = 0.0f, apx = 0.0f, apy = 0.0f, unused = 0.0f;
                     unsigned td = todo_i;
+                    bool hit = false;
                     while (td) {
                         const int j = __builtin_ctz(td);
                         td &= td - 1;
                         const float4 oj = sh.A[j][q];
-                        const float wj = sh.C[j][q].x;
+                        const float wj = sh.W[j][q];
                         const float dx = oj.x - r[i].x, dy = oj.y - r[i].y;
-                        contact_response(r[i], oj, fma_(dx, dx, dy * dy), K::rs_rr, K::ope_rr, K::w_rr, K::kt_rr, K::mu_rr, 0.0f,
-                                         fma_(wj, K::r_robot, r[i].om * K::r_robot), K::beta, K::pen2, avx, avy, apx, apy, unused, deep);
+                        const float d2 = fma_(dx, dx, dy * dy);
+                        if (d2 > 0.0f) {   // (0: two robots in one place are not a contact, rsx_kernels.hpp)
+                            hit = true;
+                            contact_response(r[i], oj, d2, K::rs_rr, K::ope_rr, K::w_rr, K::kt_rr, K::mu_rr, 0.0f,
+                                             fma_(wj, K::r_robot, r[i].om * K::r_robot), K::beta, K::pen2, avx, avy, apx, apy, unused, deep);
+                        }
                     }
                     bool touch = false;
                     if ((near >> i) & 1u) {   // the robot's side of its robot-ball contact (kicker mouth or body circle), infrared
@@ -354,7 +379,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
                         }
                         if (sweep == 0 && mouth && pen > -K::ir_tol) irbits |= 1u << i;
                     }
-                    if (todo_i | (touch ? 1u : 0u)) {   // only a body that touched something is updated
+                    if (hit | touch) {   // only a body that touched something is updated
                         r[i].vx = r[i].vx + avx; r[i].vy = r[i].vy + avy;
                         r[i].x = r[i].x + apx; r[i].y = r[i].y + apy;
                     }
@@ -364,6 +389,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
             // evaluated (its own view of the contact), so the same numbers; kicker: the last robot in index order wins
             const unsigned n1 = qdpp_u<Q_NEXT>(near), n2 = qdpp_u<Q_DIAG>(near), n3 = qdpp_u<Q_PREV>(near);   // lane 3 reads lanes 0, 1, 2
             unsigned nb = bl ? (n1 | (n2 << 6) | (n3 << 12) | (near << 18)) : 0u;
+            const unsigned k1 = qdpp_u<Q_NEXT>(kickbits), k2 = qdpp_u<Q_DIAG>(kickbits), k3 = qdpp_u<Q_PREV>(kickbits);
+            const unsigned kicks = k1 | (k2 << 6) | (k3 << 12) | (kickbits << 18);   // (lane 3's view: bit = robot index)
             if (__any(nb != 0)) {
                 RSX_QS(7, 1);
 #ifdef RSX_QSTATS
@@ -375,7 +402,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
                     const int k = __builtin_ctz(nb);
                     nb &= nb - 1;
                     const float4 oa = sh.A[k][q];
-                    const float4 oc = sh.C[k][q];   // om, c, s, kick
+                    const float2 cs = sh.CS[k][q];
+                    const float4 oc = make_float4(sh.W[k][q], cs.x, cs.y, ((kicks >> k) & 1u) ? 5.0f : 0.0f);   // om, c, s, kick speed
                     float dx = ball.x - oa.x, dy = ball.y - oa.y;
                     float nx = 0.0f, ny = 0.0f, pen = -1.0f;
                     bool mouth = false, touch = false;

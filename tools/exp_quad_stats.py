@@ -8,7 +8,7 @@ lib = L.load()
 lib.rsx_debug_qstats.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 s = torch.cuda.current_stream().cuda_stream
 NAMES = ["wave sub-steps", "sweeps on the contact path", "screening passes", "partner sets (slots)", "slots walked", "walk trips (sum over slots of max over lanes)",
-         "contacts (robot sides)", "ball passes", "ball walk trips", "walk trips if flattened (max over lanes of the lane's total)", "hot sweeps", "second sweeps", "robots near ball"]
+         "contacts (robot sides)", "ball passes", "ball walk trips", "walk trips if flattened (max over lanes of the lane's total)", "hot sweeps", "second sweeps", "robots near ball", "steps x5: closest pair of the wave > 26 cm", "steps x5: > 30 cm", "steps x5: > 34 cm"]
 B = int(os.environ.get("B", "65536"))
 for task, name in ((6, "spread"), (7, "crowded")):
     sim = L.Sim(1, 1, 11, 11, 25, B); sim.task_attach(task, 0, 0, 0); sim.task_reset()
