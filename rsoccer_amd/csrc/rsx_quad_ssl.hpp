@@ -385,10 +385,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
                     }
                 }
             }
-            // the ball's side: the robots near it, in robot order, from the snapshot — the same expressions the robot's lane
-            // evaluated (its own view of the contact), so the same numbers; kicker: the last robot in index order wins
-            const unsigned n1 = qdpp_u<Q_NEXT>(near), n2 = qdpp_u<Q_DIAG>(near), n3 = qdpp_u<Q_PREV>(near);   // lane 3 reads lanes 0, 1, 2
-            unsigned nb = bl ? (n1 | (n2 << 6) | (n3 << 12) | (near << 18)) : 0u;
+            // the ball's side: the robots that touch it (or hold it in front of a kicker that fires), in robot order, from the snapshot
+            // — the same expressions the robot's lane evaluated (its own view of the contact), so the same numbers and the same
+            // decisions: a robot whose lane found neither a touch nor a kick adds nothing here either; kicker: the last robot in
+            // index order wins
+            const unsigned mine = rb_touch | (sweep == 0 ? (irbits & kickbits) : 0u);
+            const unsigned n1 = qdpp_u<Q_NEXT>(mine), n2 = qdpp_u<Q_DIAG>(mine), n3 = qdpp_u<Q_PREV>(mine);   // lane 3 reads lanes 0, 1, 2
+            unsigned nb = bl ? (n1 | (n2 << 6) | (n3 << 12) | (mine << 18)) : 0u;
             const unsigned k1 = qdpp_u<Q_NEXT>(kickbits), k2 = qdpp_u<Q_DIAG>(kickbits), k3 = qdpp_u<Q_PREV>(kickbits);
             const unsigned kicks = k1 | (k2 << 6) | (k3 << 12) | (kickbits << 18);   // (lane 3's view: bit = robot index)
             if (__any(nb != 0)) {
@@ -443,7 +446,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
                     ball.om = ball.om + bw;
                 }
             }
-            (void)rb_touch;
             const unsigned dm = deep ? 1u : 0u;
             deep_env = ((dm | qdpp_u<Q_NEXT>(dm)) | (qdpp_u<Q_DIAG>(dm) | qdpp_u<Q_PREV>(dm))) != 0u;
             wave_sync();   // every lane has read the snapshot before it is republished

@@ -633,6 +633,51 @@ def test_quad_layout_is_bit_identical(oracle_mod, monkeypatch, task):
     assert np.array_equal(outs["quad"], outs["lanes"], equal_nan=True)
 
 
+@pytest.mark.parametrize("layout", ["quad", "lanes"])
+def test_scrimmage_robots_in_one_place_are_not_a_contact(oracle_mod, monkeypatch, layout):
+    """Two robots at EXACTLY the same position have no contact normal: the model skips the pair (0 < d2 < (2 r)^2).  The
+    four-lane kernel finds pairs with a float compare (d2 < thr) and drops the zero distance where partners are walked;
+    pairs inside one lane's six robots, across neighbouring lanes and across the diagonal, next to ordinary contacts."""
+    import torch
+    L = _lib()
+    O = oracle_mod
+    kind, ft, nb, ny = 1, 1, 11, 11
+    B = 21
+    monkeypatch.setenv("RSX_LAYOUT", layout)
+    sim = L.Sim(kind, ft, nb, ny, 25, B)
+    sim.task_attach(6, 9, 0, 0)
+    rng = np.random.default_rng(5)
+    gx, gy = np.meshgrid(np.linspace(-2.5, 2.5, 6), np.linspace(-1.5, 1.5, 4))
+    ball = np.zeros((B, 4)); rob = np.zeros((B, 22, 3))
+    same = [(0, 1), (2, 7), (3, 15), (20, 21), (5, 18), (11, 12), (4, 10)]
+    for e in range(B):
+        rob[e, :, :2] = np.stack([gx.ravel(), gy.ravel()], 1)[:22] + rng.uniform(-0.05, 0.05, (22, 2))
+        rob[e, :, 2] = rng.uniform(-180, 180, 22)
+        a, b = same[e % len(same)]
+        rob[e, b, :2] = rob[e, a, :2]                       # exactly coincident
+        c = (a + 2) % 22 if (a + 2) % 22 != b else (a + 3) % 22
+        rob[e, c, :2] = rob[e, a, :2] + (0.12, 0.05)        # and a third robot overlapping both
+        ball[e, :2] = (3.5, 2.5)
+    refs = _mk_oracles(O, kind, ft, nb, ny, B)
+    for e, r in enumerate(refs):
+        r.task_attach(6, 9, e, 0)
+        r.task_reset()
+        r.task_reset_to(ball[e], rob[e, :11], rob[e, 11:])
+    sim.task_reset()
+    sim.task_reset_to(ball, rob[:, :11], rob[:, 11:])
+    tens = sim.task_tensors()
+    a = np.zeros(tuple(tens["actions"].shape), np.float32)   # nobody drives: the coincident pairs stay coincident unless pushed
+    for t in range(12):
+        if t >= 6:
+            a = rng.uniform(-1, 1, a.shape).astype(np.float32)
+        tens["actions"].copy_(torch.from_numpy(a))
+        sim.task_step(tens["actions"].data_ptr())
+        for e, r in enumerate(refs):
+            r.task_step(a[e])
+        _cmp_task(sim, refs, tens, t)
+    sim.close()
+
+
 @pytest.mark.parametrize("B,n_step,n_roll", [(32768, 40, 0), (98304, 12, 18)], ids=["32768-steps", "98304-steps-and-a-multi-step-call"])
 def test_scrimmage_large_batch_switches_to_the_quad_layout_and_agrees(monkeypatch, B, n_step, n_roll):
     """from 32 768 envs the spread scrimmage task picks the four-lanes-per-env kernel by itself; forcing the 32-lane kernel on
