@@ -240,7 +240,7 @@ int rsx_task_step(rsx_sim* h, const float* actions_dev, void* stream);
 int rsx_task_step_n(rsx_sim* h, int n, void* stream);
 /* n consecutive random-action steps inside ONE launch (state stays in registers between
  * steps; obs / reward / done buffers hold the values of the last step).  Same results as n single steps; the
- * library may issue it that way where that is faster (SSL 11v11 handles of >= 98 304 envs do). */
+ * library may issue it that way where that is faster (SSL 11v11 handles of >= 49 152 envs do; the crowded line-up from 196 608). */
 int rsx_task_rollout(rsx_sim* h, int n, void* stream);
 
 /* Debugging aid: number of non-finite floats in the state rows and, with a task attached, in the

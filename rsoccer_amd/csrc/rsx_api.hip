@@ -61,7 +61,7 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #endif
 // from this batch on a multi-step call (rsx_task_rollout) on a four-lane handle is issued as single-step launches
 #ifndef RSX_QUAD_ROLLOUT_MIN_ENVS
-#define RSX_QUAD_ROLLOUT_MIN_ENVS 98304
+#define RSX_QUAD_ROLLOUT_MIN_ENVS 49152
 #endif
 #ifndef RSX_QUAD_ROLLOUT_MIN_ENVS_CROWDED
 #define RSX_QUAD_ROLLOUT_MIN_ENVS_CROWDED 196608

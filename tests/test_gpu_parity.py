@@ -678,10 +678,10 @@ def test_scrimmage_robots_in_one_place_are_not_a_contact(oracle_mod, monkeypatch
     sim.close()
 
 
-@pytest.mark.parametrize("B,n_step,n_roll", [(32768, 40, 0), (98304, 12, 18)], ids=["32768-steps", "98304-steps-and-a-multi-step-call"])
+@pytest.mark.parametrize("B,n_step,n_roll", [(32768, 40, 0), (65536, 12, 18)], ids=["32768-steps", "65536-steps-and-a-multi-step-call"])
 def test_scrimmage_large_batch_switches_to_the_quad_layout_and_agrees(monkeypatch, B, n_step, n_roll):
     """from 32 768 envs the spread scrimmage task picks the four-lanes-per-env kernel by itself; forcing the 32-lane kernel on
-    the same seeds gives the same buffers (full size, resets included).  From 98 304 envs a multi-step call
+    the same seeds gives the same buffers (full size, resets included).  From 49 152 envs a multi-step call
     (rsx_task_rollout) on such a handle is issued as single-step launches of that kernel: same results as the 32-lane
     kernel's one launch."""
     import torch

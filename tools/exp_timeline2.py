@@ -8,7 +8,10 @@ B = int(os.environ.get("B", 4096))
 NS = 20
 G = 64 // int(os.environ.get("LANES", 8))   # envs per wave (LANES=32 for the 11v11 task)
 nb = ((B + G - 1) // G + 7) // 8 * 8
-dbg = torch.zeros(NS * nb, dtype=torch.int64, device="cuda")
+# SSLStaticDefenders single-step launches with the placement cache on carry ceil(B / 64) helper workgroups behind the tiles: the
+# stamp rows are gridDim.x apart
+HELP = (B + 63) // 64 if os.environ.get("CFG", "vss") == "sd" and not os.environ.get("RSX_NO_PCACHE") and B <= 16384 else 0
+dbg = torch.zeros(NS * (nb + HELP), dtype=torch.int64, device="cuda")
 torch.cuda.synchronize()
 L.load().rsx_dbg_set(ctypes.c_void_p(dbg.data_ptr()))
 CFG = {"vss": (0, 0, 3, 3, 1), "sd": (1, 2, 1, 6, 2), "drib": (1, 2, 1, 4, 3), "cont": (1, 2, 1, 1, 4), "pass": (1, 2, 2, 0, 5),
@@ -18,16 +21,16 @@ s = torch.cuda.current_stream().cuda_stream
 sim.task_step_n(500, s); torch.cuda.synchronize()
 names = ["entry", "loads landed", "cmds done", "physics done", "epilogue done", "before stores", "stores issued", "stores acked",
          "sub0", "sub1", "sub2", "sub3", "sub4"]
-def collect(fn, n):
+def collect(fn, n, stride):
     acc = []
     for it in range(n):
         fn(); torch.cuda.synchronize()
-        acc.append(dbg.cpu().numpy().reshape(NS, nb).astype(np.float64))
+        acc.append(dbg.cpu().numpy()[:NS * stride].reshape(NS, stride)[:, :nb].astype(np.float64))
     return np.stack(acc)
 for label, fn in (("single-step launch", lambda: sim.task_step(None, s)),
                   ("single-step launch, last of 50 back-to-back", lambda: sim.task_step_n(50, s)),
                   ("last step of a 6-step launch", lambda: sim.task_rollout(6, s))):
-    d = collect(fn, 100)
+    d = collect(fn, 100, nb + (HELP if label.startswith("single") else 0))
     print("==", label)
     seq = [("cmds (philox, OU, targets)", 1, 2), ("sub0", 2, 8), ("sub1", 8, 9), ("sub2", 9, 10), ("sub3", 10, 11), ("sub4", 11, 12),
            ("post-physics: obs+reward+flags", 3, 4), ("episode end + obs copy", 4, 5)]
