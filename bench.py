@@ -546,7 +546,10 @@ def other_configs(L, torch, dev, timed):
              ("SSL 11v11 scrimmage, spread, 65 536 envs (four lanes per env from 32 768 envs)", 1, 1, 11, 11, L.TASK_SSL_SCRIMMAGE, 65536, SC, 60, 20),
              ("SSL 11v11 scrimmage, crowded, 65 536 envs (four lanes per env from 65 536 envs)", 1, 1, 11, 11, L.TASK_SSL_SCRIMMAGE_CROWDED, 65536, SC, 60, 20),
              ("SSL 11v11 scrimmage, spread, 262 144 envs (four lanes per env)", 1, 1, 11, 11, L.TASK_SSL_SCRIMMAGE, 262144, SC, 30, 10),
-             ("SSL 11v11 scrimmage, crowded, 262 144 envs (four lanes per env)", 1, 1, 11, 11, L.TASK_SSL_SCRIMMAGE_CROWDED, 262144, SC, 30, 10))
+             ("SSL 11v11 scrimmage, crowded, 262 144 envs (four lanes per env)", 1, 1, 11, 11, L.TASK_SSL_SCRIMMAGE_CROWDED, 262144, SC, 30, 10),
+             # the two legs above time steps 21-80 / 11-40 after a reset, where the crowded line-up is one scrum per env; later on:
+             ("SSL 11v11 scrimmage, crowded, 65 536 envs, steps 201-260 after a reset", 1, 1, 11, 11, L.TASK_SSL_SCRIMMAGE_CROWDED, 65536, SC, 60, 200),
+             ("SSL 11v11 scrimmage, crowded, 262 144 envs, steps 121-150 after a reset", 1, 1, 11, 11, L.TASK_SSL_SCRIMMAGE_CROWDED, 262144, SC, 30, 120))
     LEG = {L.TASK_SSL_STATIC_DEFENDERS: "sd", L.TASK_SSL_DRIBBLING: "drib", L.TASK_SSL_CONTESTED: "cont",
            L.TASK_SSL_PASS_ENDURANCE: "pass", L.TASK_SSL_SCRIMMAGE: "scrim", L.TASK_SSL_SCRIMMAGE_CROWDED: "scrimC"}
     out = []
