@@ -201,6 +201,9 @@ int rsx_step_dev_random(rsx_sim* h, int n, uint64_t seed, uint32_t first_tick, v
  * attach) — a run is reproducible from its seed and its sequence of calls.
  * Limits (both are 32-bit words of the Philox counter, and both are checked, never wrapped):
  *   - env_id_base + num_envs <= 2^32, else RSX_ERR_ARG;
+ *   - every [rows][num_envs] float array of a handle stays below 4 GB (rows x num_envs < 2^30: VSS 3v3 ~21 M envs,
+ *     SSL 1v6 ~12 M, SSL 11v11 ~4 M), else RSX_ERR_ARG from rsx_create / rsx_task_attach: the kernels address a
+ *     row with a 32-bit byte offset;
  *   - a handle takes at most 2^32 - 1 fused steps (rsx_task_step / _step_n / _rollout; about 11 h at 10^5 calls/s);
  *     the call that would exceed it returns RSX_ERR_STATE and changes nothing.  The counter is part of the checkpoint. */
 int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base,

@@ -476,6 +476,10 @@ int rsx_create(rsx_sim** out, int kind, int field_type, int n_blue, int n_yellow
     const size_t B = (size_t)num_envs;
     const size_t sbytes = (size_t)(h->P.state_dim + X_ROWS) * B * sizeof(float);
     const size_t cbytes = (size_t)h->P.n_robots * h->M.cmd_dim * B * sizeof(float);
+    if (sbytes >= ((size_t)1 << 32)) {   // the kernels address a row of the state with a 32-bit byte offset (rsx_kernels.hpp: at_byte)
+        free_all(h); delete h;
+        return fail(RSX_ERR_ARG, "num_envs too large: the state array would reach 4 GB (see rsx.h, limits)");
+    }
     if ((e = hipMalloc((void**)&h->arena_sim, align_up(sbytes) + align_up(cbytes))) != hipSuccess) return bail(e, "hipMalloc(state+cmds)");
     h->d_state = (float*)h->arena_sim;
     h->d_cmds = (float*)(h->arena_sim + align_up(sbytes));
@@ -683,6 +687,8 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
         return fail(RSX_ERR_ARG, "this task runs with 8 lanes per env only (unset RSX_LANES_PER_ENV)");
     const size_t B = (size_t)P.num_envs;
     const size_t n_aux = align_up((size_t)aux_rows(P.n_robots) * B * sizeof(float));
+    if (n_aux >= ((size_t)1 << 32) || B * (size_t)P.obs_dim * sizeof(float) >= ((size_t)1 << 32))
+        return fail(RSX_ERR_ARG, "num_envs too large for a fused task: the per-env scalar arena or the observation array would reach 4 GB (see rsx.h, limits)");
     const size_t n_obs = align_up(B * P.obs_dim * sizeof(float));
     const size_t n_flags = align_up(2 * B);
     const size_t n_act = align_up(B * h->M.act_dim * sizeof(float));

@@ -112,6 +112,20 @@ struct Shared {
 #endif
 #define RSX_RARE_B(KIND, bit, c) (((KIND) == RSX_KIND_SSL || (RSX_VSS_HINTS & (bit))) ? __builtin_expect(!!(c), 0) : !!(c))
 
+// Addresses into the [rows][B] arrays on the hot paths: a uniform base pointer (scalar registers) + ONE 32-bit BYTE offset per
+// lane — the global_load / global_store "saddr" form, no 64-bit vector multiply-adds and shifts per access.  The host refuses
+// batches whose arrays would reach 4 GB (rsx_api.hip: RSX_ERR_ARG at create / attach).
+#ifndef RSX_IX32
+#define RSX_IX32 1   // development A/B: 0 = 64-bit offsets
+#endif
+#if RSX_IX32
+typedef uint32_t ix_t;
+#else
+typedef size_t ix_t;
+#endif
+__device__ __forceinline__ float& at_byte(float* base, const ix_t off) { return *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off); }
+__device__ __forceinline__ const float& at_byte(const float* base, const ix_t off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + off); }
+
 // lanes of the env in slot g: body j sits at lane j * G + g
 template <int L>
 __device__ __forceinline__ unsigned long long env_lane_mask(const int g) {
@@ -559,24 +573,24 @@ template <int KIND>
 __device__ __forceinline__ RawBody load_raw(const Params& P, const float* __restrict__ st, int e,
                                             int b, bool is_robot, bool is_ball) {
     constexpr int RS = ModelD<KIND>::rs;
-    const size_t B = (size_t)P.num_envs;
+    const ix_t B4 = (ix_t)4 * (ix_t)P.num_envs, e4 = (ix_t)4 * (ix_t)e;   // bytes per row, this env's column
     RawBody r{};
     if (is_robot || is_ball) {
         const int row0 = is_ball ? 0 : 5 + RS * b;
         const int row5 = is_ball ? P.state_dim : row0 + 5;
-        const float* p = st + (size_t)row0 * B + e;
-        r.v0 = p[0]; r.v1 = p[B]; r.v2 = p[2 * B]; r.v3 = p[3 * B]; r.v4 = p[4 * B];
-        r.v5 = st[(size_t)row5 * B + e];
+        const ix_t i0 = (ix_t)row0 * B4 + e4;
+        r.v0 = at_byte(st, i0); r.v1 = at_byte(st, i0 + B4); r.v2 = at_byte(st, i0 + 2 * B4); r.v3 = at_byte(st, i0 + 3 * B4); r.v4 = at_byte(st, i0 + 4 * B4);
+        r.v5 = at_byte(st, (ix_t)row5 * B4 + e4);
     }
     if (KIND == RSX_KIND_SSL) {   // robots: infrared flag; ball: spin row (same load instruction)
-        if (is_robot || is_ball) r.ir = st[(size_t)(is_ball ? P.state_dim + 1 : 5 + RS * b + 6) * B + e];
+        if (is_robot || is_ball) r.ir = at_byte(st, (ix_t)(is_ball ? P.state_dim + 1 : 5 + RS * b + 6) * B4 + e4);
         if (is_robot) {
-            const float* p = st + (size_t)(5 + RS * b + 7) * B + e;
+            const ix_t i7 = (ix_t)(5 + RS * b + 7) * B4 + e4;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) r.w[i] = p[i * B];
+            for (int i = 0; i < 4; ++i) r.w[i] = at_byte(st, i7 + (ix_t)i * B4);
         }
     } else if (is_ball) {
-        r.ir = st[(size_t)(P.state_dim + 1) * B + e];
+        r.ir = at_byte(st, (ix_t)(P.state_dim + 1) * B4 + e4);
     }
     return r;
 }
@@ -626,20 +640,21 @@ __device__ __forceinline__ void store_body(const Params& P, float* __restrict__ 
                                            bool write_ir) {
     using K = KC<KIND>;
     constexpr int RS = ModelD<KIND>::rs;
-    const size_t B = (size_t)P.num_envs;
+    const ix_t B4 = (ix_t)4 * (ix_t)P.num_envs, e4 = (ix_t)4 * (ix_t)e;
     if (is_robot || is_ball) {
         const int row0 = is_ball ? 0 : 5 + RS * b;
         const int row5 = is_ball ? P.state_dim : row0 + 5;
-        float* p = st + (size_t)row0 * B + e;
-        p[0] = o.x; p[B] = o.y; p[2 * B] = is_ball ? K::r_ball + o.z : th_deg; p[3 * B] = o.vx; p[4 * B] = o.vy;
-        st[(size_t)row5 * B + e] = is_ball ? o.vz : om_deg;
+        const ix_t i0 = (ix_t)row0 * B4 + e4;
+        at_byte(st, i0) = o.x; at_byte(st, i0 + B4) = o.y; at_byte(st, i0 + 2 * B4) = is_ball ? K::r_ball + o.z : th_deg;
+        at_byte(st, i0 + 3 * B4) = o.vx; at_byte(st, i0 + 4 * B4) = o.vy;
+        at_byte(st, (ix_t)row5 * B4 + e4) = is_ball ? o.vz : om_deg;
     }
-    if (is_ball) st[(size_t)(P.state_dim + 1) * B + e] = o.om;
+    if (is_ball) at_byte(st, (ix_t)(P.state_dim + 1) * B4 + e4) = o.om;
     if (KIND == RSX_KIND_SSL && is_robot) {
-        float* p = st + (size_t)(5 + RS * b + 6) * B + e;
-        if (write_ir) p[0] = o.ir ? 1.0f : 0.0f;
+        const ix_t i6 = (ix_t)(5 + RS * b + 6) * B4 + e4;
+        if (write_ir) at_byte(st, i6) = o.ir ? 1.0f : 0.0f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) p[(1 + i) * B] = w[i];
+        for (int i = 0; i < 4; ++i) at_byte(st, i6 + (ix_t)(1 + i) * B4) = w[i];
     }
 }
 
@@ -705,9 +720,9 @@ __global__ __launch_bounds__(64) void sim_step_kernel(RSX_HOT_ARGS, const Params
             if (KIND == RSX_KIND_SSL) { q[1] = a0 * 2.5f; q[2] = a1 * 2.5f; q[3] = a2 * 10.0f; }
             else { q[0] = a0 * K::w_max; q[1] = a1 * K::w_max; }
         } else {
-            const float* c = bufs.cmds + (size_t)(b * CD) * B + e;
+            const ix_t B4 = (ix_t)4 * (ix_t)P.num_envs, c0 = (ix_t)(b * CD) * B4 + (ix_t)4 * (ix_t)e;
 #pragma unroll
-            for (int i = 0; i < CD; ++i) q[i] = c[i * B];
+            for (int i = 0; i < CD; ++i) q[i] = at_byte(bufs.cmds, c0 + (ix_t)i * B4);
         }
     }
     interpret_body<KIND>(raw, is_robot, is_ball, o, od, wd, w);
@@ -1325,7 +1340,7 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
         : TASK == RSX_TASK_SSL_SCRIMMAGE ? 2 + 2 * NR
         : TASK == RSX_TASK_SSL_DRIBBLING ? 21 : TASK == RSX_TASK_SSL_CONTESTED ? 14 : 16;
     const int OD = OD_C ? OD_C : P.obs_dim;
-    float* const auxe = bufs.aux + e;  // column of this env in the scalar arena
+#define auxe(ROW) at_byte(bufs.aux, (ix_t)(ROW) * ((ix_t)4 * (ix_t)P.num_envs) + (ix_t)4 * (ix_t)e)   // row ROW of this env in the scalar arena
 
 #ifdef RSX_TIMING
 #define RSX_STAMP(i) do { if (lane == 0) bufs.dbg[(size_t)(i) * gridDim.x + blockIdx.x] = __builtin_readcyclecounter(); } while (0)
@@ -1341,12 +1356,12 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
     const RawBody raw = load_raw<KIND>(P, bufs.state, e, b, is_robot, is_ball);
     int steps = 0; uint32_t episode = 0;
     if (live) {
-        steps = __float_as_int(auxe[(size_t)ROW_STEPS * B]);
-        episode = __float_as_uint(auxe[(size_t)ROW_EPISODE * B]);
+        steps = __float_as_int(auxe(ROW_STEPS));
+        episode = __float_as_uint(auxe(ROW_EPISODE));
     }
     float ou0 = 0.0f, ou1 = 0.0f;
     if (TASK == RSX_TASK_VSS_V0 && is_robot && b >= 1) {
-        ou0 = auxe[(size_t)(ROW_OU + 2 * b) * B]; ou1 = auxe[(size_t)(ROW_OU + 2 * b + 1) * B];
+        ou0 = auxe(ROW_OU + 2 * b); ou1 = auxe(ROW_OU + 2 * b + 1);
     }
     float info[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     float prev_pot = 0.0f, ep_ret = 0.0f;
@@ -1355,9 +1370,9 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
         // clears them: they are neither read nor — in the common case — written
 #pragma unroll
         for (int i = 0; i < ID; ++i)
-            if (!(TASK == RSX_TASK_VSS_V0 && (i == 0 || i >= 4))) info[i] = auxe[(size_t)(ROW_INFO + i) * B];
-        prev_pot = auxe[(size_t)ROW_PREV_POT * B];
-        if (TASK != RSX_TASK_VSS_V0) ep_ret = auxe[(size_t)ROW_EP_RET * B];   // VSS-v0: derived from the info terms
+            if (!(TASK == RSX_TASK_VSS_V0 && (i == 0 || i >= 4))) info[i] = auxe(ROW_INFO + i);
+        prev_pot = auxe(ROW_PREV_POT);
+        if (TASK != RSX_TASK_VSS_V0) ep_ret = auxe(ROW_EP_RET);   // VSS-v0: derived from the info terms
     }
     // metrics[0] (env-steps) is counted on the device by ONE lane of the grid: launches of a handle
     // are stream-ordered, so a plain read-modify-write is race free and costs no atomic
@@ -1376,11 +1391,11 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
     if (TASK == RSX_TASK_SSL_SCRIMMAGE) {   // every robot is commanded: [B][N][4]
         if (fed && is_robot) {
 #pragma unroll
-            for (int i = 0; i < AD; ++i) act[i] = bufs.actions[((size_t)e * N + b) * AD + i];
+            for (int i = 0; i < AD; ++i) act[i] = at_byte(bufs.actions, (ix_t)4 * (((ix_t)e * (ix_t)N + (ix_t)b) * (ix_t)AD + (ix_t)i));   // ([B][N][AD] is smaller than the state array)
         }
     } else if (fed && is_robot && b == 0) {
 #pragma unroll
-        for (int i = 0; i < AD; ++i) act[i] = bufs.actions[(size_t)e * AD + i];
+        for (int i = 0; i < AD; ++i) act[i] = at_byte(bufs.actions, (ix_t)4 * ((ix_t)e * (ix_t)AD + (ix_t)i));
     }
 
     // placement cache: this body's pose in the env's next episode and the episode id it was made for, loaded with the state
@@ -1420,7 +1435,7 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
 #pragma unroll
                     for (int i = 0; i < 10; ++i) info[i] = 0.0f;
 #pragma unroll
-                    for (int i = 0; i < ID; ++i) auxe[(size_t)(ROW_INFO + i) * B] = 0.0f;
+                    for (int i = 0; i < ID; ++i) auxe(ROW_INFO + i) = 0.0f;
                     ep_ret = 0.0f; prev_pot = 0.0f;
                 }
             }
@@ -1532,9 +1547,10 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
                 // episode's first step), like the dict the reference returns with `done`
 #pragma unroll
                 for (int i = 0; i < ID; ++i)
-                    if (!(TASK == RSX_TASK_VSS_V0 && (i == 0 || i >= 4)) || term || first_step) auxe[(size_t)(ROW_INFO + i) * B] = info[i];
-                auxe[(size_t)ROW_REWARD * B] = reward;
-                bufs.flags[e] = (uint8_t)term; bufs.flags[B + e] = (uint8_t)trunc;
+                    if (!(TASK == RSX_TASK_VSS_V0 && (i == 0 || i >= 4)) || term || first_step) auxe(ROW_INFO + i) = info[i];
+                auxe(ROW_REWARD) = reward;
+                if (MODE == MODE_STEP) { bufs.flags[(ix_t)e] = (uint8_t)term; bufs.flags[(ix_t)P.num_envs + (ix_t)e] = (uint8_t)trunc; }
+                else { bufs.flags[e] = (uint8_t)term; bufs.flags[B + e] = (uint8_t)trunc; }
             }
         }
 
@@ -1632,18 +1648,24 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
 
         // ---- observation out, coalesced: the tile's G rows are one contiguous run ----
         if (!DOBS) {
-            const size_t base = (size_t)tile * G * OD;
-            const size_t lim = B * (size_t)OD;
+            // single-step launches: 32-bit offsets (in floats: [B][OD] stays below 2^30 floats, host check); multi-step launches keep
+            // the 64-bit pointer they hoist out of the step loop (measured: the 32-bit form costs them 2-4 %)
+            typedef typename std::conditional<MODE == MODE_STEP, ix_t, size_t>::type ox_t;
+            const ox_t base = (ox_t)tile * (ox_t)(G * OD);
+            const ox_t lim = (ox_t)P.num_envs * (ox_t)OD;
             if (OD_C) {  // all staging reads in flight together, then the stores
                 constexpr int NCH = (G * (OD_C ? OD_C : 1) + 63) / 64;
                 float v[NCH];
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) { const int i = lane + 64 * c; v[c] = i < G * OD_C ? sh.stage[i] : 0.0f; }
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) { const int i = lane + 64 * c; if (i < G * OD_C && base + i < lim) bufs.obs[base + i] = v[c]; }
+                for (int c = 0; c < NCH; ++c) {
+                    const int i = lane + 64 * c;
+                    if (i < G * OD_C && base + (ox_t)i < lim) *reinterpret_cast<float*>(reinterpret_cast<char*>(bufs.obs) + (ox_t)4 * (base + (ox_t)i)) = v[c];
+                }
             } else {
                 for (int i = lane; i < G * OD; i += 64)
-                    if (base + i < lim) bufs.obs[base + i] = sh.stage[i];
+                    if (base + (ox_t)i < lim) *reinterpret_cast<float*>(reinterpret_cast<char*>(bufs.obs) + (ox_t)4 * (base + (ox_t)i)) = sh.stage[i];
             }
         }
         wave_sync();
@@ -1653,15 +1675,16 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
     // ---- store (wire format: degrees, deg/s; SSL: infrared + wheel speeds) ----
     if (mode != 2) store_body<KIND>(P, bufs.state, e, b, is_robot, is_ball, o, od, wd, wheels, P.n_sub != 0 || was_reset);
     if (live && b == 0) {
-        auxe[(size_t)ROW_STEPS * B] = __int_as_float(steps);
-        auxe[(size_t)ROW_EPISODE * B] = __uint_as_float(episode);
+        auxe(ROW_STEPS) = __int_as_float(steps);
+        auxe(ROW_EPISODE) = __uint_as_float(episode);
     }
     if (TASK == RSX_TASK_VSS_V0 && is_robot && b >= 1) {
-        auxe[(size_t)(ROW_OU + 2 * b) * B] = ou0; auxe[(size_t)(ROW_OU + 2 * b + 1) * B] = ou1;
+        auxe(ROW_OU + 2 * b) = ou0; auxe(ROW_OU + 2 * b + 1) = ou1;
     }
     if (is_ball) {
-        auxe[(size_t)ROW_PREV_POT * B] = prev_pot;
-        if (TASK != RSX_TASK_VSS_V0) auxe[(size_t)ROW_EP_RET * B] = ep_ret;
+        auxe(ROW_PREV_POT) = prev_pot;
+        if (TASK != RSX_TASK_VSS_V0) auxe(ROW_EP_RET) = ep_ret;
+#undef auxe
     }
     if (counts_steps) bufs.metrics[0] = steps_before + (unsigned long long)P.num_envs * (unsigned long long)n_steps;
     RSX_STAMP(6);

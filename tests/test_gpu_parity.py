@@ -828,6 +828,9 @@ def test_api_errors_are_reported_not_crashed():
     with pytest.raises(L.RsxError, match="does not match"):
         ssl.task_attach(3, 0, 0, 0)           # dribbling needs 1v4
     ssl.close()
+    # rows are addressed with 32-bit byte offsets: a batch whose state array would reach 4 GB is refused before anything is allocated
+    with pytest.raises(L.RsxError, match="4 GB"):
+        L.Sim(1, 1, 11, 11, 25, 5_000_000)    # 11v11: 249 rows x 5 M envs x 4 B
     # the two 32-bit words of the Philox counter that a caller can overrun are range-checked, not wrapped (rsx.h)
     sim = L.Sim(0, 0, 3, 3, 25, 8)
     with pytest.raises(L.RsxError, match=r"exceeds 2\^32"):
