@@ -398,8 +398,14 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
     // the sub-step loop, where the ball lane's branch is serialised with the robots' work.
     // Same place: the spin about the vertical axis decays at a constant rate to an exact stop.
     if (is_ball) ball_step_friction(P, o);
+#ifdef RSX_TIMING_SUB   // development: where a sub-step's cycles go (sub-steps 1.. only; tools/exp_substep_phases.py)
+    unsigned long long tsA = 0, tsB = 0, tsC = 0, ts0 = 0, ts1 = 0, ts2 = 0;
+#endif
 
     for (int sub = 0; sub < P.n_sub; ++sub) {
+#ifdef RSX_TIMING_SUB
+        ts0 = __builtin_readcyclecounter();
+#endif
         // ---- A: actuation + integration ----
         if (is_robot) {   // rsx_body.hpp: the per-body arithmetic is stated once for all kernel layouts
             actuate_robot<KIND>(P, o);
@@ -411,6 +417,9 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
         // (every role branch of a lane group costs a save / branch / restore of the exec mask; idle lanes hold zeros)
         o.x = fma_(o.vx, P.h, o.x);
         o.y = fma_(o.vy, P.h, o.y);
+#ifdef RSX_TIMING_SUB
+        ts1 = __builtin_readcyclecounter();
+#endif
 
         // ---- B: contacts — one Jacobi sweep over the post-integration snapshot, and a second one
         // over the corrected snapshot for the envs in which some pair overlapped by more than pen2
@@ -547,6 +556,9 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
         // SSL: every lane, no role branch (idle lanes hold zeros: inside every wall) — measured 1-3 % on the SSL tasks;
         // the VSS-v0 3v3 single-step kernel measured 1.5 % slower that way and keeps the branch
         // (SSL also: only when some body of the wave is near a wall — near_walls, rsx_body.hpp: the clamp is the identity elsewhere)
+#ifdef RSX_TIMING_SUB
+        ts2 = __builtin_readcyclecounter();
+#endif
         if (KIND == RSX_KIND_SSL ? __any(near_walls<KIND>(P, o.x, o.y)) : (is_robot || is_ball)) {
             const float vx0 = o.vx, vy0 = o.vy;
             int hit = 0;
@@ -557,7 +569,15 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
 #ifdef RSX_TIMING
         if (threadIdx.x == 0 && sh.dbg) sh.dbg[(size_t)(8 + sub) * gridDim.x + blockIdx.x] = __builtin_readcyclecounter();
 #endif
+#ifdef RSX_TIMING_SUB
+        if (sub >= 1) { const unsigned long long t3 = __builtin_readcyclecounter(); tsA += ts1 - ts0; tsB += ts2 - ts1; tsC += t3 - ts2; }
+#endif
     }
+#ifdef RSX_TIMING_SUB
+    if (threadIdx.x == 0 && sh.dbg) {
+        sh.dbg[(size_t)15 * gridDim.x + blockIdx.x] = tsA; sh.dbg[(size_t)16 * gridDim.x + blockIdx.x] = tsB; sh.dbg[(size_t)17 * gridDim.x + blockIdx.x] = tsC;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
