@@ -115,6 +115,9 @@ struct Shared {
 // Addresses into the [rows][B] arrays on the hot paths: a uniform base pointer (scalar registers) + ONE 32-bit BYTE offset per
 // lane — the global_load / global_store "saddr" form, no 64-bit vector multiply-adds and shifts per access.  The host refuses
 // batches whose arrays would reach 4 GB (rsx_api.hip: RSX_ERR_ARG at create / attach).
+#ifndef RSX_LATE_PARAMS
+#define RSX_LATE_PARAMS 1   // development A/B
+#endif
 #ifndef RSX_IX32
 #define RSX_IX32 1   // development A/B: 0 = 64-bit offsets
 #endif
@@ -1520,6 +1523,23 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
             RSX_STAMP(2);
             physics<KIND, L, NR>(P, o, b, g, live, sh);
             RSX_STAMP(3);
+#if RSX_LATE_PARAMS
+            if (MODE == MODE_STEP && (KIND == RSX_KIND_SSL || RSX_LATE_PARAMS > 1)) {
+                // Single-step launches of the SSL tasks: what the rest of the step reads of the parameter block is fetched from the kernarg
+                // segment HERE, behind an opaque pointer, instead of being loaded at the kernel's entry and parked in VGPR lanes across
+                // the physics (these kernels run out of scalar registers: ~40 v_writelane at entry, ~60 v_readlane after the physics)
+                typedef const __attribute__((address_space(4))) uint32_t* kw_t;
+                constexpr size_t KOFF = (4 * sizeof(void*) + 4 * sizeof(int) + alignof(Params) - 1) / alignof(Params) * alignof(Params);   // after RSX_HOT_ARGS
+                static_assert(sizeof(Params) % 4 == 0 && KOFF % 4 == 0, "parameter block in dwords");
+                kw_t pk = (kw_t)__builtin_amdgcn_kernarg_segment_ptr() + KOFF / 4;
+                asm volatile("" : "+s"(pk));
+                struct Words { uint32_t w[sizeof(Params) / 4]; } raw;
+#pragma unroll
+                for (size_t i = 0; i < sizeof(Params) / 4; ++i) raw.w[i] = pk[i];
+                P = __builtin_bit_cast(Params, raw);
+                P.num_envs = hp_num_envs; P.state_dim = hp_state_dim;
+            }
+#endif
 
             // ---- wire-format values, observation, reward ----
             if (is_robot) {
