@@ -17,6 +17,9 @@
 #pragma once
 #include "rsx_kernels.hpp"
 
+#ifndef RSX_QUAD_LATE_PARAMS
+#define RSX_QUAD_LATE_PARAMS 1   // development A/B
+#endif
 #ifndef RSX_QUAD_WAVES
 #define RSX_QUAD_WAVES 3   // waves per SIMD the kernel is compiled for
 #endif
@@ -467,6 +470,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
         }
     }
 
+#if RSX_QUAD_LATE_PARAMS
+    {   // what the rest of the step reads of the parameter block: fetched from the kernarg segment here instead of parked in VGPR lanes across the physics (rsx_kernels.hpp, RSX_LATE_PARAMS)
+        typedef const __attribute__((address_space(4))) uint32_t* kw_t;
+        constexpr size_t KOFF = (4 * sizeof(void*) + 4 * sizeof(int) + alignof(Params) - 1) / alignof(Params) * alignof(Params);
+        kw_t pk = (kw_t)__builtin_amdgcn_kernarg_segment_ptr() + KOFF / 4;
+        asm volatile("" : "+s"(pk));
+        struct Words { uint32_t w[sizeof(Params) / 4]; } raww;
+#pragma unroll
+        for (size_t i = 0; i < sizeof(Params) / 4; ++i) raww.w[i] = pk[i];
+        P = __builtin_bit_cast(Params, raww);
+        P.num_envs = hp_num_envs; P.state_dim = hp_state_dim;
+    }
+#endif
     // ---- wire-format values, state rows, observation ----
     if (bl) {   // episode bookkeeping: fetched now (nothing of it is live during the physics)
         steps = __float_as_int(ld(A, ROW_STEPS * B4, eo));
