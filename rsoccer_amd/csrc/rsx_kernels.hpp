@@ -129,10 +129,26 @@ typedef size_t ix_t;
 __device__ __forceinline__ float& at_byte(float* base, const ix_t off) { return *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off); }
 __device__ __forceinline__ const float& at_byte(const float* base, const ix_t off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + off); }
 
-// lanes of the env in slot g: body j sits at lane j * G + g
+// Which lane holds body j of the wave's env g (and which LDS slot: slot = lane).  Body-major (lane = j * G + g: the G lanes
+// that own "body j" of neighbouring envs are adjacent, every row access is G * 4 contiguous bytes) for L >= 16; env-major
+// (lane = g * L + j: an env's eight bodies are eight adjacent lanes, i.e. half a DPP row) for L == 8, where the all-pairs test
+// reads its partners' positions through DPP row shifts instead of an LDS round trip (RSX_ENV_MAJOR=0: body-major everywhere).
+#ifndef RSX_ENV_MAJOR
+#define RSX_ENV_MAJOR 1
+#endif
+template <int L>
+struct LaneMap {
+    static constexpr int G = 64 / L;
+    static constexpr bool EM = RSX_ENV_MAJOR != 0 && L == 8;
+    static __device__ __forceinline__ int slot(const int j, const int g) { return EM ? g * L + j : j * G + g; }
+    static __device__ __forceinline__ int body(const int lane) { return EM ? lane % L : lane / G; }
+    static __device__ __forceinline__ int env(const int lane) { return EM ? lane / L : lane % G; }
+};
+// lanes of the env in slot g
 template <int L>
 __device__ __forceinline__ unsigned long long env_lane_mask(const int g) {
     constexpr int G = 64 / L;
+    if (LaneMap<L>::EM) return ((1ull << L) - 1ull) << (g * L);
     unsigned long long m = 0;
 #pragma unroll
     for (int j = 0; j < L; ++j) m |= 1ull << (j * G);
@@ -152,7 +168,7 @@ __device__ __forceinline__ bool vss_sweep_loop(Body& o, const int N, const int g
     unsigned todo = 0;
 #pragma unroll 4
     for (int j = 0; j <= N; ++j) {
-        const float4 oj = sh.A[j * G + g];
+        const float4 oj = sh.A[LaneMap<L>::slot(j, g)];
         const bool rb = is_ball || j == N;
         const float dx = oj.x - o.x, dy = oj.y - o.y;
         const uint32_t u = __float_as_uint(fma_(dx, dx, dy * dy)) - 1u;   // own slot: 0xFFFFFFFF
@@ -166,8 +182,8 @@ __device__ __forceinline__ bool vss_sweep_loop(Body& o, const int N, const int g
     while (todo) {
         const int j = __builtin_ctz(todo);
         todo &= todo - 1;
-        const float4 oj = sh.A[j * G + g];
-        const float wj = sh.W[j * G + g];
+        const float4 oj = sh.A[LaneMap<L>::slot(j, g)];
+        const float wj = sh.W[LaneMap<L>::slot(j, g)];
         const float dx = oj.x - o.x, dy = oj.y - o.y;
         const bool rb = is_ball || j == N;
         contact_response(snap, oj, fma_(dx, dx, dy * dy), rb ? K::rs_rb : K::rs_rr, rb ? K::ope_rb : K::ope_rr,
@@ -244,7 +260,7 @@ __device__ __forceinline__ bool ssl_sweep(const Params& P, Body& o, const int N,
 #else
             float4 oth[NRX ? NRX : 1];  // all reads in flight together, one wait
 #pragma unroll
-            for (int j = 0; j < NRX; ++j) oth[j] = sh.A[j * G + g];
+            for (int j = 0; j < NRX; ++j) oth[j] = sh.A[LaneMap<L>::slot(j, g)];
 #pragma unroll
             for (int j = 0; j < NRX; ++j) {
                 float dx = oth[j].x - o.x, dy = oth[j].y - o.y;
@@ -262,7 +278,7 @@ __device__ __forceinline__ bool ssl_sweep(const Params& P, Body& o, const int N,
         } else {
 #pragma unroll 4
             for (int j = 0; j < N; ++j) {
-                const float4 oj = sh.A[j * G + g];
+                const float4 oj = sh.A[LaneMap<L>::slot(j, g)];
                 const float dx = oj.x - o.x, dy = oj.y - o.y;
                 todo |= (__float_as_uint(fma_(dx, dx, dy * dy)) - 1u) < T_RR ? 1u << j : 0u;
             }
@@ -273,8 +289,8 @@ __device__ __forceinline__ bool ssl_sweep(const Params& P, Body& o, const int N,
             // software-pipelined like the VSS walk: the next partner's slot is fetched while the current response is computed
             int jn = __builtin_ctz(todo);
             todo &= todo - 1;
-            float4 nxt = sh.A[jn * G + g];
-            float nxw = sh.W[jn * G + g];
+            float4 nxt = sh.A[LaneMap<L>::slot(jn, g)];
+            float nxw = sh.W[LaneMap<L>::slot(jn, g)];
             for (;;) {
                 const float4 oj = nxt;
                 const float wj = nxw;
@@ -282,8 +298,8 @@ __device__ __forceinline__ bool ssl_sweep(const Params& P, Body& o, const int N,
                 if (more) {
                     jn = __builtin_ctz(todo);
                     todo &= todo - 1;
-                    nxt = sh.A[jn * G + g];
-                    nxw = sh.W[jn * G + g];
+                    nxt = sh.A[LaneMap<L>::slot(jn, g)];
+                    nxw = sh.W[LaneMap<L>::slot(jn, g)];
                 }
                 const float dx = oj.x - o.x, dy = oj.y - o.y;
                 contact_response(o, oj, fma_(dx, dx, dy * dy), K::rs_rr, K::ope_rr, K::w_rr, K::kt_rr, K::mu_rr, 0.0f,
@@ -292,7 +308,7 @@ __device__ __forceinline__ bool ssl_sweep(const Params& P, Body& o, const int N,
             }
         }
         // robot - ball: kicker mouth (flat face at dck) or body circle; n points robot -> ball
-        const float4 ob = sh.A[N * G + g];
+        const float4 ob = sh.A[LaneMap<L>::slot(N, g)];
         float dx = ob.x - o.x, dy = ob.y - o.y;
         float nx = 0.0f, ny = 0.0f, pen = -1.0f;
         bool mouth = false, touch = false;
@@ -319,7 +335,7 @@ __device__ __forceinline__ bool ssl_sweep(const Params& P, Body& o, const int N,
             const float dvx = ob.z - o.vx, dvy = ob.w - o.vy;
             float vn = fma_(dvx, nx, dvy * ny);
             if (vn < 0.0f) {
-                const float omb = sh.W[N * G + g];
+                const float omb = sh.W[LaneMap<L>::slot(N, g)];
                 float q = K::ope_rb * vn * K::w_rb_r; avx = fma_(q, nx, avx); avy = fma_(q, ny, avy);
                 const float wsum = fma_(omb, K::r_ball, o.om * (mouth ? K::dck : K::r_robot));
                 const float vt = fma_(dvy, nx, -(dvx * ny)) - wsum;
@@ -394,7 +410,7 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
     const int N = NR ? NR : P.n_robots;
     const bool is_robot = live && b < N;
     const bool is_ball = live && b == N;
-    const int lane = b * G + g;
+    const int lane = LaneMap<L>::slot(b, g);
 
     // rolling resistance: a constant deceleration, applied once for the whole step() while the
     // ball is on the ground (exact stop, never reverses) — keeps the sqrt + divide chain out of
@@ -432,7 +448,7 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
         // is the env's ball low enough to be touched?  One ballot of the ball lanes' answer, each lane picks its env's bit
         // (was: the height through LDS — a write, a dependent read and its wait in every sub-step)
         const unsigned long long lowm = __ballot(is_ball && o.z < K::robot_h);
-        bool ball_low = ((lowm >> (N * G + g)) & 1ull) != 0;
+        bool ball_low = ((lowm >> (LaneMap<L>::slot(N, g))) & 1ull) != 0;
 #else
         if (is_ball) sh.zb[g] = o.z;
         bool ball_low = true;
@@ -460,7 +476,7 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
 #if !RSX_PK_SWEEP
                         float4 oth[NR + 1];  // all reads in flight together, one wait
 #pragma unroll
-                        for (int j = 0; j <= NR; ++j) oth[j] = sh.A[j * G + g];
+                        for (int j = 0; j <= NR; ++j) oth[j] = sh.A[LaneMap<L>::slot(j, g)];
 #endif
                         // Overlap test of the whole sweep, exact and with ONE compare per partner class:
                         // d2 is a sum of squares (>= +0), and non-negative floats order like their bit
@@ -508,8 +524,8 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                             // response is being computed
                             int jn = __builtin_ctz(todo);
                             todo &= todo - 1;
-                            float4 nxt = sh.A[jn * G + g];
-                            float nxw = sh.W[jn * G + g];
+                            float4 nxt = sh.A[LaneMap<L>::slot(jn, g)];
+                            float nxw = sh.W[LaneMap<L>::slot(jn, g)];
                             for (;;) {
                                 const int j = jn;
                                 const float4 oj = nxt;
@@ -518,8 +534,8 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                                 if (more) {
                                     jn = __builtin_ctz(todo);
                                     todo &= todo - 1;
-                                    nxt = sh.A[jn * G + g];
-                                    nxw = sh.W[jn * G + g];
+                                    nxt = sh.A[LaneMap<L>::slot(jn, g)];
+                                    nxw = sh.W[LaneMap<L>::slot(jn, g)];
                                 }
                                 const float dx = oj.x - o.x, dy = oj.y - o.y;
                                 const float d2 = fma_(dx, dx, dy * dy);   // the value the sweep above saw
@@ -725,7 +741,7 @@ __global__ __launch_bounds__(64) void sim_step_kernel(RSX_HOT_ARGS, const Params
     if (threadIdx.x == 0) sh.dbg = nullptr;
 #endif
     const int lane = threadIdx.x;
-    const int b = lane / G, g = lane % G;
+    const int b = LaneMap<L>::body(lane), g = LaneMap<L>::env(lane);
     const int e = tile_of_block(hp_per_xcd) * G + g;
     const int N = NR ? NR : P.n_robots;
     const bool live = e < P.num_envs;
@@ -1031,17 +1047,17 @@ __device__ __forceinline__ void place_env(const Params& P, const int N, uint32_t
     int first = 0;
     float bx, by;
     if (TASK == RSX_TASK_SSL_DRIBBLING) {  // dribbling.py:187-202: fixed course
-        A[N * G + g] = make_float4(-0.1f, 0.0f, 0.0f, 0.0f);
-        A[0 * G + g] = make_float4(0.0f, 0.0f, 180.0f, 0.0f);
-        for (int k = 1; k < 5; ++k) A[k * G + g] = make_float4(-0.5f * (float)k, 0.0f, 180.0f, 0.0f);
+        A[LaneMap<L>::slot(N, g)] = make_float4(-0.1f, 0.0f, 0.0f, 0.0f);
+        A[LaneMap<L>::slot(0, g)] = make_float4(0.0f, 0.0f, 180.0f, 0.0f);
+        for (int k = 1; k < 5; ++k) A[LaneMap<L>::slot(k, g)] = make_float4(-0.5f * (float)k, 0.0f, 180.0f, 0.0f);
         return;
     }
     if (TASK == RSX_TASK_SSL_CONTESTED) {  // contested_possession.py:203-220: the opponent holds the ball
         const float2 u = draw();
         const float ex = P.pl_xlo + P.pl_xspan * u.x, ey = P.pl_ylo + P.pl_yspan * u.y;
-        A[N * G + g] = make_float4(ex - 0.1f, ey, 0.0f, 0.0f);
-        A[0 * G + g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        A[1 * G + g] = make_float4(ex, ey, 180.0f, 0.0f);
+        A[LaneMap<L>::slot(N, g)] = make_float4(ex - 0.1f, ey, 0.0f, 0.0f);
+        A[LaneMap<L>::slot(0, g)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        A[LaneMap<L>::slot(1, g)] = make_float4(ex, ey, 180.0f, 0.0f);
         return;
     }
     if (TASK == RSX_TASK_SSL_PASS_ENDURANCE) {  // pass_endurance.py:156-185
@@ -1056,9 +1072,9 @@ __device__ __forceinline__ void place_env(const Params& P, const int N, uint32_t
             if (!(fabsf(rx - px) < 1.0f)) break;
         }
         const float ry = -py;
-        A[N * G + g] = make_float4(px, py, 0.0f, 0.0f);
-        A[0 * G + g] = make_float4(sx, sy, side > 0.0f ? 270.0f : 90.0f, 0.0f);
-        A[1 * G + g] = make_float4(rx, ry, (atan2_f32(ry - sy, rx - sx) + 3.14159265358979323846f) * KC<RSX_KIND_SSL>::rad2deg, 0.0f);
+        A[LaneMap<L>::slot(N, g)] = make_float4(px, py, 0.0f, 0.0f);
+        A[LaneMap<L>::slot(0, g)] = make_float4(sx, sy, side > 0.0f ? 270.0f : 90.0f, 0.0f);
+        A[LaneMap<L>::slot(1, g)] = make_float4(rx, ry, (atan2_f32(ry - sy, rx - sx) + 3.14159265358979323846f) * KC<RSX_KIND_SSL>::rad2deg, 0.0f);
         return;
     }
     if (TASK == RSX_TASK_SSL_STATIC_DEFENDERS) {
@@ -1069,14 +1085,14 @@ __device__ __forceinline__ void place_env(const Params& P, const int N, uint32_t
             by = P.pl_ylo + P.pl_yspan * u.y;
             if (!(bx > P.pen_x && fabsf(by) < P.half_pen_wid)) break;
         }
-        A[0 * G + g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // blue 0 at the origin
+        A[LaneMap<L>::slot(0, g)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // blue 0 at the origin
         first = 1;
     } else {
         const float2 u = draw();
         bx = P.pl_xlo + P.pl_xspan * u.x;
         by = P.pl_ylo + P.pl_yspan * u.y;
     }
-    A[N * G + g] = make_float4(bx, by, 0.0f, 0.0f);
+    A[LaneMap<L>::slot(N, g)] = make_float4(bx, by, 0.0f, 0.0f);
     for (int k = first; k < N; ++k) {
         float x = 0.0f, y = 0.0f;
         for (int t = 0; t < 64; ++t) {
@@ -1089,14 +1105,14 @@ __device__ __forceinline__ void place_env(const Params& P, const int N, uint32_t
                 if (dx * dx + dy * dy < P.pl_min_d2) ok = false;
             }
             for (int q = 0; q < k; ++q) {
-                const float4 pq = A[q * G + g];
+                const float4 pq = A[LaneMap<L>::slot(q, g)];
                 float dx = x - pq.x, dy = y - pq.y;
                 if (dx * dx + dy * dy < P.pl_min_d2) ok = false;
             }
             if (ok) break;
         }
         const float2 u = draw();
-        A[k * G + g] = make_float4(x, y, 360.0f * u.x, 0.0f);
+        A[LaneMap<L>::slot(k, g)] = make_float4(x, y, 360.0f * u.x, 0.0f);
     }
 }
 
@@ -1132,18 +1148,15 @@ __device__ __forceinline__ float4 place_env_parallel(const Params& P, const int 
             by = P.pl_ylo + P.pl_yspan * u.y;
             if (!(bx > P.pen_x && fabsf(by) < P.half_pen_wid)) break;
         }
-        if (b == 0) A[0 * G + g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // blue 0 at the origin
+        if (b == 0) A[LaneMap<L>::slot(0, g)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // blue 0 at the origin
         m = 1;
     } else {
         const float2 u = getdraw(n++);
         bx = P.pl_xlo + P.pl_xspan * u.x;
         by = P.pl_ylo + P.pl_yspan * u.y;
     }
-    // lanes of this env: body j sits at lane j * G + g
-    unsigned long long envmask = 0;
-#pragma unroll
-    for (int j = 0; j < L; ++j) envmask |= 1ull << (j * G);
-    envmask <<= g;
+    // lanes of this env: body j sits at lane LaneMap<L>::slot(j, g)
+    const unsigned long long envmask = env_lane_mask<L>(g);
     int t = 0;   // tries robot m has used
     while (m < N) {
         const bool spec = is_robot && b >= m;
@@ -1153,7 +1166,7 @@ __device__ __forceinline__ float4 place_env_parallel(const Params& P, const int 
             x = P.pl_xlo + P.pl_xspan * u.x;
             y = P.pl_ylo + P.pl_yspan * u.y;
             th = 360.0f * v.x;
-            A[b * G + g] = make_float4(x, y, th, 0.0f);
+            A[LaneMap<L>::slot(b, g)] = make_float4(x, y, th, 0.0f);
         }
         wave_sync();
         bool bad = false;
@@ -1165,7 +1178,7 @@ __device__ __forceinline__ float4 place_env_parallel(const Params& P, const int 
             if (NRC) {
                 float4 pq[NRC ? NRC : 1];
 #pragma unroll
-                for (int q = 0; q < NRC; ++q) pq[q] = A[q * G + g];
+                for (int q = 0; q < NRC; ++q) pq[q] = A[LaneMap<L>::slot(q, g)];
 #pragma unroll
                 for (int q = 0; q < NRC; ++q) {
                     float dx = x - pq[q].x, dy = y - pq[q].y;
@@ -1173,7 +1186,7 @@ __device__ __forceinline__ float4 place_env_parallel(const Params& P, const int 
                 }
             } else {
                 for (int q = 0; q < b; ++q) {
-                    const float4 pq = A[q * G + g];
+                    const float4 pq = A[LaneMap<L>::slot(q, g)];
                     float dx = x - pq.x, dy = y - pq.y;
                     if (dx * dx + dy * dy < P.pl_min_d2) bad = true;
                 }
@@ -1182,7 +1195,7 @@ __device__ __forceinline__ float4 place_env_parallel(const Params& P, const int 
         }
         wave_sync();   // the next round overwrites A
         const unsigned long long bm = __ballot(bad) & envmask;
-        const int f = bm ? (int)(__builtin_ctzll(bm) / G) : N;   // lowest failing robot
+        const int f = bm ? LaneMap<L>::body((int)__builtin_ctzll(bm)) : N;   // lowest failing robot
         if (f < N) {
             t = f == m ? t + 1 : 1;
             n += 2u * (uint32_t)(f - m) + 1u;
@@ -1269,7 +1282,7 @@ __device__ __forceinline__ void placement_helper(const Params& P, const Buffers&
     constexpr int G = 64 / L, N = NR, NBD = N + 1;
     const size_t B = (size_t)P.num_envs;
     const int lane = threadIdx.x;
-    const int b = lane / G, g = lane % G;
+    const int b = LaneMap<L>::body(lane), g = LaneMap<L>::env(lane);
     float* const pw = bufs.pcache + (size_t)(P.tick_base & 1u) * (size_t)pcache_rows<NBD>() * B;
     // one lane per env: which of this wave's 64 envs lack the poses of their next episode?
     const int e0 = helper * 64 + lane;
@@ -1348,7 +1361,7 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
         }
     }
     const int lane = threadIdx.x;
-    const int b = lane / G, g = lane % G;
+    const int b = LaneMap<L>::body(lane), g = LaneMap<L>::env(lane);
     const int tile = tile_of_block(HOT ? hp_per_xcd : (int)(gridDim.x >> 3));
     const int e = tile * G + g;
     const int N = NR ? NR : P.n_robots;
@@ -1581,7 +1594,7 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
             // episode-end flag of the env: held by its ball lane (lane N*G + g), spread with one
             // ballot instead of an LDS round trip
             const unsigned long long endm = __ballot(is_ball && (term | trunc));
-            ended = live && ((endm >> (N * G + g)) & 1ull) != 0;
+            ended = live && ((endm >> (LaneMap<L>::slot(N, g))) & 1ull) != 0;
             if (is_ball) {
                 // info is reported as it stands after this step (cleared lazily at the next
                 // episode's first step), like the dict the reference returns with `done`
@@ -1667,7 +1680,7 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
             } else {
                 if (ended && is_ball) place_env<TASK, L>(P, N, env_id, episode, g, sh.A, sh.draws[g]);
                 wave_sync();
-                if (ended && (is_robot || is_ball)) pz = sh.A[b * G + g];
+                if (ended && (is_robot || is_ball)) pz = sh.A[LaneMap<L>::slot(b, g)];
             }
             RSX_STAMP(17);
             if (ended) {
