@@ -9,11 +9,12 @@
 // Mapping (wave64):
 //   * one lane owns one rigid body (robot or ball); an env occupies a group of L lanes
 //     (L = 8 for <= 7 robots, 16, 32, or 64 = the whole wavefront) and a wave hosts G = 64/L
-//     envs.  lane = body * G + env_in_wave, so the G lanes that own "body k" of neighbouring
-//     envs are adjacent and read adjacent floats of SoA row k: every row access of a wave is
-//     G*4 contiguous bytes per body (32 B segments at L = 8), and the 6..11 rows of one body
-//     share cache lines with the neighbouring tiles handled by the SAME XCD (tile -> XCD map
-//     below), so every byte fetched into an L2 is used.
+//     envs.  L >= 16: lane = body * G + env_in_wave, so the G lanes that own "body k" of
+//     neighbouring envs are adjacent and read adjacent floats of SoA row k (G*4 contiguous bytes
+//     per body).  L = 8: lane = env_in_wave * 8 + body (LaneMap below; measured -1 % at the
+//     latency-bound batches, +2-3 % at 65 536 envs).  Either way a wave touches the same 32-byte
+//     pieces, and the 6..11 rows of one body share cache lines with the neighbouring tiles handled
+//     by the SAME XCD (tile -> XCD map below), so every byte fetched into an L2 is used.
 //   * the all-pairs contact test is a Jacobi sweep: each lane publishes (x, y, vx, vy) as one
 //     float4 in LDS and reads the other bodies' float4 back (ds_read_b128, broadcast inside a
 //     group, G distinct 16-B slots per instruction -> conflict free).  With the robot count a
