@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define RSX_ABI_VERSION 3
+#define RSX_ABI_VERSION 4
 
 /* kind: which robosim class the handle stands for (rsim.py:116 robosim.VSS, :169 robosim.SSL) */
 #define RSX_KIND_VSS 0
@@ -237,14 +237,39 @@ int rsx_task_reset_to(rsx_sim* h, const double* ball, const double* blue, const 
  * action -> commands (+ OU noise for the non-agent robots), physics, observation, reward,
  * done, TimeLimit and same-step auto-reset. */
 int rsx_task_step(rsx_sim* h, const float* actions_dev, void* stream);
-/* n consecutive random-action steps = n kernel launches issued from C (no per-step FFI cost).
- * (A hipGraph replay of the same launches was measured slower on MI355X / ROCm 7 — ~2.7 us per graph
- * node vs back-to-back eager launches — and is not offered.) */
+/* n consecutive random-action steps = n kernel launches issued from C (no per-step FFI cost). */
 int rsx_task_step_n(rsx_sim* h, int n, void* stream);
 /* n consecutive random-action steps inside ONE launch (state stays in registers between
  * steps; obs / reward / done buffers hold the values of the last step).  Same results as n single steps; the
  * library may issue it that way where that is faster (SSL 11v11 handles of >= 49 152 envs do; the crowded line-up from 196 608). */
 int rsx_task_rollout(rsx_sim* h, int n, void* stream);
+
+/* ---- hipGraph / stream capture ------------------------------------------------------------------
+ * A trainer steps once per policy action (vss_gym_base.py:72-90; the loop of the reference's README.md:116-133), and
+ * with a small policy network that loop is bound by launch overheads: the usual cure is to capture
+ * policy(obs) -> step(actions) into one hipGraph (torch.cuda.CUDAGraph) and replay it.
+ *
+ * By default the handle's step counter — the key of the per-step random draws (random actions, OU noise) and the
+ * parity of the placement cache — is a HOST count baked into each launch's arguments.  A captured launch would replay
+ * one tick for ever, so the three stepping calls REFUSE to be captured in that mode: RSX_ERR_STATE, nothing enqueued
+ * (the capture itself stays valid).
+ *
+ * rsx_task_enable_capture(h, stream) moves the counter to device memory for the rest of the handle's life (one 32-bit
+ * slot per workgroup behind the metrics vector: every workgroup of a stepping launch reads its slot and writes it back
+ * advanced, no atomics, no extra launch).  Call it once, OUTSIDE any capture, stream-ordered after the handle's earlier
+ * work.  From then on rsx_task_step / _step_n / _rollout (and rsx_task_reset) may be captured and replayed any number
+ * of times, mixed freely with eager calls; every replay advances the counter exactly as the eager call would have, so a
+ * run is bit-identical whether its steps were issued eagerly, captured, or both.  Costs nothing on handles that never
+ * call it; on handles that did, a stepping launch reads one more dword.
+ *   - the 2^32 - 1 step limit is then enforced on the device: a launch that would wrap the counter changes nothing and
+ *     sets a mark that rsx_task_tick / rsx_read_metrics report as RSX_ERR_STATE;
+ *   - rsx_task_checkpoint_save / _load carry the counter in either mode;
+ *   - RSX_DEBUG_FINITE=1 (a synchronous scan) makes captured stepping calls fail with RSX_ERR_STATE;
+ *   - calls that keep host-side state stay uncapturable and say so: rsx_step_dev_flip (buffer roles).  The raw
+ *     rsx_step_dev / rsx_reset_dev launches hold no host state and can be captured as they are. */
+int rsx_task_enable_capture(rsx_sim* h, void* stream);
+/* fused steps this handle has taken since attach (the counter above).  Device-keyed handles: synchronises `stream`. */
+int rsx_task_tick(rsx_sim* h, uint32_t* out, void* stream);
 
 /* Debugging aid: number of non-finite floats in the state rows and, with a task attached, in the
  * observations, rewards and info rows.  Synchronises `stream`.  With RSX_DEBUG_FINITE=1 in the

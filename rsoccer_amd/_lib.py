@@ -36,6 +36,7 @@ SYMBOLS = (
     "rsx_task_view_get", "rsx_task_layout", "rsx_task_placement_cache_stats", "rsx_task_reset", "rsx_task_reset_to", "rsx_task_step",
     "rsx_task_step_n", "rsx_task_rollout", "rsx_read_metrics", "rsx_metrics_fold", "rsx_check_finite",
     "rsx_task_checkpoint_size", "rsx_task_checkpoint_save", "rsx_task_checkpoint_load",
+    "rsx_task_enable_capture", "rsx_task_tick",
 )
 
 
@@ -107,7 +108,9 @@ def load():
     lib.rsx_task_checkpoint_save.argtypes = [vp, vp, C.c_size_t, vp]
     lib.rsx_task_checkpoint_load.argtypes = [vp, vp, C.c_size_t, vp]
     lib.rsx_check_finite.argtypes = [vp, C.POINTER(C.c_int64), vp]
-    if lib.rsx_abi_version() != 3:
+    lib.rsx_task_enable_capture.argtypes = [vp, vp]
+    lib.rsx_task_tick.argtypes = [vp, C.POINTER(C.c_uint32), vp]
+    if lib.rsx_abi_version() != 4:
         raise RsxError("librsx_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -350,6 +353,17 @@ class Sim:
 
     def task_rollout(self, n, stream=None):
         _chk(self._lib.rsx_task_rollout(self._h, int(n), self._stream(stream)))
+
+    def task_enable_capture(self, stream=None):
+        """rsx_task_enable_capture: move the step counter to device memory so that stepping calls can be captured into a
+        hipGraph (torch.cuda.CUDAGraph) and replayed.  Call once, outside any capture."""
+        _chk(self._lib.rsx_task_enable_capture(self._h, self._stream(stream)))
+
+    def task_tick(self, stream=None):
+        """fused steps taken since attach (rsx_task_tick)"""
+        n = C.c_uint32(0)
+        _chk(self._lib.rsx_task_tick(self._h, C.byref(n), self._stream(stream)))
+        return int(n.value)
 
     def check_finite(self, stream=None):
         """Number of non-finite floats in state / obs / reward / info (debugging aid; synchronises)."""

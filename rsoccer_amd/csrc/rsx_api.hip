@@ -21,7 +21,9 @@ void launch_vss_epl(bool rollout, const Params& P, const Buffers& b, int n_steps
 void launch_ssl_epl(int task, bool rollout, const Params& P, const Buffers& b, int n_steps, hipStream_t s);
 // rsx_big.hip: the 32-lanes-per-env kernel of the SSL 11v11 scrimmage task built for large batches
 void launch_scrimmage_big(bool rollout, const Params& P, const Buffers& b, int n_steps, hipStream_t s);
-void launch_ssl_quad(const Params& P, const Buffers& b, hipStream_t s);   // rsx_quad_ssl.hpp: four lanes per env, single-step launches
+void launch_ssl_quad(const Params& P, const Buffers& b, int n_steps, hipStream_t s);   // rsx_quad_ssl.hpp: four lanes per env, single-step launches
+int ssl_quad_grid(int num_envs);   // workgroups of those launches
+int epl_grid(int num_envs);
 }
 
 using namespace rsx;
@@ -115,7 +117,11 @@ struct rsx_sim {
     bool host_state_valid = false;
     bool host_state_cache = true;
     bool task_ready = false;   // a reset has opened the first episode
-    uint32_t tick = 0;                        // fused steps taken since attach (key of the per-step draws)
+    uint32_t tick = 0;                        // fused steps taken since attach (key of the per-step draws); stale once tick_dev is set
+    // rsx_task_enable_capture: the step counter lives in device memory (one slot per workgroup behind the metrics vector,
+    // rsx_kernels.hpp: step_tick) so that captured stepping launches advance it when a graph replays them
+    bool tick_dev = false;
+    int tick_slots = 0;                       // workgroups of the handle's largest stepping launch
 };
 
 namespace {
@@ -258,7 +264,7 @@ void launch_task_m(const rsx_sim* h, const float* actions, int n_steps, hipStrea
     }
     if (NRS <= 7 && h->NR == NRS && h->L == 16) { RSX_LAUNCH((task_step_kernel<KIND, 16, TASK, (NRS <= 7 ? NRS : 0), MODE>), h->P, b, n_steps); return; }
     if (TASK == RSX_TASK_SSL_SCRIMMAGE && h->NR == 22 && h->L == 32) {   // 11v11: robot count known at compile time
-        if (h->quad && MODE == MODE_STEP) { launch_ssl_quad(h->P, b, s); return; }
+        if (h->quad && MODE == MODE_STEP) { launch_ssl_quad(h->P, b, n_steps, s); return; }
         if (h->big && (MODE == MODE_STEP || MODE == MODE_ROLLOUT)) { launch_scrimmage_big(MODE == MODE_ROLLOUT, h->P, b, n_steps, s); return; }
         RSX_LAUNCH((task_step_kernel<KIND, 32, TASK, (TASK == RSX_TASK_SSL_SCRIMMAGE ? 22 : 0), MODE>), h->P, b, n_steps);
         return;
@@ -278,7 +284,7 @@ void launch_task_m(const rsx_sim* h, const float* actions, int n_steps, hipStrea
 template <int KIND, int TASK, int NRS>
 void launch_task_k(const rsx_sim* h, const float* actions, int n_steps, int mode, hipStream_t s) {
     switch (mode) {
-        case MODE_STEP: launch_task_m<KIND, TASK, NRS, MODE_STEP>(h, actions, 1, s); break;
+        case MODE_STEP: launch_task_m<KIND, TASK, NRS, MODE_STEP>(h, actions, n_steps, s); break;   // n_steps = 1 | flags
         case MODE_ROLLOUT: launch_task_m<KIND, TASK, NRS, MODE_ROLLOUT>(h, nullptr, n_steps, s); break;
         case MODE_RESET: launch_task_m<KIND, TASK, NRS, MODE_RESET>(h, nullptr, 1, s); break;
         default: launch_task_m<KIND, TASK, NRS, MODE_REFRESH>(h, nullptr, 1, s); break;
@@ -298,7 +304,7 @@ void launch_fixed_m(const rsx_sim* h, const float* actions, int n_steps, hipStre
 template <int TASK, int NRS>
 void launch_fixed(const rsx_sim* h, const float* actions, int n_steps, int mode, hipStream_t s) {
     switch (mode) {
-        case MODE_STEP: launch_fixed_m<TASK, NRS, MODE_STEP>(h, actions, 1, s); break;
+        case MODE_STEP: launch_fixed_m<TASK, NRS, MODE_STEP>(h, actions, n_steps, s); break;
         case MODE_ROLLOUT: launch_fixed_m<TASK, NRS, MODE_ROLLOUT>(h, nullptr, n_steps, s); break;
         case MODE_RESET: launch_fixed_m<TASK, NRS, MODE_RESET>(h, nullptr, 1, s); break;
         default: launch_fixed_m<TASK, NRS, MODE_REFRESH>(h, nullptr, 1, s); break;
@@ -315,6 +321,29 @@ void launch_task(const rsx_sim* h, const float* actions, int n_steps, int mode, 
             launch_task_k<RSX_KIND_SSL, RSX_TASK_SSL_SCRIMMAGE, 22>(h, actions, n_steps, mode, s); break;
         default: launch_fixed<RSX_TASK_SSL_PASS_ENDURANCE, 2>(h, actions, n_steps, mode, s); break;
     }
+}
+
+// workgroups of the handle's stepping launches (MODE_STEP / MODE_ROLLOUT), mirroring the dispatch above: what the
+// per-workgroup tick slots of a device-keyed handle are sized and kept in sync by (rsx_kernels.hpp: step_tick)
+int step_grid(const rsx_sim* h, int mode) {
+    const int B = h->P.num_envs;
+    if (h->epl) return epl_grid(B);
+    if (h->quad && mode == MODE_STEP) return ssl_quad_grid(B);
+    int g = (int)grid_for(h).x;
+    if (mode == MODE_STEP && h->d_pcache) g += (B + 63) / 64;   // placement helpers behind the tiles
+    return g;
+}
+uint32_t* tick_words(const rsx_sim* h) { return reinterpret_cast<uint32_t*>(h->d_metrics); }
+
+// slots [from, to) := value, or := slot 0 (copy != 0).  Stream-ordered between two stepping launches.
+__global__ void tick_fill_kernel(uint32_t* __restrict__ slots, int from, int to, uint32_t value, int copy) {
+    const int i = from + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < to) slots[i] = copy ? __atomic_load_n(&slots[0], __ATOMIC_RELAXED) : value;
+}
+void tick_fill(const rsx_sim* h, int from, int to, uint32_t value, int copy, hipStream_t s) {
+    if (to <= from) return;
+    hipLaunchKernelGGL(tick_fill_kernel, dim3((unsigned)((to - from + 255) / 256)), dim3(256), 0, s,
+                       tick_words(h) + TICK_SLOT_WORD0, from, to, value, copy);
 }
 
 // Makes the handle's device current for the duration of one API call and puts the caller's device
@@ -427,6 +456,9 @@ static int check_finite_impl(rsx_sim* h, int64_t* n_bad, hipStream_t s) {
 static int debug_finite(rsx_sim* h, hipStream_t s, const char* where) {
     static const bool on = std::getenv("RSX_DEBUG_FINITE") != nullptr && std::getenv("RSX_DEBUG_FINITE")[0] == '1';
     if (!on) return RSX_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) (void)hipGetLastError();
+    else if (cs != hipStreamCaptureStatusNone) return fail(RSX_ERR_STATE, "RSX_DEBUG_FINITE=1 scans synchronously and cannot run inside a stream capture");
     int64_t bad = 0;
     if (int rc = check_finite_impl(h, &bad, s)) return rc;
     if (bad) return fail(RSX_ERR_STATE, std::string("RSX_DEBUG_FINITE: ") + std::to_string(bad) + " non-finite value(s) after " + where);
@@ -653,6 +685,11 @@ int rsx_step_dev_random(rsx_sim* h, int n, uint64_t seed, uint32_t first_tick, v
 
 int rsx_step_dev_flip(rsx_sim* h, void* stream) {
     RSX_ENTER(h);
+    {   // which buffer is current is host state: a replayed graph would keep writing the same one
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)stream, &cs) != hipSuccess) (void)hipGetLastError();
+        else if (cs != hipStreamCaptureStatusNone) return fail(RSX_ERR_STATE, "rsx_step_dev_flip cannot be captured (the buffer roles are host state); capture rsx_step_dev instead");
+    }
     if (int rc = ensure_alt(h)) return rc;
     h->host_state_valid = false;
     launch_sim(h, (hipStream_t)stream, h->d_state_alt);
@@ -692,7 +729,9 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
     const size_t n_obs = align_up(B * P.obs_dim * sizeof(float));
     const size_t n_flags = align_up(2 * B);
     const size_t n_act = align_up(B * h->M.act_dim * sizeof(float));
-    const size_t n_met = align_up(RSX_METRICS * sizeof(unsigned long long));
+    // metrics[8] | error word | (256 bytes in) one step-counter slot per workgroup of the largest stepping launch any layout
+    // of this batch could use (rsx_kernels.hpp: step_tick; only the first tick_slots are kept in sync)
+    const size_t n_met = align_up((size_t)TICK_SLOT_WORD0 * 4 + ((size_t)grid_for(h).x + (B + 63) / 64) * sizeof(uint32_t));
     const size_t n_slots = align_up((size_t)MSLOTS * RSX_METRICS * sizeof(unsigned long long));
     // placement cache: static defenders 1v6 (short episodes: several resetting waves per launch) at latency-bound batches
     const bool pc = !std::getenv("RSX_NO_PCACHE") && h->L == 8 && P.num_envs <= RSX_PCACHE_MAX_ENVS && P.n_sub > 0 &&
@@ -747,7 +786,40 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
         if (rows * (size_t)P.num_envs * sizeof(float) >= ((size_t)1 << 31) || (size_t)P.num_envs * P.obs_dim * sizeof(float) >= ((size_t)1 << 31)) h->epl = false;
     }
     h->task_ready = false;
+    h->tick_dev = false;
+    h->tick_slots = step_grid(h, MODE_STEP);
     HIP_TRY(hipDeviceSynchronize());   // null-stream memsets done before any caller stream steps
+    return RSX_OK;
+}
+
+int rsx_task_enable_capture(rsx_sim* h, void* stream) {
+    RSX_ENTER_TASK(h);
+    if (h->tick_dev) return RSX_OK;
+    hipStream_t s = (hipStream_t)stream;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) (void)hipGetLastError();
+    else if (cs != hipStreamCaptureStatusNone)
+        return fail(RSX_ERR_STATE, "rsx_task_enable_capture must be called BEFORE the capture begins (it writes the step counter once; a captured write would reset it on every replay)");
+    tick_fill(h, 0, h->tick_slots, h->tick, 0, s);
+    HIP_TRY(hipGetLastError());
+    h->tick_dev = true;
+    h->host_state_cache = false; h->host_state_valid = false;   // a replayed graph changes the state without passing through this API
+    return RSX_OK;
+}
+
+int rsx_task_tick(rsx_sim* h, uint32_t* out, void* stream) {
+    RSX_ENTER(h);
+    if (!out) return fail(RSX_ERR_ARG, "out is null");
+    if (h->P.task == RSX_TASK_NONE) return fail(RSX_ERR_STATE, "no task attached (rsx_task_attach)");
+    if (!h->tick_dev) { *out = h->tick; return RSX_OK; }
+    uint32_t w[2] = {0, 0};   // slot 0, error word
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(&w[0], tick_words(h) + TICK_SLOT_WORD0, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&w[1], tick_words(h) + TICK_ERR_WORD, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *out = w[0];
+    h->tick = w[0];
+    if (w[1]) return fail(RSX_ERR_STATE, "step counter exhausted: a launch that would have wrapped it was refused on the device (a handle takes at most 2^32 - 1 fused steps)");
     return RSX_OK;
 }
 
@@ -811,15 +883,33 @@ int rsx_task_reset_to(rsx_sim* h, const double* ball, const double* blue, const 
 
 // The handle's step counter keys the per-step random draws and is one 32-bit word of the Philox counter: a handle that
 // has taken 2^32 - 1 fused steps refuses further ones instead of silently replaying its random streams.
-#define RSX_NEED_TICKS(h, n) do { if ((uint64_t)(h)->tick + (uint64_t)(n) > 0xFFFFFFFFull) \
-    return fail(RSX_ERR_STATE, "step counter exhausted: a handle takes at most 2^32 - 1 fused steps (it keys the per-step random draws); attach a fresh handle with another seed"); } while (0)
+// Host-keyed handles (the default) check that here and bake the count into the launch — which is why they refuse to be
+// captured: a replayed graph would step with one tick for ever.  Device-keyed handles (rsx_task_enable_capture) pass
+// RSX_TICK_DEV instead: the kernels read, check and advance the counter themselves (rsx_kernels.hpp: step_tick).
+static int step_prologue(rsx_sim* h, hipStream_t s, uint64_t n, int* flags) {
+    *flags = 0;
+    if (h->tick_dev) { *flags = RSX_TICK_DEV; return RSX_OK; }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) (void)hipGetLastError();   // (e.g. the legacy stream while another one captures: the launch reports it)
+    else if (cs != hipStreamCaptureStatusNone)
+        return fail(RSX_ERR_STATE, "this stream is being captured, and the handle's step counter (the key of its per-step random draws) is still a host-side "
+                                   "launch argument: a replayed graph would repeat one random stream. Call rsx_task_enable_capture(h, stream) once, before the capture begins");
+    if ((uint64_t)h->tick + n > 0xFFFFFFFFull)
+        return fail(RSX_ERR_STATE, "step counter exhausted: a handle takes at most 2^32 - 1 fused steps (it keys the per-step random draws); attach a fresh handle with another seed");
+    return RSX_OK;
+}
+// device-keyed handles: slots the launch did not cover (a grid without the placement helpers) follow slot 0
+static void tick_resync(const rsx_sim* h, int mode, hipStream_t s) {
+    if (h->tick_dev) tick_fill(h, step_grid(h, mode), h->tick_slots, 0u, 1, s);
+}
 
 int rsx_task_step(rsx_sim* h, const float* actions_dev, void* stream) {
     RSX_ENTER_TASK(h);
     RSX_NEED_RESET(h);
-    RSX_NEED_TICKS(h, 1);
+    int fl = 0;
+    if (int rc = step_prologue(h, (hipStream_t)stream, 1, &fl)) return rc;
     h->P.tick_base = h->tick++;
-    launch_task(h, actions_dev, 1, MODE_STEP, (hipStream_t)stream);
+    launch_task(h, actions_dev, 1 | fl, MODE_STEP, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return debug_finite(h, (hipStream_t)stream, "rsx_task_step");
 }
@@ -828,8 +918,9 @@ int rsx_task_step_n(rsx_sim* h, int n, void* stream) {
     RSX_ENTER_TASK(h);
     RSX_NEED_RESET(h);
     if (n < 1) return fail(RSX_ERR_ARG, "n must be >= 1");
-    RSX_NEED_TICKS(h, n);
-    for (int i = 0; i < n; ++i) { h->P.tick_base = h->tick++; launch_task(h, nullptr, 1, MODE_STEP, (hipStream_t)stream); }
+    int fl = 0;
+    if (int rc = step_prologue(h, (hipStream_t)stream, (uint64_t)n, &fl)) return rc;
+    for (int i = 0; i < n; ++i) { h->P.tick_base = h->tick++; launch_task(h, nullptr, 1 | fl, MODE_STEP, (hipStream_t)stream); }
     HIP_TRY(hipGetLastError());
     return debug_finite(h, (hipStream_t)stream, "rsx_task_step_n");
 }
@@ -837,17 +928,20 @@ int rsx_task_step_n(rsx_sim* h, int n, void* stream) {
 int rsx_task_rollout(rsx_sim* h, int n, void* stream) {
     RSX_ENTER_TASK(h);
     RSX_NEED_RESET(h);
-    if (n < 0) return fail(RSX_ERR_ARG, "n must be >= 0");  // 0 = load + store only (profiling)
-    RSX_NEED_TICKS(h, n);
-    if (h->quad && n >= 1 && h->P.num_envs >= (h->P.task == RSX_TASK_SSL_SCRIMMAGE ? RSX_QUAD_ROLLOUT_MIN_ENVS : RSX_QUAD_ROLLOUT_MIN_ENVS_CROWDED)) {
+    if (n < 0 || n > RSX_N_STEPS_MASK) return fail(RSX_ERR_ARG, "n must be in 0 .. 2^30 - 1");  // 0 = load + store only (profiling)
+    int fl = 0;
+    if (int rc = step_prologue(h, (hipStream_t)stream, (uint64_t)n, &fl)) return rc;
+    // (a device-keyed four-lane handle always takes the first form: all of its stepping launches then share one grid)
+    if (h->quad && n >= 1 && (h->tick_dev || h->P.num_envs >= (h->P.task == RSX_TASK_SSL_SCRIMMAGE ? RSX_QUAD_ROLLOUT_MIN_ENVS : RSX_QUAD_ROLLOUT_MIN_ENVS_CROWDED))) {
         // 11v11 at large batches: n launches of the four-lanes-per-env kernel beat one launch of the 32-lane kernel
         // (262 144 envs, us per step: spread 182 vs 275, crowded 298 vs 340; crowded 131 072: 161 vs 164); same steps, same results
-        for (int i = 0; i < n; ++i) { h->P.tick_base = h->tick++; launch_task(h, nullptr, 1, MODE_STEP, (hipStream_t)stream); }
+        for (int i = 0; i < n; ++i) { h->P.tick_base = h->tick++; launch_task(h, nullptr, 1 | fl, MODE_STEP, (hipStream_t)stream); }
         HIP_TRY(hipGetLastError());
         return debug_finite(h, (hipStream_t)stream, "rsx_task_rollout");
     }
     h->P.tick_base = h->tick; h->tick += (uint32_t)n;
-    launch_task(h, nullptr, n, MODE_ROLLOUT, (hipStream_t)stream);
+    launch_task(h, nullptr, n | fl, MODE_ROLLOUT, (hipStream_t)stream);
+    tick_resync(h, MODE_ROLLOUT, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return debug_finite(h, (hipStream_t)stream, "rsx_task_rollout");
 }
@@ -912,7 +1006,10 @@ int rsx_task_checkpoint_save(rsx_sim* h, void* blob, size_t bytes, void* stream)
     HIP_TRY(hipMemcpyAsync(p, h->d_final_obs, k.obs_bytes, hipMemcpyDeviceToHost, s)); p += k.obs_bytes;
     HIP_TRY(hipMemcpyAsync(p, h->d_flags, k.flag_bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(k.metrics, h->d_metrics, sizeof(k.metrics), hipMemcpyDeviceToHost, s));
+    if (h->tick_dev)   // device-keyed handle: the step counter is slot 0 of the per-workgroup slots (all equal between launches)
+        HIP_TRY(hipMemcpyAsync(&k.tick, tick_words(h) + TICK_SLOT_WORD0, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (h->tick_dev) h->tick = k.tick;
     std::memcpy(blob, &k, sizeof(k));
     if (h->P.task == RSX_TASK_VSS_V0) {
         // The task scalar of VSS-v0 (previous ball potential, vss_gym.py:256-283) is a function of the ball position
@@ -960,6 +1057,11 @@ int rsx_task_checkpoint_load(rsx_sim* h, const void* blob, size_t bytes, void* s
     HIP_TRY(hipMemcpyAsync(h->d_flags, p, k.flag_bytes, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemsetAsync(h->d_mslots, 0, (size_t)MSLOTS * RSX_METRICS * sizeof(unsigned long long), s));
     HIP_TRY(hipMemcpyAsync(h->d_metrics, k.metrics, sizeof(k.metrics), hipMemcpyHostToDevice, s));
+    if (h->tick_dev) {   // device-keyed handle: every slot takes the blob's step counter; a refused-launch mark is cleared with it
+        tick_fill(h, 0, h->tick_slots, k.tick, 0, s);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemsetAsync(tick_words(h) + TICK_ERR_WORD, 0, sizeof(uint32_t), s));
+    }
     HIP_TRY(hipStreamSynchronize(s));
     h->tick = k.tick;
     h->task_ready = true;
@@ -983,7 +1085,10 @@ int rsx_read_metrics(rsx_sim* h, int64_t out[RSX_METRICS], void* stream) {
     hipLaunchKernelGGL(fold_metrics_kernel, dim3(1), dim3(64), 0, s, h->d_metrics, h->d_mslots);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, h->d_metrics, RSX_METRICS * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    uint32_t refused = 0;
+    if (h->tick_dev) HIP_TRY(hipMemcpyAsync(&refused, tick_words(h) + TICK_ERR_WORD, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (refused) return fail(RSX_ERR_STATE, "step counter exhausted: stepping launches of this device-keyed handle were refused on the device (out[] is valid; a handle takes at most 2^32 - 1 fused steps)");
     return RSX_OK;
 }
 

@@ -12,13 +12,18 @@
 
 namespace rsx {
 
+int ssl_quad_grid(int num_envs);
+int epl_grid(int num_envs);
+
 // development knob: RSX_EPL_LDS_PAD=<bytes> of dynamic LDS per workgroup limit the waves per CU (occupancy
 // sensitivity measurements); 0 in production
 // tile order of a single-step launch: alternates with the step counter (tile_of_block_zigzag, rsx_kernels.hpp);
 // RSX_EPL_ZIGZAG=0 keeps one direction (development A/B)
-static int step_per_xcd(const Params& P, const dim3& grid) {
+// (device-keyed launches — n_steps carries RSX_TICK_DEV — cannot be told the parity: a negative `per` asks the kernel to alternate)
+static int step_per_xcd(const Params& P, const dim3& grid, const int n_steps) {
     static const bool zig = !(std::getenv("RSX_EPL_ZIGZAG") && std::atoi(std::getenv("RSX_EPL_ZIGZAG")) == 0);
     const int per = (int)(grid.x >> 3);
+    if (n_steps & RSX_TICK_DEV) return zig ? -per : per;
     return (zig && (P.tick_base & 1u)) ? -per : per;
 }
 
@@ -39,7 +44,7 @@ void launch_vss_epl(bool rollout, const Params& P, const Buffers& b, int n_steps
                            P.num_envs, P.state_dim, (int)(grid.x >> 3), n_steps, P, b);
     else
         hipLaunchKernelGGL((vss_epl_kernel<MODE_STEP>), grid, dim3(64), epl_lds_pad(), s, b.state, b.aux, b.actions, b.flags,
-                           P.num_envs, P.state_dim, step_per_xcd(P, grid), n_steps, P, b);
+                           P.num_envs, P.state_dim, step_per_xcd(P, grid, n_steps), n_steps, P, b);
 }
 
 template <int TASK>
@@ -59,19 +64,22 @@ static void launch_ssl_epl_t(bool rollout, const Params& P, const Buffers& b, in
                                      : TASK == RSX_TASK_SSL_CONTESTED || (TASK == RSX_TASK_SSL_STATIC_DEFENDERS && P.num_envs < RSX_SD_LEAN_MAX_ENVS);
         if (lean && (TASK == RSX_TASK_SSL_CONTESTED || TASK == RSX_TASK_SSL_STATIC_DEFENDERS))
             hipLaunchKernelGGL((ssl_epl_kernel<TASK, MODE_STEP, (TASK == RSX_TASK_SSL_CONTESTED || TASK == RSX_TASK_SSL_STATIC_DEFENDERS)>), grid, dim3(64), 0, s,
-                               b.state, b.aux, b.actions, b.flags, P.num_envs, P.state_dim, step_per_xcd(P, grid), n_steps, P, b);
+                               b.state, b.aux, b.actions, b.flags, P.num_envs, P.state_dim, step_per_xcd(P, grid, n_steps), n_steps, P, b);
         else
             hipLaunchKernelGGL((ssl_epl_kernel<TASK, MODE_STEP>), grid, dim3(64), 0, s, b.state, b.aux, b.actions, b.flags,
-                               P.num_envs, P.state_dim, step_per_xcd(P, grid), n_steps, P, b);
+                               P.num_envs, P.state_dim, step_per_xcd(P, grid, n_steps), n_steps, P, b);
     }
 }
 
-void launch_ssl_quad(const Params& P, const Buffers& b, hipStream_t s) {   // SSL 11v11 scrimmage, four lanes per env, single-step launches
-    const int tiles = (P.num_envs + Q_ENVS - 1) / Q_ENVS;
-    const dim3 grid((unsigned)(((tiles + 7) / 8) * 8));
+void launch_ssl_quad(const Params& P, const Buffers& b, int n_steps, hipStream_t s) {   // SSL 11v11 scrimmage, four lanes per env, single-step launches (n_steps = 1 | flags)
+    const dim3 grid((unsigned)ssl_quad_grid(P.num_envs));
     hipLaunchKernelGGL((ssl_quad_kernel<MODE_STEP>), grid, dim3(64), 0, s, b.state, b.aux, b.actions, b.flags,
-                       P.num_envs, P.state_dim, step_per_xcd(P, grid), 1, P, b);
+                       P.num_envs, P.state_dim, step_per_xcd(P, grid, n_steps), n_steps, P, b);
 }
+
+// workgroups of a launch (the host sizes the per-workgroup tick slots from these: rsx_kernels.hpp, step_tick)
+int ssl_quad_grid(int num_envs) { const int tiles = (num_envs + Q_ENVS - 1) / Q_ENVS; return ((tiles + 7) / 8) * 8; }
+int epl_grid(int num_envs) { const int tiles = (num_envs + 63) / 64; return ((tiles + 7) / 8) * 8; }
 
 void launch_ssl_epl(int task, bool rollout, const Params& P, const Buffers& b, int n_steps, hipStream_t s) {
     switch (task) {

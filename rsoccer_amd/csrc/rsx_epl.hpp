@@ -68,10 +68,15 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
     constexpr int ID = T::info_dim;
     Params P = P_; P.num_envs = hp_num_envs; P.state_dim = hp_state_dim;
     Buffers bufs = bufs_; bufs.state = hp_state; bufs.aux = hp_aux; bufs.actions = hp_in; bufs.flags = hp_flags;
-    const int n_steps = MODE == MODE_ROLLOUT ? hp_n_steps : 1;
+    const int n_steps = MODE == MODE_ROLLOUT ? (hp_n_steps & RSX_N_STEPS_MASK) : 1;
     __shared__ EplShared sh;
     const int lane = threadIdx.x;
-    const int tile = tile_of_block_zigzag(hp_per_xcd);
+    // step counter of this launch (rsx_kernels.hpp: step_tick).  Device-keyed launches also pick the tile direction here
+    // (the host cannot: it does not know the tick's parity), host-keyed ones get it as the sign of hp_per_xcd
+    const bool tick_dev = (hp_n_steps & RSX_TICK_DEV) != 0;
+    const StepTick tk = step_tick(tick_dev, P, bufs, (uint32_t)n_steps);
+    if (__builtin_expect(!tk.ok, 0)) return;
+    const int tile = tile_of_block_zigzag(zigzag_per(tick_dev, tk.t, hp_per_xcd));
     const int e_raw = tile * 64 + lane;
     const bool live = e_raw < P.num_envs;
     // lanes beyond the batch shadow its last env: every load is valid and unconditional (no branch per load),
@@ -148,7 +153,7 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
     float reward = 0.0f; int term = 0, trunc = 0;
 
     for (int it = 0; it < n_steps; ++it) {
-        const uint32_t t = P.tick_base + (uint32_t)it;   // see task_step_kernel
+        const uint32_t t = tk.t + (uint32_t)it;   // see task_step_kernel
         if (STEP || it == 0) {
             // The previous ball potential (vss_gym.py:256-283) is the potential of the ball where this step
             // finds it: the same expression on the same floats as last step's, so the same number as the one

@@ -62,10 +62,13 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
     constexpr bool LATE = LEAN;
     Params P = P_; P.num_envs = hp_num_envs; P.state_dim = hp_state_dim;
     Buffers bufs = bufs_; bufs.state = hp_state; bufs.aux = hp_aux; bufs.actions = hp_in; bufs.flags = hp_flags;
-    const int n_steps = MODE == MODE_ROLLOUT ? hp_n_steps : 1;
+    const int n_steps = MODE == MODE_ROLLOUT ? (hp_n_steps & RSX_N_STEPS_MASK) : 1;
     __shared__ SeplShared<N> sh;
     const int lane = threadIdx.x;
-    const int tile = tile_of_block_zigzag(hp_per_xcd);
+    const bool tick_dev = (hp_n_steps & RSX_TICK_DEV) != 0;   // step counter of this launch: rsx_kernels.hpp, step_tick
+    const StepTick tk = step_tick(tick_dev, P, bufs, (uint32_t)n_steps);
+    if (__builtin_expect(!tk.ok, 0)) return;
+    const int tile = tile_of_block_zigzag(zigzag_per(tick_dev, tk.t, hp_per_xcd));
     const int e_raw = tile * 64 + lane;
     int live_i = e_raw < P.num_envs ? 1 : 0;
     asm volatile("" : "+v"(live_i));   // decided here: one flag through the step, not the index it is made of
@@ -141,7 +144,7 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
 
     for (int it = 0; it < n_steps; ++it) {
         bool first_step = steps == 0;
-        const uint32_t t = P.tick_base + (uint32_t)it;   // see task_step_kernel
+        const uint32_t t = tk.t + (uint32_t)it;   // see task_step_kernel
         if (!LATE && first_step) {
 #pragma unroll
             for (int i = 0; i < 10; ++i) info[i] = 0.0f;

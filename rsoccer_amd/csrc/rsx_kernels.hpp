@@ -712,6 +712,12 @@ __device__ __forceinline__ int tile_of_block_zigzag(const int per_signed) {
     const int q = blockIdx.x >> 3;
     return (blockIdx.x & 7) * per + (per_signed < 0 ? per - 1 - q : q);
 }
+// who picks the direction: host-keyed launches get it as the sign of `per` (the launcher negates it on odd ticks);
+// device-keyed launches (step_tick below) get a negative `per` for "alternate" and decide from the tick they read
+__device__ __forceinline__ int zigzag_per(const bool dev, const uint32_t tick, const int per_signed) {
+    if (!dev || per_signed >= 0) return per_signed;
+    return (tick & 1u) ? per_signed : -per_signed;
+}
 
 // Kernel arguments.  The first twelve dwords are plain pointers / ints so that the command
 // processor PRELOADS them into SGPRs (-amdgpu-kernarg-preload-count=12, gfx940+): what the first
@@ -788,6 +794,38 @@ __global__ __launch_bounds__(64) void sim_step_kernel(RSX_HOT_ARGS, const Params
 constexpr int MSLOTS = 256;
 __device__ __forceinline__ unsigned long long* metric_slot(const Buffers& b) {
     return b.mslots + (size_t)(blockIdx.x & (MSLOTS - 1)) * RSX_METRICS;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The step counter that keys the per-step random draws (and the parity of the placement cache).
+//
+// Host-keyed (default): the host counts the stepping launches of a handle and passes the count as Params::tick_base.
+// That value is baked into the launch — a hipGraph that captured the launch would replay ONE tick for ever.
+// Device-keyed (rsx_task_enable_capture; flagged by RSX_TICK_DEV in the n_steps argument, a preloaded SGPR): the
+// counter lives in device memory, one 32-bit slot PER WORKGROUP behind the metrics vector.  Workgroup b reads slot b
+// and writes slot b + n back; launches of a handle are stream-ordered, nobody else touches that slot, so this needs no
+// atomic and cannot race with late-starting workgroups of the same launch (a single shared word could: a workgroup
+// that starts after another one finished would read the next launch's tick).  All slots of a handle hold the same
+// value between launches (the host re-syncs the slots a smaller grid did not cover, rsx_api.hip: tick_resync).
+// A counter about to wrap refuses the launch: every workgroup sees the same value, sets the error word and returns
+// before touching any state (rsx.h: "checked, never wrapped").
+// ---------------------------------------------------------------------------------------------
+constexpr int RSX_TICK_DEV = 1 << 30;        // flag bit of the n_steps kernel argument
+constexpr int RSX_N_STEPS_MASK = RSX_TICK_DEV - 1;
+constexpr int TICK_ERR_WORD = 18;            // uint32 index behind metrics[0]: bytes 72..75
+constexpr int TICK_SLOT_WORD0 = 64;          // uint32 index of slot 0: 256 bytes behind metrics[0]
+struct StepTick { uint32_t t; bool ok; };
+__device__ __forceinline__ StepTick step_tick(const bool dev, const Params& P, const Buffers& bufs, const uint32_t n) {
+    if (!dev) return StepTick{P.tick_base, true};
+    uint32_t* const w = reinterpret_cast<uint32_t*>(bufs.metrics);
+    uint32_t* const slot = w + TICK_SLOT_WORD0 + blockIdx.x;
+    const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)__atomic_load_n(slot, __ATOMIC_RELAXED));
+    if (t > 0xFFFFFFFFu - n) {
+        if (threadIdx.x == 0) w[TICK_ERR_WORD] = 1u;
+        return StepTick{t, false};
+    }
+    if (threadIdx.x == 0) __atomic_store_n(slot, t + n, __ATOMIC_RELAXED);
+    return StepTick{t, true};
 }
 
 // observation entries owned by this lane -> staging row of its env; values are the WIRE-format
@@ -1278,13 +1316,13 @@ template <int NB>
 __host__ __device__ constexpr int pcache_rows() { return 3 * NB + 1; }
 
 template <int KIND, int L, int TASK, int NR>
-__device__ __forceinline__ void placement_helper(const Params& P, const Buffers& bufs, const int helper, Shared<L>& sh) {
+__device__ __forceinline__ void placement_helper(const Params& P, const Buffers& bufs, const int helper, const uint32_t tick, Shared<L>& sh) {
     static_assert(L == 8 && NR > 0, "the placement cache serves the 8-lane kernels of the fixed team sizes");
     constexpr int G = 64 / L, N = NR, NBD = N + 1;
     const size_t B = (size_t)P.num_envs;
     const int lane = threadIdx.x;
     const int b = LaneMap<L>::body(lane), g = LaneMap<L>::env(lane);
-    float* const pw = bufs.pcache + (size_t)(P.tick_base & 1u) * (size_t)pcache_rows<NBD>() * B;
+    float* const pw = bufs.pcache + (size_t)(tick & 1u) * (size_t)pcache_rows<NBD>() * B;
     // one lane per env: which of this wave's 64 envs lack the poses of their next episode?
     const int e0 = helper * 64 + lane;
     uint32_t ep_next = 0;
@@ -1342,9 +1380,16 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
         P.num_envs = hp_num_envs; P.state_dim = hp_state_dim;
         bufs.state = hp_state; bufs.aux = hp_aux; bufs.actions = hp_in; bufs.flags = hp_flags;
     }
-    const int n_steps_arg = hp_n_steps;
+    const int n_steps_arg = hp_n_steps & RSX_N_STEPS_MASK;
     constexpr int mode = MODE == MODE_ROLLOUT ? MODE_STEP : MODE;
     const int n_steps = MODE == MODE_ROLLOUT ? n_steps_arg : 1;
+    // the step counter of this launch (see step_tick): every workgroup — tiles, idle tail, placement helpers — takes part
+    StepTick tk{0u, true};
+    if (MODE == MODE_STEP || MODE == MODE_ROLLOUT) {
+        tk = step_tick((hp_n_steps & RSX_TICK_DEV) != 0, P, bufs, (uint32_t)n_steps);
+        if (__builtin_expect(!tk.ok, 0)) return;
+    }
+    const uint32_t tick0 = tk.t;
     using K = KC<KIND>;
     using T = TC<TASK>;
     constexpr int G = 64 / L;
@@ -1357,7 +1402,7 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
     constexpr bool PC = MODE == MODE_STEP && L == 8 && TASK == RSX_TASK_SSL_STATIC_DEFENDERS && NR == 7;
     if constexpr (PC) {
         if (__builtin_expect(bufs.pcache != nullptr && (int)blockIdx.x >= hp_per_xcd * 8, 0)) {   // a helper workgroup (behind the tiles)
-            placement_helper<KIND, L, TASK, (PC ? NR : 1)>(P, bufs, (int)blockIdx.x - hp_per_xcd * 8, sh);
+            placement_helper<KIND, L, TASK, (PC ? NR : 1)>(P, bufs, (int)blockIdx.x - hp_per_xcd * 8, tick0, sh);
             return;
         }
     }
@@ -1443,7 +1488,7 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
         pc_on = bufs.pcache != nullptr;
         if (pc_on && (is_robot || is_ball)) {
             constexpr int NBD = (PC ? NR : 1) + 1;
-            const float* const pr = bufs.pcache + (size_t)((P.tick_base + 1u) & 1u) * (size_t)pcache_rows<NBD>() * B;
+            const float* const pr = bufs.pcache + (size_t)((tick0 + 1u) & 1u) * (size_t)pcache_rows<NBD>() * B;
             pcx = pr[(size_t)(0 * NBD + b) * B + e]; pcy = pr[(size_t)(1 * NBD + b) * B + e]; pcth = pr[(size_t)(2 * NBD + b) * B + e];
             ptag = __float_as_uint(pr[(size_t)(3 * NBD) * B + e]);
         }
@@ -1451,7 +1496,7 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
 
     // single-step launches: this step's random numbers, computed in the shadow of the loads
     StepDraw pre;
-    if (MODE == MODE_STEP) pre = draw_for_step<KIND, TASK>(P, env_id, P.tick_base, b, is_robot, fed);
+    if (MODE == MODE_STEP) pre = draw_for_step<KIND, TASK>(P, env_id, tick0, b, is_robot, fed);
 
     // All loads land here, once.  Without this the compiler parks a vmcnt(0) at the top of the
     // step loop (loop-carried values come from loads on the first trip), and on gfx9-class
@@ -1490,7 +1535,7 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
             }
         } else {
             const bool first_step = steps == 0;
-            const uint32_t t = P.tick_base + (uint32_t)it;   // per-step draws are keyed by the handle's step count, not by the env's counters
+            const uint32_t t = tick0 + (uint32_t)it;   // per-step draws are keyed by the handle's step count, not by the env's counters
             if (is_ball && first_step) {
 #pragma unroll
                 for (int i = 0; i < 10; ++i) info[i] = 0.0f;

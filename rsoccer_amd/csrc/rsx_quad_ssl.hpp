@@ -83,7 +83,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
     const int q = lane >> 2;           // env of the wave
     const int p = lane & 3;            // which quarter of the robots
     const bool bl = p == 3;            // the ball's lane (reward, termination, episode bookkeeping of the env)
-    const int tile = tile_of_block_zigzag(hp_per_xcd);
+    const bool tick_dev = (hp_n_steps & RSX_TICK_DEV) != 0;   // step counter of this launch: rsx_kernels.hpp, step_tick
+    const StepTick tk = step_tick(tick_dev, P, bufs, 1u);
+    if (__builtin_expect(!tk.ok, 0)) return;
+    const int tile = tile_of_block_zigzag(zigzag_per(tick_dev, tk.t, hp_per_xcd));
     const int e_raw = tile * Q_ENVS + q;
     int live_i = e_raw < P.num_envs ? 1 : 0;
     asm volatile("" : "+v"(live_i));               // decided here: one flag through the step, not the index it is made of
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
     ball.x = rawb[0]; ball.y = rawb[1]; ball.vx = rawb[3]; ball.vy = rawb[4];
     ball.z = bl ? rawb[2] - K::r_ball : 0.0f; ball.vz = rawb[5]; ball.om = rawb[6];   // (the other lanes carry an all-zero ball)
 
-    const uint32_t t = P.tick_base;
+    const uint32_t t = tk.t;
     unsigned kickbits = 0;
     // ---- actions -> commands: every robot (v_x, v_y, v_theta, kick), block 6p + m of the step ----
 #pragma unroll

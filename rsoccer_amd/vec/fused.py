@@ -105,6 +105,26 @@ class VecFusedEnv:
         t = self._t
         return t["obs"], t["reward"], t["terminated"], t["truncated"], self._info()
 
+    def enable_graph_capture(self):
+        """Make ``step()`` / ``step_random()`` capturable into a ``torch.cuda.CUDAGraph`` (hipGraph) and replayable.
+
+        The engine's step counter — the key of the per-step random draws — moves to device memory
+        (``rsx_task_enable_capture``), so every replay advances it exactly as an eager call would: a run is
+        bit-identical whether its steps are issued eagerly, replayed from a graph, or both.  Call once, outside any
+        capture; without it a captured ``step()`` raises instead of silently replaying one random stream.  Typical use
+        (the loop of the reference's README.md:116-133 with the policy on the GPU)::
+
+            env.enable_graph_capture()
+            actions = torch.zeros(env.num_envs, env.sim.act_dim, device=env.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                actions.copy_(policy(obs))
+                env.step(actions)
+            for _ in range(n): g.replay()      # obs / reward / flags are the same tensor views as ever
+        """
+        self.sim.task_enable_capture(self._stream())
+        return self
+
     def step_async(self, actions=None):
         """``gymnasium.vector``-style split call: enqueue the step (host-asynchronous, stream-ordered,
         exactly what ``step`` does)."""
