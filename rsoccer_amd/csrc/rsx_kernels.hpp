@@ -1384,12 +1384,7 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
     constexpr int mode = MODE == MODE_ROLLOUT ? MODE_STEP : MODE;
     const int n_steps = MODE == MODE_ROLLOUT ? n_steps_arg : 1;
     // the step counter of this launch (see step_tick): every workgroup — tiles, idle tail, placement helpers — takes part
-    StepTick tk{0u, true};
-    if (MODE == MODE_STEP || MODE == MODE_ROLLOUT) {
-        tk = step_tick((hp_n_steps & RSX_TICK_DEV) != 0, P, bufs, (uint32_t)n_steps);
-        if (__builtin_expect(!tk.ok, 0)) return;
-    }
-    const uint32_t tick0 = tk.t;
+    const bool tick_dev = __builtin_expect((hp_n_steps & RSX_TICK_DEV) != 0, 0);
     using K = KC<KIND>;
     using T = TC<TASK>;
     constexpr int G = 64 / L;
@@ -1402,10 +1397,17 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
     constexpr bool PC = MODE == MODE_STEP && L == 8 && TASK == RSX_TASK_SSL_STATIC_DEFENDERS && NR == 7;
     if constexpr (PC) {
         if (__builtin_expect(bufs.pcache != nullptr && (int)blockIdx.x >= hp_per_xcd * 8, 0)) {   // a helper workgroup (behind the tiles)
-            placement_helper<KIND, L, TASK, (PC ? NR : 1)>(P, bufs, (int)blockIdx.x - hp_per_xcd * 8, tick0, sh);
+            const StepTick th = step_tick(tick_dev, P, bufs, 1u);
+            if (th.ok) placement_helper<KIND, L, TASK, (PC ? NR : 1)>(P, bufs, (int)blockIdx.x - hp_per_xcd * 8, th.t, sh);
             return;
         }
     }
+    StepTick tk{0u, true};
+    if (MODE == MODE_STEP || MODE == MODE_ROLLOUT) {
+        tk = step_tick(tick_dev, P, bufs, (uint32_t)n_steps);
+        if (__builtin_expect(!tk.ok, 0)) return;
+    }
+    const uint32_t tick0 = tk.t;
     const int lane = threadIdx.x;
     const int b = LaneMap<L>::body(lane), g = LaneMap<L>::env(lane);
     const int tile = tile_of_block(HOT ? hp_per_xcd : (int)(gridDim.x >> 3));
