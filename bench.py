@@ -168,7 +168,11 @@ def leg_traffic(leg):
         files.sort(key=lambda f: int(re.search(r"r(\d+)_", os.path.basename(f)).group(1)), reverse=True)
         for f in files:
             try:
-                _LEG_TRAFFIC = (json.load(open(f)).get("legs", {}), os.path.relpath(f, ROOT))
+                doc = json.load(open(f))
+                fa = doc.get("factors")
+                how = (f"FETCH_SIZE x {fa['FETCH_SIZE']:g} + WRITE_SIZE x {fa['WRITE_SIZE']:g}, factors calibrated in {fa['source']}" if fa
+                       else "FETCH_SIZE x 2 + WRITE_SIZE x 1, uncalibrated")
+                _LEG_TRAFFIC = (doc.get("legs", {}), os.path.relpath(f, ROOT) + f" [{how}]")
                 break
             except Exception:
                 continue
@@ -405,9 +409,12 @@ def main():
                          key=lambda f: int(re.search(r"r(\d+)_", os.path.basename(f)).group(1))):   # newest ROUND first (r10 after r9)
             if B == 4096 and args.mode == "step":   # the counters were collected on this configuration
                 try:
-                    traffic = json.load(open(tp)).get("bytes_per_launch")
-                    tsrc = (os.path.relpath(tp, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of this command, "
-                            "corrected as MI355X_MICROARCH.md prescribes; not measured in this run)")
+                    doc = json.load(open(tp))
+                    traffic = doc.get("bytes_per_launch")
+                    fa = doc.get("factors")
+                    tsrc = (os.path.relpath(tp, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of this command; "
+                            + (f"FETCH_SIZE x {fa['FETCH_SIZE']:g} + WRITE_SIZE x {fa['WRITE_SIZE']:g}, factors calibrated in {fa['source']}" if fa
+                               else "FETCH_SIZE x 2 + WRITE_SIZE x 1, uncalibrated") + "; not measured in this run)")
                     break
                 except Exception:
                     traffic = None

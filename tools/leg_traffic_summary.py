@@ -1,11 +1,16 @@
 """Summarises the per-leg FETCH_SIZE / WRITE_SIZE passes of tools/prof_leg_traffic.sh: per leg the median counter value of
-the per-step kernel's dispatches, corrected as MI355X_MICROARCH.md (HBM section) prescribes: counters are KB, FETCH_SIZE
-reports half of the bytes of wide coalesced reads on gfx950 -> doubled, WRITE_SIZE as is."""
+the per-step kernel's dispatches, in KB, scaled by the factors tools/prof_calibration.sh measured on launches of the same kernels with a known byte count
+(profiles/rNN_counter_calibration.json; MI355X_MICROARCH.md, HBM section, asks for exactly that calibration)."""
 import csv, glob, json, os, statistics, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 root = sys.argv[1]
+from calib_factors import calibrated_factors
+
+FF, WF, FSRC = calibrated_factors()
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no tracing) -- python tools/leg_target.py <leg>; "
                  "per-step launches after a warm-up launch; MI355X",
-       "correction": "KB counters; gfx950: FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM), WRITE_SIZE as is; bytes_per_launch = 2 * FETCH + WRITE",
+       "correction": f"KB counters; bytes_per_launch = {FF:g} * FETCH_SIZE + {WF:g} * WRITE_SIZE, factors measured on launches of these kernels with a known byte count: {FSRC}",
+       "factors": {"FETCH_SIZE": FF, "WRITE_SIZE": WF, "source": FSRC},
        "legs": {}}
 for d in sorted(glob.glob(os.path.join(root, "*"))):
     leg = os.path.basename(d).replace("_", ":")
@@ -28,6 +33,6 @@ for d in sorted(glob.glob(os.path.join(root, "*"))):
         rec[c + "_KB"] = statistics.median(vals[k])
         rec["dispatches"] = len(vals[k])
     if "FETCH_SIZE_KB" in rec and "WRITE_SIZE_KB" in rec:
-        rec["bytes_per_launch"] = int((2 * rec["FETCH_SIZE_KB"] + rec["WRITE_SIZE_KB"]) * 1024)
+        rec["bytes_per_launch"] = int((FF * rec["FETCH_SIZE_KB"] + WF * rec["WRITE_SIZE_KB"]) * 1024)
     out["legs"][leg] = rec
 print(json.dumps(out, indent=1))

@@ -1,6 +1,9 @@
 """Summarises the FETCH_SIZE / WRITE_SIZE passes of tools/refresh_profiles.sh into the JSON that
-bench.py reads for roofline.traffic (corrections per MI355X_MICROARCH.md, HBM section)."""
+bench.py reads for roofline.traffic (factors: tools/calib_factors.py)."""
 import csv, glob, json, os, statistics, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from calib_factors import calibrated_factors
+FF, WF, FSRC = calibrated_factors()
 out = sys.argv[1]
 KERNEL = "task_step_kernel<0, 8, 1, 6, 0>"
 vals = {}
@@ -17,8 +20,9 @@ res = {
     "kernel": f"rsx::{KERNEL} (one launch = {B} envs x 1 fused VSS-v0 step)",
     "FETCH_SIZE_KB_median_per_launch": vals["FETCH_SIZE"],
     "WRITE_SIZE_KB_median_per_launch": vals["WRITE_SIZE"],
-    "correction": "MI355X_MICROARCH.md HBM section: counters are in KB; on gfx950 FETCH_SIZE reports half of the fetched bytes -> doubled; WRITE_SIZE taken as is",
-    "bytes_per_launch": None if None in vals.values() else int(2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024),
+    "correction": f"counters are in KB; bytes_per_launch = {FF:g} * FETCH_SIZE + {WF:g} * WRITE_SIZE, factors measured on launches of this kernel family with a known byte count: {FSRC}",
+    "factors": {"FETCH_SIZE": FF, "WRITE_SIZE": WF, "source": FSRC},
+    "bytes_per_launch": None if None in vals.values() else int(FF * vals["FETCH_SIZE"] * 1024 + WF * vals["WRITE_SIZE"] * 1024),
     "expected_from_layout": {"read_B_per_env": 252, "write_B_per_env": 418,
                              "note": "state 44 f32 (36 robot + 5 ball + height, vz, spin) + steps/episode + OU 10 + info 6 + prev_pot read; the same + obs 40 f32 + reward + 2 flag bytes written"},
     "algorithmic_bytes_per_launch": 541 * B,
