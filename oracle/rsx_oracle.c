@@ -54,7 +54,6 @@ typedef struct rsxo_cfg {
     double dck, half_kw, ir_tol, drib_vmax;
     double mu_rr, mu_rb, mu_wb, spin_dec;   /* Coulomb friction in contacts, spin deceleration (rad/s^2) */
     double pen2;                            /* overlap beyond which an env gets the second contact sweep */
-    int exp_sweeps, exp_project;            /* model experiments only: max sweeps per sub-step (2), position-only passes (0) */
     double wheel_ang[4];
     double pinv[3][4];
 } rsxo_cfg;
@@ -119,8 +118,6 @@ static int rsxo_cfg_init(rsxo_cfg* c, int kind, int field_type, int nb, int ny, 
     c->mu_rr = 0.2; c->mu_rb = 0.35; c->mu_wb = 0.3; c->spin_dec = 30.0;   /* build */
     c->pen2 = 0.005;                                                       /* build */
     if (getenv("RSXO_PEN2")) c->pen2 = atof(getenv("RSXO_PEN2"));          /* model experiments only */
-    c->exp_sweeps = getenv("RSXO_SWEEPS") ? atoi(getenv("RSXO_SWEEPS")) : 2;  /* model experiments only (tools/exp_jam.py) */
-    c->exp_project = getenv("RSXO_PROJECT") ? atoi(getenv("RSXO_PROJECT")) : 0;
     for (int k = 0; k < 4; ++k) c->wheel_ang[k] = f[10 + k] * RSXO_PI / 180.0;
     if (kind == 1) {
         /* omni inverse kinematics: wheel surface speed_k = -sin(a_k) vx + cos(a_k) vy + R w.

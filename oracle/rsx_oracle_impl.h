@@ -22,6 +22,7 @@ typedef struct SUF(rsxo_env) {
     R h, half_len, half_wid, ghw, gd, margin, r_robot, r_ball;
     R rs_rr, rs_rr2, rs_rb, rs_rb2;
     R w_rr, w_rb_r, w_rb_b, ope_rr, ope_rb, e_wb, e_wr, beta;
+    int wall_aware;   /* model v2: per-axis shares of robot - robot pairs at a wall, third / fourth sweep (SSL only: DESIGN.md 4) */
     R w_max, half_rw, rw_2b, inv_rw, r_wheel;
     R a_lin_h, a_lin_h2, a_lat_h, a_ang_h, mu_g_dt, g_h, e_ground, vz_min, robot_h;
     R dck_rb, half_kw, ir_tol, drib_gain, drib_vmax, drib_vmax2;
@@ -69,6 +70,7 @@ void* SUF(rsxo_create)(int kind, int field_type, int nb, int ny, int ts_ms) {
     e->rs_rb = RC(c->r_robot + c->r_ball);
     e->rs_rb2 = RC((c->r_robot + c->r_ball) * (c->r_robot + c->r_ball));
     double imr = 1.0 / c->m_robot, imb = 1.0 / c->m_ball;
+    e->wall_aware = c->kind == 1;
     e->w_rr = RC(0.5); e->w_rb_r = RC(imr / (imr + imb)); e->w_rb_b = RC(imb / (imr + imb));
     e->ope_rr = RC(1.0 + c->e_rr); e->ope_rb = RC(1.0 + c->e_rb);
     e->e_wb = RC(c->e_wall_ball); e->e_wr = RC(c->e_wall_robot); e->beta = RC(c->beta);
@@ -166,6 +168,24 @@ static int SUF(walls)(const SUF(rsxo_env)* e, R r, R rest, R* px, R* py, R* pvx,
         if (ay > yl) { y = sy * yl; if (vy * sy > RC(0)) { vy = -rest * vy; hit |= 2; } ay = yl; }
         R xl = (e->half_len + e->margin) - r;
         if (ax > xl) { x = sx * xl; if (vx * sx > RC(0)) { vx = -rest * vx; hit |= 1; } ax = xl; }
+        {   /* goal posts: the open ends of the goal's side walls, points at (+-L/2, +-goal_width/2) that a body keeps its radius
+             * from (without them a body overlaps the wall's end from the field side and is thrown sideways by the side-wall clamp
+             * the moment it crosses the goal line).  Folded into the first quadrant; n points post -> body. */
+            R dxp = ax - e->half_len, dyp = ay - e->ghw;
+            R d2 = R_FMA(dxp, dxp, dyp * dyp);
+            if (d2 < r * r && d2 > RC(0)) {
+                R d = R_SQRT(d2), inv = RC(1) / d;
+                R nxp = dxp * inv, nyp = dyp * inv;
+                ax = R_FMA(r, nxp, e->half_len); ay = R_FMA(r, nyp, e->ghw);
+                x = sx * ax; y = sy * ay;
+                R vr = R_FMA(vx * sx, nxp, (vy * sy) * nyp);     /* radial speed; < 0: moving into the post */
+                if (vr < RC(0)) {
+                    R dv = -((RC(1) + rest) * vr);
+                    vx = R_FMA(sx, dv * nxp, vx); vy = R_FMA(sy, dv * nyp, vy);
+                    hit |= 4;
+                }
+            }
+        }
         if (ax > e->half_len) {
             R back = e->half_len + e->gd;
             if (ay < e->ghw) {
@@ -254,20 +274,52 @@ static inline int SUF(rb_geom)(const SUF(rsxo_env)* e, const SUF(body)* a, const
  * point), w = a's share of the normal impulse, kt = a's share of the tangential one, mu = Coulomb
  * coefficient, spin_c = spin gained per unit of tangential velocity change (ball only). */
 static inline void SUF(respond)(const SUF(rsxo_env)* e, R nx, R ny, R pen, R dvx, R dvy, R wsum,
-                                R ope, R w, R kt, R mu, R spin_c,
+                                R ope, R w, R wx, R wy, R kt, R mu, R spin_c,
                                 R* avx, R* avy, R* apx, R* apy, R* aw) {
+    /* (wx, wy): a's share of the normal impulse and of the de-penetration, per axis — w on both axes except for a robot - robot
+     * pair at a wall (wall_shares below); the Coulomb limit keeps the nominal share w */
     R vn = R_FMA(dvx, nx, dvy * ny);
     if (vn < RC(0)) {
-        R q = ope * vn * w;                               /* <= 0: pushes a away from p */
-        *avx = R_FMA(q, nx, *avx); *avy = R_FMA(q, ny, *avy);
+        R q = ope * vn;                                   /* <= 0: pushes a away from p */
+        *avx = R_FMA(q * wx, nx, *avx); *avy = R_FMA(q * wy, ny, *avy);
         R vt = R_FMA(dvy, nx, -(dvx * ny)) - wsum;        /* along t = (-ny, nx) */
-        R lim = q * mu;
+        R lim = (q * w) * mu;
         R ft = SUF(clampr)(vt * kt, lim, -lim);           /* sticking impulse, Coulomb-limited */
         *avx = R_FMA(-ft, ny, *avx); *avy = R_FMA(ft, nx, *avy);
         *aw = R_FMA(ft, spin_c, *aw);
     }
-    R pc = e->beta * pen * w;
-    *apx = R_FMA(-pc, nx, *apx); *apy = R_FMA(-pc, ny, *apy);
+    R pc = e->beta * pen;
+    *apx = R_FMA(-(pc * wx), nx, *apx); *apy = R_FMA(-(pc * wy), ny, *apy);
+}
+
+/* Model v2 (SSL): a robot that stands against a wall cannot yield along that wall's normal: in a robot - robot pair the partner
+ * then takes the whole correction on that axis (the wall holds the other side).  Without this a pile that the robots' own push
+ * presses against a wall overlaps by centimetres: the contact phase moves the outer robot into the wall, the wall clamp puts it back
+ * into its neighbour.  Blocked axes are found by PROBING: each body displaced by 1 mm the way this contact pushes it (a: against n,
+ * p: along n); an axis is blocked when the probe lies where the wall clamp (walls above, a robot's radius) acts on that coordinate:
+ *   x: beyond the end wall's limit | within r of a goal post | in a goal: at its back wall from inside, or behind it
+ *   y: beyond the side wall's limit | within r of a goal post | in a goal: at a side wall from inside, or beside it from outside
+ * Shares per axis: blocked body 0, its free partner 1, otherwise 1/2 each.  Returns whether any axis of either body was blocked
+ * (a "wall pair"). */
+static inline void SUF(blocked_axes)(const SUF(rsxo_env)* e, R x, R y, int* bx, int* by) {
+    const R r = e->r_robot;
+    const R ax = R_FABS(x), ay = R_FABS(y);
+    const R dxp = ax - e->half_len, dyp = ay - e->ghw;
+    const R d2 = R_FMA(dxp, dxp, dyp * dyp);
+    const int post = d2 < r * r && d2 > RC(0);
+    const R back = e->half_len + e->gd;
+    const int beyond = ax > e->half_len, in_mouth = ay < e->ghw, inside = in_mouth && ax < back;
+    *bx = ax > (e->half_len + e->margin) - r || post || (beyond && ((inside && ax > back - r) || (in_mouth && !(ax < back) && ax < back + r)));
+    *by = ay > (e->half_wid + e->margin) - r || post || (beyond && ((inside && ay > e->ghw - r) || (!in_mouth && ay < e->ghw + r && ax < back)));
+}
+static inline int SUF(wall_shares)(const SUF(rsxo_env)* e, R xa, R ya, R xp, R yp, R nx, R ny, R* wx, R* wy) {
+    const R eps = RC(0.001);
+    int abx, aby, pbx, pby;
+    SUF(blocked_axes)(e, xa - eps * nx, ya - eps * ny, &abx, &aby);
+    SUF(blocked_axes)(e, xp + eps * nx, yp + eps * ny, &pbx, &pby);
+    *wx = (abx && !pbx) ? RC(0) : ((!abx && pbx) ? RC(1) : RC(0.5));
+    *wy = (aby && !pby) ? RC(0) : ((!aby && pby) ? RC(1) : RC(0.5));
+    return abx | aby | pbx | pby;
 }
 
 typedef struct SUF(kick) { int ovr, okick; R ovx, ovy, ovz; } SUF(kick);
@@ -282,7 +334,7 @@ static int SUF(contacts)(SUF(rsxo_env)* e, SUF(body)* b, int first, SUF(kick)* K
     SUF(body)* ball = &b[N];
     R dvx[MAXBOD], dvy[MAXBOD], dpx[MAXBOD], dpy[MAXBOD], dws = RC(0);
     int got[MAXBOD];   /* body had at least one touching partner: only those are updated */
-    int any = 0;
+    int any = 0, wallpair = 0;
     for (int i = 0; i < M; ++i) {
         R avx = RC(0), avy = RC(0), apx = RC(0), apy = RC(0), aw = RC(0);
         int touched = 0;
@@ -294,8 +346,10 @@ static int SUF(contacts)(SUF(rsxo_env)* e, SUF(body)* b, int first, SUF(kick)* K
                 if (d2 < e->rs_rr2 && d2 > RC(0)) {
                     R d = R_SQRT(d2), inv = RC(1) / d;
                     R wsum = R_FMA(b[j].om, e->r_robot, b[i].om * e->r_robot);
+                    R wx = e->w_rr, wy = e->w_rr;
+                    if (e->wall_aware && SUF(wall_shares)(e, b[i].x, b[i].y, b[j].x, b[j].y, dx * inv, dy * inv, &wx, &wy)) wallpair = 1;
                     SUF(respond)(e, dx * inv, dy * inv, e->rs_rr - d, b[j].vx - b[i].vx, b[j].vy - b[i].vy, wsum,
-                                 e->ope_rr, e->w_rr, e->kt_rr, e->mu_rr, RC(0), &avx, &avy, &apx, &apy, &aw);
+                                 e->ope_rr, e->w_rr, wx, wy, e->kt_rr, e->mu_rr, RC(0), &avx, &avy, &apx, &apy, &aw);
                     if (e->rs_rr - d > e->pen2) any = 1;
                     touched = 1;
                 }
@@ -305,7 +359,7 @@ static int SUF(contacts)(SUF(rsxo_env)* e, SUF(body)* b, int first, SUF(kick)* K
                 if (touch) {
                     R wsum = R_FMA(ball->om, e->r_ball, b[i].om * (mouth ? e->dck : e->r_robot));
                     SUF(respond)(e, nx, ny, pen, ball->vx - b[i].vx, ball->vy - b[i].vy, wsum,
-                                 e->ope_rb, e->w_rb_r, e->kt_rb_r, e->mu_rb, RC(0), &avx, &avy, &apx, &apy, &aw);
+                                 e->ope_rb, e->w_rb_r, e->w_rb_r, e->w_rb_r, e->kt_rb_r, e->mu_rb, RC(0), &avx, &avy, &apx, &apy, &aw);
                     if (pen > e->pen2) any = 1;
                     touched = 1;
                 }
@@ -317,7 +371,7 @@ static int SUF(contacts)(SUF(rsxo_env)* e, SUF(body)* b, int first, SUF(kick)* K
                     R d = R_SQRT(d2), inv = RC(1) / d;
                     R wsum = R_FMA(b[j].om, e->r_robot, ball->om * e->r_ball);
                     SUF(respond)(e, dx * inv, dy * inv, e->rs_rb - d, b[j].vx - ball->vx, b[j].vy - ball->vy, wsum,
-                                 e->ope_rb, e->w_rb_b, e->kt_rb_b, e->mu_rb, e->spin_c, &avx, &avy, &apx, &apy, &aw);
+                                 e->ope_rb, e->w_rb_b, e->w_rb_b, e->w_rb_b, e->kt_rb_b, e->mu_rb, e->spin_c, &avx, &avy, &apx, &apy, &aw);
                     if (e->rs_rb - d > e->pen2) any = 1;
                     touched = 1;
                 }
@@ -369,7 +423,7 @@ static int SUF(contacts)(SUF(rsxo_env)* e, SUF(body)* b, int first, SUF(kick)* K
         b[i].x = b[i].x + dpx[i]; b[i].y = b[i].y + dpy[i];
     }
     if (got[N]) ball->om = ball->om + dws;
-    return any;
+    return any | (wallpair && any ? 2 : 0);   /* bit 1: deep, and some touching robot - robot pair stood at a wall */
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -479,19 +533,9 @@ static void SUF(step_core)(SUF(rsxo_env)* e, const R* cmds) {
         SUF(kick) K; memset(&K, 0, sizeof(K));
         if (SUF(contacts)(e, b, 1, &K)) {
             int deep = SUF(contacts)(e, b, 0, &K);
-            /* model EXPERIMENTS only (RSXO_SWEEPS / RSXO_PROJECT, tools/exp_jam.py; both off in the model of DESIGN.md 4):
-             * more Jacobi sweeps, and position-only Gauss-Seidel passes over the robot - robot overlaps */
-            for (int sw = 2; sw < c->exp_sweeps && deep; ++sw) deep = SUF(contacts)(e, b, 0, &K);
-            for (int it = 0; it < c->exp_project; ++it)
-                for (int i = 0; i < N; ++i)
-                    for (int j = i + 1; j < N; ++j) {
-                        R dx = b[j].x - b[i].x, dy = b[j].y - b[i].y;
-                        R d2 = dx * dx + dy * dy;
-                        if (d2 < e->rs_rr2 && d2 > RC(0)) {
-                            R d = R_SQRT(d2), k = RC(0.5) * (e->rs_rr - d) / d;
-                            b[i].x -= k * dx; b[i].y -= k * dy; b[j].x += k * dx; b[j].y += k * dy;
-                        }
-                    }
+            /* a third and a fourth sweep for piles at a wall: while the last sweep saw a deep pair AND a touching robot - robot pair
+             * with a wall-blocked axis (the share-1 corrections of wall pairs need the extra relaxation; piles in the open do not) */
+            for (int sw = 2; sw < 4 && (deep & 2); ++sw) deep = SUF(contacts)(e, b, 0, &K);
         }
         if (K.ovr) {
             ball->vx = K.ovx; ball->vy = K.ovy; ball->om = RC(0);

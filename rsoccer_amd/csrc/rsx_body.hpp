@@ -62,6 +62,27 @@ __device__ __forceinline__ void walls(const Params& P, const float r, const floa
         const bool fx0 = hx & (vx * sx > 0.0f);
         x = hx ? sx * xl : x; vx = fx0 ? -rest * vx : vx; ax = hx ? xl : ax;
         hit = (fx0 ? 1 : 0) | (fy0 ? 2 : 0);
+#ifndef RSX_V2_NO_POSTS
+        {   // goal posts (model v2): the open ends of the goal's side walls are points at (+-L/2, +-goal_width/2) that a body keeps
+            // its radius from — without them a body overlaps the wall's end from the field side and is thrown sideways by the
+            // side-wall clamp the moment it crosses the goal line.  Folded into the first quadrant, n points post -> body;
+            // predicated like the rest of the clamp (a garbage sqrt / divide of a far-away body is selected away).
+            const float dxp = ax - P.half_len, dyp = ay - P.ghw;
+            const float d2 = fma_(dxp, dxp, dyp * dyp);
+            const bool inp = (d2 < r * r) & (d2 > 0.0f);
+            if (__builtin_expect(__any(inp), 0)) {   // wave-uniform: the square root and the division stay off the clamp's usual path
+            const float d = sqrtf(d2), inv = 1.0f / d;
+            const float nxp = dxp * inv, nyp = dyp * inv;
+            ax = inp ? fma_(r, nxp, P.half_len) : ax; ay = inp ? fma_(r, nyp, P.ghw) : ay;
+            x = inp ? sx * ax : x; y = inp ? sy * ay : y;
+            const float vr = fma_(vx * sx, nxp, (vy * sy) * nyp);   // radial speed; < 0: moving into the post
+            const bool fp = inp & (vr < 0.0f);
+            const float dv = -((1.0f + rest) * vr);
+            vx = fp ? fma_(sx, dv * nxp, vx) : vx; vy = fp ? fma_(sy, dv * nyp, vy) : vy;
+            hit |= fp ? 4 : 0;
+            }
+        }
+#endif
         if (ax > P.half_len) {   // beyond a goal line: the goal's walls (rare)
             const float back = P.half_len + P.gd;
             const bool in_mouth = ay < P.ghw;
@@ -80,6 +101,85 @@ __device__ __forceinline__ void walls(const Params& P, const float r, const floa
             hit |= (fx ? 1 : 0) | (fy ? 2 : 0);
         }
     }
+}
+
+// Is this body anywhere near a wall?  walls<KIND> with a robot's radius (and, a fortiori, the ball's) changes nothing outside this
+// region — SSL: |x| <= L/2 (no goal geometry), |y| <= W/2 + margin - r_robot and farther than r_robot from every goal post; VSS:
+// |x| <= L/2 - r_robot and |y| <= W/2 - r_robot — so kernels test a whole wave's bodies with this and skip the clamp when none is out there (the division-A
+// field is 12 m x 9 m: most sub-steps).  NaN ("ghost" slots of rsx_quad_ssl.hpp) compares false.
+template <int KIND>
+__device__ __forceinline__ bool near_walls(const Params& P, const float x, const float y) {
+    using K = KC<KIND>;
+#ifdef RSX_NO_WALL_SKIP   // development A/B: always run the clamp
+    return true;
+#endif
+    if (KIND == RSX_KIND_VSS) return (fabsf(x) > P.half_len - K::r_robot) | (fabsf(y) > P.half_wid - K::r_robot);
+#ifdef RSX_V2_LOOSE_NEAR
+    return (fabsf(x) > P.half_len - K::r_robot) | (fabsf(y) > (P.half_wid + K::margin) - K::r_robot);
+#endif
+#ifdef RSX_V2_NO_POSTS
+    return (fabsf(x) > P.half_len) | (fabsf(y) > (P.half_wid + K::margin) - K::r_robot);
+#endif
+    // SSL: beyond a goal line, at a boundary wall, or within a robot's radius of a goal post
+    return (fabsf(x) > P.half_len) | (fabsf(y) > (P.half_wid + K::margin) - K::r_robot) |
+           ((fabsf(x) > P.half_len - K::r_robot) & (fabsf(fabsf(y) - P.ghw) < K::r_robot));
+}
+
+// Is a robot's centre within 2 mm of where the wall clamp acts on it (or beyond)?  The probes of wall_shares lie within 1 mm of the
+// body, so a pair of which NEITHER body is at_wall has unblocked probes by construction and keeps the plain 1/2 : 1/2 shares —
+// the limits are those of the clamp minus 2 mm (one of them rounding slack).  (Computed from the fields the kernels hold anyway: two
+// more words in the parameter block cost the SSL task kernels scalar registers they do not have.)
+template <int KIND>
+__device__ __forceinline__ bool at_wall(const Params& P, const float x, const float y) {
+    using K = KC<KIND>;
+    return (fabsf(x) > P.half_len - (K::r_robot + 0.002f)) | (fabsf(y) > P.half_wid + (K::margin - K::r_robot - 0.002f));
+}
+
+// Model v2: a robot that stands against a wall cannot yield along that wall's normal — in a robot - robot pair the partner then takes
+// the whole correction on that axis (the wall holds the other side).  Without this a pile that the robots' own push presses against a
+// wall overlaps by centimetres: the contact phase moves the outer robot into the wall, the wall clamp puts it back into its neighbour.
+// Blocked axes are found by PROBING: each body displaced by 1 mm the way this contact pushes it (a: against n, p: along n); an axis
+// is blocked when the probe lies where the wall clamp acts on that coordinate (blocked_axes below).  Shares per axis: blocked body 0, its free partner 1,
+// otherwise 1/2 each.  Returns whether any axis of either body was blocked (a "wall pair": such envs may take a third and a fourth
+// sweep).  Callers evaluate it only for pairs with a body at_wall (everywhere else the result is 1/2, 1/2, false).
+// does the wall clamp (walls<SSL>, a robot's radius) act on the x / the y coordinate of this point?
+//   x: beyond the end wall's limit | within r of a goal post | in a goal: at its back wall from inside, or behind it
+//   y: beyond the side wall's limit | within r of a goal post | in a goal: at a side wall from inside, or beside it from outside
+// Every predicate "a > b" is the SIGN BIT of the float b - a (exact: a difference of finite floats is negative iff a > b), combined
+// with integer AND / OR / NOT in vector registers; the answer is bit 31 of bx / by.  Written as compares, each truth value is a
+// 64-bit lane mask in a scalar-register pair: two probes x fifteen predicates live at once pushed the lane-group kernels out of
+// scalar registers (176 v_writelane / v_readlane in the 32-lane sub-step loop, +4-8 % on every SSL configuration at the
+// latency-bound batches) for code that runs next to walls only.
+template <int KIND>
+__device__ __forceinline__ void blocked_axes(const Params& P, const float x, const float y, uint32_t& bx, uint32_t& by) {
+    using K = KC<KIND>;
+    static_assert(KIND == RSX_KIND_SSL, "model v2 is defined for the SSL class");
+    constexpr float r = K::r_robot;
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float dxp = ax - P.half_len, dyp = ay - P.ghw;
+    const float d2 = fma_(dxp, dxp, dyp * dyp);
+    const uint32_t post = __float_as_uint(d2 - r * r) & ~(__float_as_uint(d2) - 1u);   // d2 < r^2 and d2 > 0 (bits(+0) - 1 wraps: sign set)
+    const float back = P.half_len + P.gd;
+    const uint32_t beyond = __float_as_uint(P.half_len - ax);     // ax > L/2
+    const uint32_t in_mouth = __float_as_uint(dyp);               // ay < goal half width
+    const uint32_t lt_back = __float_as_uint(ax - back);          // ax < back wall
+    const uint32_t inside = in_mouth & lt_back;
+    bx = __float_as_uint(((P.half_len + K::margin) - r) - ax) | post |
+         (beyond & ((inside & __float_as_uint((back - r) - ax)) | (in_mouth & ~lt_back & __float_as_uint(ax - (back + r)))));
+    by = __float_as_uint(((P.half_wid + K::margin) - r) - ay) | post |
+         (beyond & ((inside & __float_as_uint((P.ghw - r) - ay)) | (~in_mouth & __float_as_uint(ay - (P.ghw + r)) & lt_back)));
+}
+template <int KIND>
+__device__ __forceinline__ bool wall_shares(const Params& P, const float xa, const float ya, const float xp, const float yp,
+                                            const float nx, const float ny, float& wx, float& wy) {
+    constexpr float eps = 0.001f;
+    uint32_t abx, aby, pbx, pby;
+    blocked_axes<KIND>(P, xa - eps * nx, ya - eps * ny, abx, aby);
+    blocked_axes<KIND>(P, xp + eps * nx, yp + eps * ny, pbx, pby);
+    // blocked body 0, its free partner 1, otherwise 1/2: 1/2 + (partner blocked - body blocked) / 2 (exact)
+    wx = fma_((float)(pbx >> 31) - (float)(abx >> 31), 0.5f, 0.5f);
+    wy = fma_((float)(pby >> 31) - (float)(aby >> 31), 0.5f, 0.5f);
+    return (int32_t)((abx | aby) | (pbx | pby)) < 0;
 }
 
 // A bounce of the BALL off a wall with Coulomb friction at the contact point: couples the velocity
@@ -161,18 +261,54 @@ __device__ __forceinline__ void respond(const float nx, const float ny, const fl
     float pc = beta * pen * w;
     apx = fma_(-pc, nx, apx); apy = fma_(-pc, ny, apy);
 }
+// The same with the body's share of the normal impulse and of the de-penetration given PER AXIS (model v2: a robot - robot pair at
+// a wall, wall_shares above); the Coulomb limit keeps the nominal share w.  With wx == wy == w every operation is the one respond()
+// performs ((ope vn) w, (beta pen) w: same association), so the two agree bit for bit — which lets the kernels keep the short form
+// on the hot path and take this one only next to a wall.
+__device__ __forceinline__ void respond_axes(const float nx, const float ny, const float pen, const float dvx,
+                                             const float dvy, const float wsum, const float ope, const float w,
+                                             const float wx, const float wy,
+                                             const float kt, const float mu, const float spin_c, const float beta,
+                                             float& avx, float& avy, float& apx, float& apy, float& aw) {
+    float vn = fma_(dvx, nx, dvy * ny);
+    if (vn < 0.0f) {
+        float q = ope * vn;
+        avx = fma_(q * wx, nx, avx); avy = fma_(q * wy, ny, avy);
+        float vt = fma_(dvy, nx, -(dvx * ny)) - wsum;
+        float lim = (q * w) * mu;
+        float ft = clampf(vt * kt, lim, -lim);
+        avx = fma_(-ft, ny, avx); avy = fma_(ft, nx, avy);
+        aw = fma_(ft, spin_c, aw);
+    }
+    float pc = beta * pen;
+    apx = fma_(-(pc * wx), nx, apx); apy = fma_(-(pc * wy), ny, apy);
+}
 
 // circle - circle pair known to overlap (d2 = squared centre distance)
-__device__ __forceinline__ void contact_response(const Body& o, const float4 oj, const float d2,
+// rr: a robot - robot pair (per lane): its shares are wall-aware, `wallp` records that an axis was blocked.
+// v2w: WAVE-UNIFORM, computed once per sweep by the caller — does any robot of the wave stand at_wall?  If not, no pair can have a
+// blocked axis and the partner loop runs v1's instructions, untouched; the wall-aware code hangs off a scalar branch (a divergent
+// test here would be structurised in place: its body, exec-mask copies and all, in the middle of the hot loop).
+template <int KIND>
+__device__ __forceinline__ void contact_response(const Params& P, const Body& o, const float4 oj, const float d2,
                                                  const float rs, const float ope, const float w,
                                                  const float kt, const float mu, const float spin_c,
-                                                 const float wsum, const float beta, const float pen2,
+                                                 const float wsum, const float beta, const float pen2, const bool rr, const bool v2w,
                                                  float& avx, float& avy, float& apx, float& apy, float& aw,
-                                                 bool& deep) {
+                                                 bool& deep, bool& wallp) {
     float dx = oj.x - o.x, dy = oj.y - o.y;
     float d = sqrtf(d2), inv = 1.0f / d;
-    respond(dx * inv, dy * inv, rs - d, oj.z - o.vx, oj.w - o.vy, wsum, ope, w, kt, mu, spin_c, beta,
-            avx, avy, apx, apy, aw);
+    const float nx = dx * inv, ny = dy * inv;
+    // the hot path is v1's: only a pair with a body within 2 mm of where the wall clamp acts (at_wall: 3 instructions per partner)
+    // evaluates the probes — rare, laid out away from the loop
+    if (KC<KIND>::wall_aware && __builtin_expect(v2w, 0)) {
+        float wx = w, wy = w;
+        if constexpr (KC<KIND>::wall_aware)
+            if (rr && (at_wall<KIND>(P, o.x, o.y) | at_wall<KIND>(P, oj.x, oj.y))) wallp |= wall_shares<KIND>(P, o.x, o.y, oj.x, oj.y, nx, ny, wx, wy);
+        respond_axes(nx, ny, rs - d, oj.z - o.vx, oj.w - o.vy, wsum, ope, w, wx, wy, kt, mu, spin_c, beta, avx, avy, apx, apy, aw);
+    } else {
+        respond(nx, ny, rs - d, oj.z - o.vx, oj.w - o.vy, wsum, ope, w, kt, mu, spin_c, beta, avx, avy, apx, apy, aw);
+    }
     deep |= rs - d > pen2;   // an impact at speed or a jammed pile: the env gets a second sweep
 }
 
@@ -184,36 +320,71 @@ __device__ __forceinline__ void contact_response(const Body& o, const float4 oj,
 // and a negated operand is free.  Shared: one square root, one division, one normal; per side: the shares w / kt,
 // the Coulomb limit, the surface-speed term wsum (whose rounding depends on the side) and the sums.
 // ai = {vx, vy, px, py} sums of body i (a robot: no spin), aj the same of body j, awj the spin sum of j (ball only).
-__device__ __forceinline__ void contact_pair(const Body& bi, const Body& bj, const float wsum_i, const float wsum_j,
+// rr: a robot - robot pair: per-axis shares from wall_shares (i's view; j's are the mirror image: the two probes are the same
+// points from either side), `wallp` records a blocked axis.
+template <int KIND>
+__device__ __forceinline__ void contact_pair(const Params& P, const Body& bi, const Body& bj, const float wsum_i, const float wsum_j,
                                              const float rs, const float ope, const float w_i, const float w_j,
                                              const float kt_i, const float kt_j, const float mu, const float spin_c_j,
-                                             const float beta, const float pen2, float* ai, float* aj, float& awj, bool& deep) {
+                                             const float beta, const float pen2, const bool rr, const bool v2w, float* ai, float* aj, float& awj,
+                                             bool& deep, bool& wallp) {
     const float dx = bj.x - bi.x, dy = bj.y - bi.y;
     const float d = sqrtf(fma_(dx, dx, dy * dy)), inv = 1.0f / d;
     const float nx = dx * inv, ny = dy * inv, pen = rs - d;           // n: i -> j
     const float dvx = bj.vx - bi.vx, dvy = bj.vy - bi.vy;
     const float vn = fma_(dvx, nx, dvy * ny);
-    if (vn < 0.0f) {
-        const float vt0 = fma_(dvy, nx, -(dvx * ny));
-        {   // body i
-            const float q = ope * vn * w_i;
-            ai[0] = fma_(q, nx, ai[0]); ai[1] = fma_(q, ny, ai[1]);
-            const float lim = q * mu;
-            const float ft = clampf((vt0 - wsum_i) * kt_i, lim, -lim);
-            ai[0] = fma_(-ft, ny, ai[0]); ai[1] = fma_(ft, nx, ai[1]);
+    if (KC<KIND>::wall_aware && __builtin_expect(v2w, 0)) {   // (wave-uniform: see contact_response)
+        // model v2, some robot of the wave at a wall: per-axis shares (respond_axes from either side; a pair's shares add up to 1 per axis)
+        float wxi = w_i, wyi = w_i, wxj = w_j, wyj = w_j;
+        if constexpr (KC<KIND>::wall_aware) {
+            if (rr && (at_wall<KIND>(P, bi.x, bi.y) | at_wall<KIND>(P, bj.x, bj.y))) {
+                wallp |= wall_shares<KIND>(P, bi.x, bi.y, bj.x, bj.y, nx, ny, wxi, wyi);
+                wxj = 1.0f - wxi; wyj = 1.0f - wyi;   // {0, 1/2, 1} -> {1, 1/2, 0}: exact
+            }
         }
-        {   // body j: normal -n
-            const float q = ope * vn * w_j;
-            aj[0] = fma_(q, -nx, aj[0]); aj[1] = fma_(q, -ny, aj[1]);
-            const float lim = q * mu;
-            const float ft = clampf((vt0 - wsum_j) * kt_j, lim, -lim);
-            aj[0] = fma_(ft, ny, aj[0]); aj[1] = fma_(ft, -nx, aj[1]);
-            awj = fma_(ft, spin_c_j, awj);
+        if (vn < 0.0f) {
+            const float vt0 = fma_(dvy, nx, -(dvx * ny));
+            const float q0 = ope * vn;
+            {   // body i
+                ai[0] = fma_(q0 * wxi, nx, ai[0]); ai[1] = fma_(q0 * wyi, ny, ai[1]);
+                const float lim = (q0 * w_i) * mu;
+                const float ft = clampf((vt0 - wsum_i) * kt_i, lim, -lim);
+                ai[0] = fma_(-ft, ny, ai[0]); ai[1] = fma_(ft, nx, ai[1]);
+            }
+            {   // body j: normal -n
+                aj[0] = fma_(q0 * wxj, -nx, aj[0]); aj[1] = fma_(q0 * wyj, -ny, aj[1]);
+                const float lim = (q0 * w_j) * mu;
+                const float ft = clampf((vt0 - wsum_j) * kt_j, lim, -lim);
+                aj[0] = fma_(ft, ny, aj[0]); aj[1] = fma_(ft, -nx, aj[1]);
+                awj = fma_(ft, spin_c_j, awj);
+            }
         }
+        const float pc = beta * pen;
+        ai[2] = fma_(-(pc * wxi), nx, ai[2]); ai[3] = fma_(-(pc * wyi), ny, ai[3]);
+        aj[2] = fma_(pc * wxj, nx, aj[2]); aj[3] = fma_(pc * wyj, ny, aj[3]);
+    } else {
+        if (vn < 0.0f) {
+            const float vt0 = fma_(dvy, nx, -(dvx * ny));
+            {   // body i
+                const float q = ope * vn * w_i;
+                ai[0] = fma_(q, nx, ai[0]); ai[1] = fma_(q, ny, ai[1]);
+                const float lim = q * mu;
+                const float ft = clampf((vt0 - wsum_i) * kt_i, lim, -lim);
+                ai[0] = fma_(-ft, ny, ai[0]); ai[1] = fma_(ft, nx, ai[1]);
+            }
+            {   // body j: normal -n
+                const float q = ope * vn * w_j;
+                aj[0] = fma_(q, -nx, aj[0]); aj[1] = fma_(q, -ny, aj[1]);
+                const float lim = q * mu;
+                const float ft = clampf((vt0 - wsum_j) * kt_j, lim, -lim);
+                aj[0] = fma_(ft, ny, aj[0]); aj[1] = fma_(ft, -nx, aj[1]);
+                awj = fma_(ft, spin_c_j, awj);
+            }
+        }
+        const float pci = beta * pen * w_i, pcj = beta * pen * w_j;
+        ai[2] = fma_(-pci, nx, ai[2]); ai[3] = fma_(-pci, ny, ai[3]);
+        aj[2] = fma_(pcj, nx, aj[2]); aj[3] = fma_(pcj, ny, aj[3]);
     }
-    const float pci = beta * pen * w_i, pcj = beta * pen * w_j;
-    ai[2] = fma_(-pci, nx, ai[2]); ai[3] = fma_(-pci, ny, ai[3]);
-    aj[2] = fma_(pcj, nx, aj[2]); aj[3] = fma_(pcj, ny, aj[3]);
     deep |= pen > pen2;   // an impact at speed or a jammed pile: the env gets a second sweep
 }
 
@@ -284,18 +455,6 @@ __device__ __forceinline__ void ball_step_friction(const Params& P, Body& ball) 
         const float aw = fabsf(ball.om) - P.spin_dec_dt;
         ball.om = aw > 0.0f ? (ball.om < 0.0f ? -aw : aw) : 0.0f;
     }
-}
-// SSL: is this body anywhere near a wall?  walls<SSL> changes nothing while |x| <= half_len (no goal geometry) and |y| <=
-// half_wid + margin - r_robot (the tightest of the y limits, robots' and ball's): kernels test a whole wave's bodies with
-// this and skip the clamp when none is out there (the division-A field is 12 m x 9 m: most sub-steps).  NaN ("ghost"
-// slots of rsx_quad_ssl.hpp) compares false.
-template <int KIND>
-__device__ __forceinline__ bool near_walls(const Params& P, const float x, const float y) {
-    using K = KC<KIND>;
-#ifdef RSX_NO_WALL_SKIP   // development A/B: always run the clamp
-    return true;
-#endif
-    return (fabsf(x) > P.half_len) | (fabsf(y) > (P.half_wid + K::margin) - K::r_robot);
 }
 // the ball's wall clamp incl. the friction of a bounce
 template <int KIND>

@@ -233,17 +233,19 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
                 }
                 return ball_low ? touching : (touching & ~PM[N]);
             };
-            bool deep = false;
-            for (int sweep = 0; sweep < 2; ++sweep) {   // the second sweep runs the same (cached) instructions
-                if (sweep == 1 && !__any(deep)) break;   // no env of the wave had a deep pair: no second pair test either
-                const unsigned touching = (sweep == 0 || deep) ? find_touching() : 0u;   // second: envs with a deep pair only
+            bool deep = false, wallp = false;
+            for (int sweep = 0; sweep < 4; ++sweep) {   // the later sweeps run the same (cached) instructions
+                // second: envs with a deep pair only; third and fourth: envs whose last sweep also saw a wall pair (model v2)
+                const bool mine = sweep == 0 || (deep && (sweep == 1 || wallp));
+                if (sweep >= 1 && !__any(mine)) break;   // no env of the wave goes on: no further pair test either
+                const unsigned touching = mine ? find_touching() : 0u;
                 if (!__any(touching != 0)) break;
                 // some env of the wave has a contact: sums in LDS, pairs walked per lane, both sides of a pair from one normal
                 // (epl_walk_pairs, rsx_epl_common.hpp: the ball is body N, a circle like the robots)
                 epl_zero_sums(sh.c, lane);
                 wave_sync();
-                deep = false;
-                epl_walk_pairs<KIND, N, true>(r, ball, sh.c, lane, touching, deep);
+                deep = false; wallp = false;
+                epl_walk_pairs<KIND, N, true>(P, r, ball, sh.c, lane, touching, deep, wallp);
                 wave_sync();
                 epl_apply_sums<N>(r, ball, sh.c, lane, [&](int k) { return (touching & PM[k]) != 0; });   // (the registers still held the snapshot)
                 wave_sync();

@@ -96,7 +96,14 @@ static_assert(epl_pair_mask<7>(0) == 0x00003Fu && epl_pair_mask<7>(3) == 0x03888
 // select chains: a snapshot in LDS would cost a wave of occupancy); BALL: body N is the ball as a circle (VSS).  Both sides
 // of a pair from one normal (contact_pair, rsx_body.hpp); each body's sums are read-modify-written in LDS.
 template <int KIND, int N, bool BALL>
-__device__ __forceinline__ void epl_walk_pairs(const Body* r, const Body& ball, EplSums<N + 1>& c, const int lane, unsigned todo, bool& deep) {
+__device__ __forceinline__ void epl_walk_pairs(const Params& P, const Body* r, const Body& ball, EplSums<N + 1>& c, const int lane, unsigned todo, bool& deep, bool& wallp) {
+    // does any robot of the wave's envs (with a touching pair) stand at a wall?  (wave-uniform, once per sweep: contact_pair, rsx_body.hpp)
+    bool aw_ = false;
+    if (KC<KIND>::wall_aware && todo) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) aw_ |= at_wall<KIND>(P, r[k].x, r[k].y);
+    }
+    const bool v2w = KC<KIND>::wall_aware && __any(aw_);
     using K = KC<KIND>;
     while (todo) {
         const int p = __builtin_ctz(todo);
@@ -116,9 +123,9 @@ __device__ __forceinline__ void epl_walk_pairs(const Body* r, const Body& ball, 
         float ai[4] = {c.acc[0][i][lane], c.acc[1][i][lane], c.acc[2][i][lane], c.acc[3][i][lane]};
         float aj[4] = {c.acc[0][j][lane], c.acc[1][j][lane], c.acc[2][j][lane], c.acc[3][j][lane]};
         float awj = rb ? c.accw[lane] : 0.0f;
-        contact_pair(bi, bj, fma_(wj, lever_j, wi * K::r_robot), fma_(wi, K::r_robot, wj * lever_j), rb ? K::rs_rb : K::rs_rr,
-                     rb ? K::ope_rb : K::ope_rr, rb ? K::w_rb_r : K::w_rr, rb ? K::w_rb_b : K::w_rr, rb ? K::kt_rb_r : K::kt_rr,
-                     rb ? K::kt_rb_b : K::kt_rr, rb ? K::mu_rb : K::mu_rr, rb ? K::spin_c : 0.0f, K::beta, K::pen2, ai, aj, awj, deep);
+        contact_pair<KIND>(P, bi, bj, fma_(wj, lever_j, wi * K::r_robot), fma_(wi, K::r_robot, wj * lever_j), rb ? K::rs_rb : K::rs_rr,
+                           rb ? K::ope_rb : K::ope_rr, rb ? K::w_rb_r : K::w_rr, rb ? K::w_rb_b : K::w_rr, rb ? K::kt_rb_r : K::kt_rr,
+                           rb ? K::kt_rb_b : K::kt_rr, rb ? K::mu_rb : K::mu_rr, rb ? K::spin_c : 0.0f, K::beta, K::pen2, !rb, v2w, ai, aj, awj, deep, wallp);
         c.acc[0][i][lane] = ai[0]; c.acc[1][i][lane] = ai[1]; c.acc[2][i][lane] = ai[2]; c.acc[3][i][lane] = ai[3];
         c.acc[0][j][lane] = aj[0]; c.acc[1][j][lane] = aj[1]; c.acc[2][j][lane] = aj[2]; c.acc[3][j][lane] = aj[3];
         if (rb) c.accw[lane] = awj;

@@ -212,13 +212,14 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
                 }
                 return ball_low ? near : 0u;
             };
-            bool deep = false;
+            bool deep = false, wallp = false;
             BallOverride bo{false, false, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int k = 0; k < N; ++k) r[k].ir = 0;   // refreshed by the first sweep; robots far from the ball: no infrared
-            for (int sweep = 0; sweep < 2; ++sweep) {   // the second sweep runs the same (cached) instructions
-                if (sweep == 1 && !__any(deep)) break;   // no env of the wave had a deep pair: no second pair test either
-                const bool mine = sweep == 0 || deep;   // second: envs with a deep pair only
+            for (int sweep = 0; sweep < 4; ++sweep) {   // the later sweeps run the same (cached) instructions
+                // second: envs with a deep pair only; third and fourth: envs whose last sweep also saw a wall pair (model v2)
+                const bool mine = sweep == 0 || (deep && (sweep == 1 || wallp));
+                if (sweep >= 1 && !__any(mine)) break;   // no env of the wave goes on: no further pair test either
                 const unsigned touching = mine ? find_pairs() : 0u;
                 const unsigned near = mine ? find_near() : 0u;
                 if (sub == 0 && sweep == 0) RSX_STAMP(5);
@@ -227,9 +228,9 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
                 const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // = lane, re-derived: the index is not held across the sub-steps for this path
                 epl_zero_sums(sh.c, ln);
                 wave_sync();
-                deep = false;
+                deep = false; wallp = false;
                 // robot-robot pairs, in pair order: every body receives its partners in index order (rsx_epl_common.hpp)
-                epl_walk_pairs<KIND, N, false>(r, ball, sh.c, ln, touching, deep);
+                epl_walk_pairs<KIND, N, false>(P, r, ball, sh.c, ln, touching, deep, wallp);
                 // robot-ball, robot by robot (the ball sums the robots' records in robot order): kicker mouth
                 // (flat face at dck) or body circle; n points robot -> ball.  Mirrors ssl_sweep.
                 unsigned rb_touch = 0;   // robots that touch the ball in this sweep

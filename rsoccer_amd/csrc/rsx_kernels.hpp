@@ -160,8 +160,8 @@ __device__ __forceinline__ unsigned long long env_lane_mask(const int g) {
 // partner, then the lane walks ITS partners in index order.  First sweep of the run-time-count
 // kernels and second sweep (rare) of all VSS kernels.  Returns whether some pair was deep.
 template <int KIND, int L>
-__device__ __forceinline__ bool vss_sweep_loop(Body& o, const int N, const int g, const bool is_ball,
-                                               const bool ball_low, const Shared<L>& sh) {
+__device__ __forceinline__ bool vss_sweep_loop(const Params& P, Body& o, const int N, const int g, const bool is_ball,
+                                               const bool ball_low, const Shared<L>& sh, bool& wallp) {
     using K = KC<KIND>;
     constexpr int G = 64 / L;
     constexpr uint32_t T_RR = __builtin_bit_cast(uint32_t, K::rs_rr2) - 1u;
@@ -176,6 +176,7 @@ __device__ __forceinline__ bool vss_sweep_loop(Body& o, const int N, const int g
         todo |= ((u < (rb ? T_RB : T_RR)) & (!rb | ball_low)) ? 1u << j : 0u;
     }
     if (todo == 0) return false;
+    const bool v2w = K::wall_aware && __any(!is_ball && at_wall<KIND>(P, o.x, o.y));   // (rsx_body.hpp: contact_response)
     bool deep = false;
     float avx = 0.0f, avy = 0.0f, apx = 0.0f, apy = 0.0f, aw = 0.0f;
     const Body snap = o;   // every partner is evaluated against the snapshot
@@ -187,11 +188,11 @@ __device__ __forceinline__ bool vss_sweep_loop(Body& o, const int N, const int g
         const float wj = sh.W[LaneMap<L>::slot(j, g)];
         const float dx = oj.x - o.x, dy = oj.y - o.y;
         const bool rb = is_ball || j == N;
-        contact_response(snap, oj, fma_(dx, dx, dy * dy), rb ? K::rs_rb : K::rs_rr, rb ? K::ope_rb : K::ope_rr,
+        contact_response<KIND>(P, snap, oj, fma_(dx, dx, dy * dy), rb ? K::rs_rb : K::rs_rr, rb ? K::ope_rb : K::ope_rr,
                          is_ball ? K::w_rb_b : (j == N ? K::w_rb_r : K::w_rr),
                          is_ball ? K::kt_rb_b : (j == N ? K::kt_rb_r : K::kt_rr), rb ? K::mu_rb : K::mu_rr,
                          is_ball ? K::spin_c : 0.0f, fma_(wj, j == N ? K::r_ball : K::r_robot, snap.om * lever),
-                         K::beta, K::pen2, avx, avy, apx, apy, aw, deep);
+                         K::beta, K::pen2, !rb, v2w, avx, avy, apx, apy, aw, deep, wallp);
     }
     // only a body that touched something is updated (the others keep their bits)
     o.vx = o.vx + avx; o.vy = o.vy + avy;
@@ -244,7 +245,7 @@ struct BallOverride { bool ovr, okick; float ovx, ovy, ovz; };
 template <int KIND, int L, int NRX>
 __device__ __forceinline__ bool ssl_sweep(const Params& P, Body& o, const int N, const int g, const int lane,
                                           const bool is_robot, const bool is_ball, const bool ball_low,
-                                          const bool first, Shared<L>& sh, BallOverride& bo) {
+                                          const bool first, Shared<L>& sh, BallOverride& bo, bool& wallp) {
     using K = KC<KIND>;
     constexpr int G = 64 / L;
     constexpr uint32_t T_RR = __builtin_bit_cast(uint32_t, K::rs_rr2) - 1u;
@@ -287,6 +288,7 @@ __device__ __forceinline__ bool ssl_sweep(const Params& P, Body& o, const int N,
         if (RSX_RARE_B(KIND, 2, todo != 0)) {   // per-lane partner walk, see the VSS sweep
             bool& deep = touched;
             got = true;
+            const bool v2w = K::wall_aware && __any(at_wall<KIND>(P, o.x, o.y));   // some robot of the wave (that has a partner) at a wall
             // software-pipelined like the VSS walk: the next partner's slot is fetched while the current response is computed
             int jn = __builtin_ctz(todo);
             todo &= todo - 1;
@@ -303,8 +305,8 @@ __device__ __forceinline__ bool ssl_sweep(const Params& P, Body& o, const int N,
                     nxw = sh.W[LaneMap<L>::slot(jn, g)];
                 }
                 const float dx = oj.x - o.x, dy = oj.y - o.y;
-                contact_response(o, oj, fma_(dx, dx, dy * dy), K::rs_rr, K::ope_rr, K::w_rr, K::kt_rr, K::mu_rr, 0.0f,
-                                 fma_(wj, K::r_robot, o.om * K::r_robot), K::beta, K::pen2, avx, avy, apx, apy, aw, deep);
+                contact_response<KIND>(P, o, oj, fma_(dx, dx, dy * dy), K::rs_rr, K::ope_rr, K::w_rr, K::kt_rr, K::mu_rr, 0.0f,
+                                       fma_(wj, K::r_robot, o.om * K::r_robot), K::beta, K::pen2, true, v2w, avx, avy, apx, apy, aw, deep, wallp);
                 if (!more) break;
             }
         }
@@ -469,6 +471,7 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
             if (sweep == 0) ball_low = sh.zb[g] < K::robot_h;
 #endif
             bool deep = false;   // this lane saw a deep contact
+            bool wallp = false;  // ... a touching robot - robot pair with a wall-blocked axis (model v2: wall_shares)
 
             if (KIND == RSX_KIND_VSS) {
                 // every pair is circle-circle; only the constants depend on the pair type
@@ -519,6 +522,7 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                                 else asm("v_cmp_gt_u32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(todo) : "v"(u[j]), "v"(thr_r) : "vcc");
                             }
                             if (!ball_low) todo = is_ball ? 0u : (todo & ~(1u << NR));
+                            const bool v2w = K::wall_aware && __any(is_robot && at_wall<KIND>(P, o.x, o.y));   // (rsx_body.hpp: contact_response)
                             float avx = 0.0f, avy = 0.0f, apx = 0.0f, apy = 0.0f, aw = 0.0f;
                             const float lever = is_ball ? K::r_ball : K::r_robot;
                             // software-pipelined: the next partner's slot is fetched while the current
@@ -541,12 +545,12 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                                 const float dx = oj.x - o.x, dy = oj.y - o.y;
                                 const float d2 = fma_(dx, dx, dy * dy);   // the value the sweep above saw
                                 const bool rb = is_ball || j == NR;
-                                contact_response(o, oj, d2, rb ? K::rs_rb : K::rs_rr, rb ? K::ope_rb : K::ope_rr,
-                                                 is_ball ? K::w_rb_b : (j == NR ? K::w_rb_r : K::w_rr),
-                                                 is_ball ? K::kt_rb_b : (j == NR ? K::kt_rb_r : K::kt_rr),
-                                                 rb ? K::mu_rb : K::mu_rr, is_ball ? K::spin_c : 0.0f,
-                                                 fma_(wj, j == NR ? K::r_ball : K::r_robot, o.om * lever), K::beta, K::pen2,
-                                                 avx, avy, apx, apy, aw, deep);
+                                contact_response<KIND>(P, o, oj, d2, rb ? K::rs_rb : K::rs_rr, rb ? K::ope_rb : K::ope_rr,
+                                                       is_ball ? K::w_rb_b : (j == NR ? K::w_rb_r : K::w_rr),
+                                                       is_ball ? K::kt_rb_b : (j == NR ? K::kt_rb_r : K::kt_rr),
+                                                       rb ? K::mu_rb : K::mu_rr, is_ball ? K::spin_c : 0.0f,
+                                                       fma_(wj, j == NR ? K::r_ball : K::r_robot, o.om * lever), K::beta, K::pen2, !rb, v2w,
+                                                       avx, avy, apx, apy, aw, deep, wallp);
                                 if (!more) break;
                             }
                             // only a body that touched something is updated (the others keep their bits)
@@ -555,16 +559,27 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                             if (is_ball) o.om = o.om + aw;
                         }
                     } else {
-                        deep = vss_sweep_loop<KIND, L>(o, N, g, is_ball, ball_low, sh);
+                        deep = vss_sweep_loop<KIND, L>(P, o, N, g, is_ball, ball_low, sh, wallp);
                     }
                 }
             } else {
-                deep = ssl_sweep<KIND, L, NR>(P, o, N, g, lane, is_robot && active, is_ball && active, ball_low, sweep == 0, sh, bo);
+                deep = ssl_sweep<KIND, L, NR>(P, o, N, g, lane, is_robot && active, is_ball && active, ball_low, sweep == 0, sh, bo, wallp);
             }
-            // second sweep for the envs in which some pair was deep: one ballot, usually no lane
+            // second sweep for the envs in which some pair was deep: one ballot, usually no lane; a third and a fourth one for the
+            // envs in which the last sweep also saw a wall pair (model v2: piles pressed against a wall)
             const unsigned long long dmask = __ballot(deep);
+#ifdef RSX_V2_TWO_SWEEPS
             if (sweep == 1 || !RSX_RARE_B(KIND, 2, dmask != 0)) break;
-            active = active && (L == 64 ? dmask : (dmask & env_lane_mask<L>(g))) != 0;
+#else
+            if (sweep == 3 || !RSX_RARE_B(KIND, 2, dmask != 0)) break;
+#endif
+            bool again = (L == 64 ? dmask : (dmask & env_lane_mask<L>(g))) != 0;
+            if (sweep >= 1) {
+                const unsigned long long wmask = __ballot(wallp);
+                again = again && (L == 64 ? wmask : (wmask & env_lane_mask<L>(g))) != 0;
+            }
+            active = active && again;
+            if (sweep >= 1 && !__any(active)) break;
             wave_sync();   // every lane has read the first snapshot before it is republished
         }
         if (KIND == RSX_KIND_SSL && bo.ovr) {   // kicker / dribbler: decided in the first sweep, applied after the impulses

@@ -194,11 +194,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
         constexpr float NEAR2 = 0.13f * 0.13f;   // > (dck_rb + ir_tol)^2 + half_kw^2 = 0.126^2 and > rs_rb^2 (rsx_epl_ssl.hpp)
         irbits = 0;
         BallOverride bo{false, false, 0.0f, 0.0f, 0.0f};
-        bool deep_env = false;
+        bool deep_env = false, wall_env = false;
         RSX_QS(0, 1);
-        for (int sweep = 0; sweep < 2; ++sweep) {
-            if (sweep == 1 && !__any(deep_env)) break;   // no env of the wave had a deep pair: no second pair test either
-            const bool active = sweep == 0 || deep_env;
+        for (int sweep = 0; sweep < 4; ++sweep) {
+            // second sweep: envs with a deep pair only; third and fourth: envs whose last sweep also saw a wall pair (model v2)
+            const bool active = sweep == 0 || (deep_env && (sweep == 1 || wall_env));
+            if (sweep >= 1 && !__any(active)) break;   // no env of the wave goes on: no further pair test either
             auto dist2 = [](float xj, float yj, float xi, float yi) -> float {
                 const float dx = xj - xi, dy = yj - yi;
                 return fma_(dx, dx, dy * dy);
@@ -311,7 +312,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
             }
             wave_sync();
             const unsigned near = nf;
-            bool deep = false;
+            bool deep = false, wallp = false;
+            bool aw_ = false;   // does any robot of the wave's active envs stand at a wall?  (wave-uniform, once per sweep: contact_response, rsx_body.hpp)
+            if (active) {
+#pragma unroll
+                for (int m = 0; m < R; ++m) aw_ |= at_wall<KIND>(P, r[m].x, r[m].y);   // (a ghost slot's NaN compares false)
+            }
+            const bool v2w = __any(aw_);
             unsigned rb_touch = 0;   // my robots that touch the ball in this sweep
             unsigned todo[R];   // partner sets (Jacobi: nothing has moved since the pair test)
             {   // bit = robot index: the relative order rotated into place by 6 p
@@ -347,8 +354,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
                         const float d2 = fma_(dx, dx, dy * dy);
                         if (d2 > 0.0f) {   // (0: two robots in one place are not a contact, rsx_kernels.hpp)
                             hit = true;
-                            contact_response(r[i], oj, d2, K::rs_rr, K::ope_rr, K::w_rr, K::kt_rr, K::mu_rr, 0.0f,
-                                             fma_(wj, K::r_robot, r[i].om * K::r_robot), K::beta, K::pen2, avx, avy, apx, apy, unused, deep);
+                            contact_response<KIND>(P, r[i], oj, d2, K::rs_rr, K::ope_rr, K::w_rr, K::kt_rr, K::mu_rr, 0.0f,
+                                                   fma_(wj, K::r_robot, r[i].om * K::r_robot), K::beta, K::pen2, true, v2w, avx, avy, apx, apy, unused, deep, wallp);
                         }
                     }
                     bool touch = false;
@@ -452,8 +459,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
                     ball.om = ball.om + bw;
                 }
             }
-            const unsigned dm = deep ? 1u : 0u;
-            deep_env = ((dm | qdpp_u<Q_NEXT>(dm)) | (qdpp_u<Q_DIAG>(dm) | qdpp_u<Q_PREV>(dm))) != 0u;
+            const unsigned dm = (deep ? 1u : 0u) | (wallp ? 2u : 0u);
+            const unsigned de = (dm | qdpp_u<Q_NEXT>(dm)) | (qdpp_u<Q_DIAG>(dm) | qdpp_u<Q_PREV>(dm));
+            deep_env = (de & 1u) != 0u; wall_env = (de & 2u) != 0u;
             wave_sync();   // every lane has read the snapshot before it is republished
         }
         if (bo.ovr) {   // kicker: decided in the first sweep, applied after the impulses
