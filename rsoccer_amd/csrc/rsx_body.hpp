@@ -62,7 +62,6 @@ __device__ __forceinline__ void walls(const Params& P, const float r, const floa
         const bool fx0 = hx & (vx * sx > 0.0f);
         x = hx ? sx * xl : x; vx = fx0 ? -rest * vx : vx; ax = hx ? xl : ax;
         hit = (fx0 ? 1 : 0) | (fy0 ? 2 : 0);
-#ifndef RSX_V2_NO_POSTS
         {   // goal posts (model v2): the open ends of the goal's side walls are points at (+-L/2, +-goal_width/2) that a body keeps
             // its radius from — without them a body overlaps the wall's end from the field side and is thrown sideways by the
             // side-wall clamp the moment it crosses the goal line.  Folded into the first quadrant, n points post -> body;
@@ -82,7 +81,6 @@ __device__ __forceinline__ void walls(const Params& P, const float r, const floa
             hit |= fp ? 4 : 0;
             }
         }
-#endif
         if (ax > P.half_len) {   // beyond a goal line: the goal's walls (rare)
             const float back = P.half_len + P.gd;
             const bool in_mouth = ay < P.ghw;
@@ -104,8 +102,7 @@ __device__ __forceinline__ void walls(const Params& P, const float r, const floa
 }
 
 // Is this body anywhere near a wall?  walls<KIND> with a robot's radius (and, a fortiori, the ball's) changes nothing outside this
-// region — SSL: |x| <= L/2 (no goal geometry), |y| <= W/2 + margin - r_robot and farther than r_robot from every goal post; VSS:
-// |x| <= L/2 - r_robot and |y| <= W/2 - r_robot — so kernels test a whole wave's bodies with this and skip the clamp when none is out there (the division-A
+// region — |x| <= L/2 - r_robot (SSL: no goal post within reach, no goal geometry) and |y| <= W/2 + margin - r_robot — so kernels test a whole wave's bodies with this and skip the clamp when none is out there (the division-A
 // field is 12 m x 9 m: most sub-steps).  NaN ("ghost" slots of rsx_quad_ssl.hpp) compares false.
 template <int KIND>
 __device__ __forceinline__ bool near_walls(const Params& P, const float x, const float y) {
@@ -113,16 +110,10 @@ __device__ __forceinline__ bool near_walls(const Params& P, const float x, const
 #ifdef RSX_NO_WALL_SKIP   // development A/B: always run the clamp
     return true;
 #endif
-    if (KIND == RSX_KIND_VSS) return (fabsf(x) > P.half_len - K::r_robot) | (fabsf(y) > P.half_wid - K::r_robot);
-#ifdef RSX_V2_LOOSE_NEAR
+    // one form for both classes (K::margin is 0 for VSS).  SSL: the strip of a robot's radius before the goal lines is there for the goal
+    // posts only; testing |y| against the posts as well would be exact, but costs two more DEPENDENT instructions at the end of every
+    // sub-step of every wave (measured: +1.3 % on the 1v6 and 11v11 steps at the latency-bound batches) to save a rare clamp
     return (fabsf(x) > P.half_len - K::r_robot) | (fabsf(y) > (P.half_wid + K::margin) - K::r_robot);
-#endif
-#ifdef RSX_V2_NO_POSTS
-    return (fabsf(x) > P.half_len) | (fabsf(y) > (P.half_wid + K::margin) - K::r_robot);
-#endif
-    // SSL: beyond a goal line, at a boundary wall, or within a robot's radius of a goal post
-    return (fabsf(x) > P.half_len) | (fabsf(y) > (P.half_wid + K::margin) - K::r_robot) |
-           ((fabsf(x) > P.half_len - K::r_robot) & (fabsf(fabsf(y) - P.ghw) < K::r_robot));
 }
 
 // Is a robot's centre within 2 mm of where the wall clamp acts on it (or beyond)?  The probes of wall_shares lie within 1 mm of the

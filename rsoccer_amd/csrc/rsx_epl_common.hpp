@@ -103,7 +103,7 @@ __device__ __forceinline__ void epl_walk_pairs(const Params& P, const Body* r, c
 #pragma unroll
         for (int k = 0; k < N; ++k) aw_ |= at_wall<KIND>(P, r[k].x, r[k].y);
     }
-    const bool v2w = KC<KIND>::wall_aware && __any(aw_);
+    const bool v2w = KC<KIND>::wall_aware && __ballot(aw_) != 0ull;
     using K = KC<KIND>;
     while (todo) {
         const int p = __builtin_ctz(todo);

@@ -176,7 +176,7 @@ __device__ __forceinline__ bool vss_sweep_loop(const Params& P, Body& o, const i
         todo |= ((u < (rb ? T_RB : T_RR)) & (!rb | ball_low)) ? 1u << j : 0u;
     }
     if (todo == 0) return false;
-    const bool v2w = K::wall_aware && __any(!is_ball && at_wall<KIND>(P, o.x, o.y));   // (rsx_body.hpp: contact_response)
+    const bool v2w = K::wall_aware && __ballot(!is_ball && at_wall<KIND>(P, o.x, o.y)) != 0ull;   // (rsx_body.hpp: contact_response)
     bool deep = false;
     float avx = 0.0f, avy = 0.0f, apx = 0.0f, apy = 0.0f, aw = 0.0f;
     const Body snap = o;   // every partner is evaluated against the snapshot
@@ -288,7 +288,7 @@ __device__ __forceinline__ bool ssl_sweep(const Params& P, Body& o, const int N,
         if (RSX_RARE_B(KIND, 2, todo != 0)) {   // per-lane partner walk, see the VSS sweep
             bool& deep = touched;
             got = true;
-            const bool v2w = K::wall_aware && __any(at_wall<KIND>(P, o.x, o.y));   // some robot of the wave (that has a partner) at a wall
+            const bool v2w = K::wall_aware && __ballot(at_wall<KIND>(P, o.x, o.y)) != 0ull;   // some robot of the wave (that has a partner) at a wall
             // software-pipelined like the VSS walk: the next partner's slot is fetched while the current response is computed
             int jn = __builtin_ctz(todo);
             todo &= todo - 1;
@@ -522,7 +522,7 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                                 else asm("v_cmp_gt_u32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(todo) : "v"(u[j]), "v"(thr_r) : "vcc");
                             }
                             if (!ball_low) todo = is_ball ? 0u : (todo & ~(1u << NR));
-                            const bool v2w = K::wall_aware && __any(is_robot && at_wall<KIND>(P, o.x, o.y));   // (rsx_body.hpp: contact_response)
+                            const bool v2w = K::wall_aware && __ballot(is_robot && at_wall<KIND>(P, o.x, o.y)) != 0ull;   // (rsx_body.hpp: contact_response)
                             float avx = 0.0f, avy = 0.0f, apx = 0.0f, apy = 0.0f, aw = 0.0f;
                             const float lever = is_ball ? K::r_ball : K::r_robot;
                             // software-pipelined: the next partner's slot is fetched while the current

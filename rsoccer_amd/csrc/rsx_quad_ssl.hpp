@@ -318,7 +318,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
 #pragma unroll
                 for (int m = 0; m < R; ++m) aw_ |= at_wall<KIND>(P, r[m].x, r[m].y);   // (a ghost slot's NaN compares false)
             }
-            const bool v2w = __any(aw_);
+            const bool v2w = __ballot(aw_) != 0ull;
             unsigned rb_touch = 0;   // my robots that touch the ball in this sweep
             unsigned todo[R];   // partner sets (Jacobi: nothing has moved since the pair test)
             {   // bit = robot index: the relative order rotated into place by 6 p

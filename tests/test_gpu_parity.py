@@ -304,17 +304,17 @@ def test_full_size_soak_invariants(task, kind, ft, nb, ny, B, steps):
     assert np.array_equal(out[0], out[1])
 
 
-RR_WORST_CM, RR_P99_CM = 4.5, 2.0   # measured envelope of the scrum below (MI355X: see the assertion message)
+RR_WORST_CM, RR_P99_CM = 1.5, 0.7   # model v2; measured on MI355X: 1.32 / 0.47 (model v1: 4.0-4.5 / 1.7-2.0)
 
 
 def test_crowded_11v11_full_size_contact_invariants():
     """BASELINE.json configs[3] at its full size: 1024 envs x 22 robots on the division-A field, all of
     them chasing the ball (a 22-robot scrum: the worst case for the all-pairs contact sweeps), random
     kicks and dribblers, 1000 steps.  Size-independent properties: everything finite and inside the
-    walls, robot-robot overlap below a third of a diameter even in the jammed pile (two Jacobi
-    sweeps per sub-step; the residual behaves like a penalty spring; oracle-calibrated:
-    worst 4.1 cm over 160 envs x 1000 steps), and the ball centre never deep inside
-    a kicker face (4 cm in the worst squeeze)."""
+    walls, robot-robot overlap below a tenth of a diameter even in a pile that the robots' own push presses against a
+    wall, into a corner or into a goal (model v2: wall-aware shares, third and fourth sweep at walls, goal posts — DESIGN.md 4,
+    profiles/r05_jam_model_v2.txt; the CPU definition of the model gives worst 1.32 cm, p99 0.47 cm over 256 envs x 1000 steps),
+    and the ball centre never deep inside a kicker face."""
     import torch
     L = _lib()
     B, N = 1024, 22
@@ -365,11 +365,8 @@ def test_crowded_11v11_full_size_contact_invariants():
     if os.environ.get("RSX_PRINT_ENVELOPE"):
         print(f"crowded 11v11 envelope: worst robot-robot overlap {worst_rr * 100:.2f} cm, p99 {p99 * 100:.2f} cm, "
               f"worst ball-in-kicker {worst_rb * 100:.2f} cm")
-    # The bounds are the MEASURED envelope of the frozen model, not a tuning target: a change that makes
-    # the jam behaviour worse has to fail here.  Why centimetres at all: every sample deeper than 2.5 cm is a pile that
-    # the robots' own push holds against a goal's back wall or the boundary wall — phase C clamps bodies into the field
-    # AFTER the contact phase of the sub-step, which puts a robot the pile squeezed over the line back into its
-    # neighbour; more Jacobi sweeps or projection passes do not remove it (profiles/r03_jam_experiment.txt).
+    # In the open the contact model holds 4-5 mm; what is left above that sits at walls, corners and goals (tools/exp_jam2.py).  A change
+    # that makes the jam behaviour worse has to fail here.
     msg = (f"worst robot-robot overlap {worst_rr * 100:.2f} cm (bound %s), p99 {p99 * 100:.2f} cm (bound %s): the wall-pile "
            "residual of the contact model grew — see DESIGN.md 4") % (RR_WORST_CM, RR_P99_CM)
     assert 0.005 < worst_rr < RR_WORST_CM / 100.0, msg      # it IS a scrum, and nothing tunnels
