@@ -149,7 +149,11 @@ int rsx_get_field_params(const rsx_sim* h, double out[RSX_FIELD_PARAMS]);
 int rsx_reset(rsx_sim* h, const double* ball, const double* blue, const double* yellow,
               const uint8_t* env_mask, void* stream);
 
-/* step(cmds) — rsim.py:102 (VSS, [B][N][2]) and rsim.py:155 (SSL, [B][N][8]); host f64. */
+/* step(cmds) — rsim.py:102 (VSS, [B][N][2]) and rsim.py:155 (SSL, [B][N][8]); host f64.
+ * The device-side command buffer (rsx_dev_view.cmds, what rsx_step_dev reads) is UNSPECIFIED after this call: handles of at
+ * most 64 envs read the commands straight from pinned host memory and never write them there.  Callers that mix the host-format
+ * and the device-resident calls fill view.cmds themselves before rsx_step_dev (results of rsx_step itself do not depend on the
+ * path: tests/test_gpu_parity.py::test_host_format_step_with_and_without_zero_copy). */
 int rsx_step(rsx_sim* h, const double* cmds, void* stream);
 
 /* get_state() — rsim.py:105,158; out [B][state_dim] host f64 */

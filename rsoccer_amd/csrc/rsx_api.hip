@@ -71,13 +71,13 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #ifndef RSX_EPL_MIN_ENVS_SSL
 #define RSX_EPL_MIN_ENVS_SSL 65536
 #endif
-// largest batch whose host-format step (rsx_step / rsx_step_state) lets the kernel read the commands from, and mirror the
-// state into, pinned host memory (one launch + one synchronisation; PCIe latency instead of two copy engines' worth of it)
 // largest batch whose single-step launches carry placement-helper workgroups (rsx_kernels.hpp: placement_helper): where a
 // launch is as long as its slowest wave and half of the SIMDs are idle anyway
 #ifndef RSX_PCACHE_MAX_ENVS
 #define RSX_PCACHE_MAX_ENVS 16384
 #endif
+// largest batch whose host-format step (rsx_step / rsx_step_state) lets the kernel read the commands from, and mirror the
+// state into, pinned host memory (one launch + one synchronisation; PCIe latency instead of two copy engines' worth of it)
 #ifndef RSX_ZERO_COPY_MAX_ENVS
 #define RSX_ZERO_COPY_MAX_ENVS 64
 #endif

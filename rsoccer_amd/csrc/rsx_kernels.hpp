@@ -132,8 +132,9 @@ __device__ __forceinline__ const float& at_byte(const float* base, const ix_t of
 
 // Which lane holds body j of the wave's env g (and which LDS slot: slot = lane).  Body-major (lane = j * G + g: the G lanes
 // that own "body j" of neighbouring envs are adjacent, every row access is G * 4 contiguous bytes) for L >= 16; env-major
-// (lane = g * L + j: an env's eight bodies are eight adjacent lanes, i.e. half a DPP row) for L == 8, where the all-pairs test
-// reads its partners' positions through DPP row shifts instead of an LDS round trip (RSX_ENV_MAJOR=0: body-major everywhere).
+// (lane = g * L + j: an env's eight bodies are eight adjacent lanes) for L == 8 — measured -1 % at 4096 envs, +2-3 % at 65 536
+// (RSX_ENV_MAJOR=0: body-major everywhere).  Partners are read through the LDS snapshot in every width (reading them through DPP
+// row shifts was measured and dropped: profiles/LABBOOK.md).
 #ifndef RSX_ENV_MAJOR
 #define RSX_ENV_MAJOR 1
 #endif
@@ -742,6 +743,15 @@ __device__ __forceinline__ int zigzag_per(const bool dev, const uint32_t tick, c
 // follow carry everything else and are fetched while the state loads are in flight.
 #define RSX_HOT_ARGS float* hp_state, float* hp_aux, const float* hp_in, uint8_t* hp_flags, \
                      const int hp_num_envs, const int hp_state_dim, const int hp_per_xcd, const int hp_n_steps
+// bytes of the kernarg segment RSX_HOT_ARGS occupies: the by-value Params block starts at the next multiple of its alignment
+// (the late parameter fetch below and in rsx_quad_ssl.hpp reads it from there — keep the two in step when a hot argument is added)
+constexpr size_t RSX_HOT_ARGS_BYTES = 4 * sizeof(void*) + 4 * sizeof(int);
+constexpr size_t RSX_PARAMS_KERNARG_OFFSET = (RSX_HOT_ARGS_BYTES + alignof(Params) - 1) / alignof(Params) * alignof(Params);
+namespace hot_args_check {   // the macro and the constant cannot drift apart: a function with exactly these parameters
+inline void probe(RSX_HOT_ARGS) {}
+template <typename... A> constexpr size_t bytes_of(void (*)(A...)) { return (sizeof(A) + ... + 0); }
+static_assert(bytes_of(&probe) == RSX_HOT_ARGS_BYTES, "RSX_HOT_ARGS changed: update RSX_HOT_ARGS_BYTES (kernarg offset of Params)");
+}
 
 // =============================================================================================
 // raw simulator step: robosim.step(cmds) + get_state() on the SoA buffers
@@ -1605,7 +1615,7 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
                 // segment HERE, behind an opaque pointer, instead of being loaded at the kernel's entry and parked in VGPR lanes across
                 // the physics (these kernels run out of scalar registers: ~40 v_writelane at entry, ~60 v_readlane after the physics)
                 typedef const __attribute__((address_space(4))) uint32_t* kw_t;
-                constexpr size_t KOFF = (4 * sizeof(void*) + 4 * sizeof(int) + alignof(Params) - 1) / alignof(Params) * alignof(Params);   // after RSX_HOT_ARGS
+                constexpr size_t KOFF = RSX_PARAMS_KERNARG_OFFSET;   // after RSX_HOT_ARGS
                 static_assert(sizeof(Params) % 4 == 0 && KOFF % 4 == 0, "parameter block in dwords");
                 kw_t pk = (kw_t)__builtin_amdgcn_kernarg_segment_ptr() + KOFF / 4;
                 asm volatile("" : "+s"(pk));

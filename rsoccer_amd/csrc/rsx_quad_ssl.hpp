@@ -484,7 +484,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
 #if RSX_QUAD_LATE_PARAMS
     {   // what the rest of the step reads of the parameter block: fetched from the kernarg segment here instead of parked in VGPR lanes across the physics (rsx_kernels.hpp, RSX_LATE_PARAMS)
         typedef const __attribute__((address_space(4))) uint32_t* kw_t;
-        constexpr size_t KOFF = (4 * sizeof(void*) + 4 * sizeof(int) + alignof(Params) - 1) / alignof(Params) * alignof(Params);
+        constexpr size_t KOFF = RSX_PARAMS_KERNARG_OFFSET;   // rsx_kernels.hpp, tied to RSX_HOT_ARGS by a static_assert
         kw_t pk = (kw_t)__builtin_amdgcn_kernarg_segment_ptr() + KOFF / 4;
         asm volatile("" : "+s"(pk));
         struct Words { uint32_t w[sizeof(Params) / 4]; } raww;

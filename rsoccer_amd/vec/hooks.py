@@ -129,12 +129,13 @@ class _VecBaseEnv:
             ended = done | truncated
             info["final_obs"] = obs.clone()     # the hook may hand out a buffer it reuses
             if self._device_placement is None:
-                # step() before any reset(): not yet known what the placement hook returns.  One placement of the
-                # ended envs tells (the hook is never called just to look at its return type: a user's hook draws
-                # from its own random stream)
-                self._place(ended)
-                self.steps.masked_fill_(ended, 0)
-                obs = torch.where(ended[:, None], self._frame_to_observations(), obs)
+                # step() before any reset(): not yet known what the placement hook returns.  The first placement of envs that
+                # really ended tells — the hook is never called just to look at its return type (a user's hook draws from its
+                # own random stream: runs that do and do not reset() first must see the same stream)
+                if bool(ended.any()):
+                    self._place(ended)
+                    self.steps.masked_fill_(ended, 0)
+                    obs = torch.where(ended[:, None], self._frame_to_observations(), obs)
             elif self._device_placement:
                 # device placement: stream-ordered and masked on the device, no host round trip — every step
                 self._place(ended)

@@ -87,6 +87,8 @@ class VSSEnv(VSSBaseEnv):
 
     def _get_commands(self, actions):
         nb, ny = self.n_robots_blue, self.n_robots_yellow
+        if type(self)._actions_to_v_wheels is not VSSEnv._actions_to_v_wheels:
+            return self._get_commands_per_robot(actions)   # a subclass replaced the reference's extension point: honour it
         rows = np.empty((nb + ny, 2), dtype=np.float64)
         # the agent's pair keeps the dtype of the action (a float32 action gives float32 wheel speeds in the reference:
         # max_v and the wheel radius are python floats), the noise rows are float64
@@ -102,6 +104,24 @@ class VSSEnv(VSSBaseEnv):
                                                           v_wheel0=agent[0] if k == 0 else row[0],
                                                           v_wheel1=agent[1] if k == 0 else row[1]))
         commands.agent = agent     # the agent's pair in the action's dtype (what the energy penalty sums)
+        return commands
+
+    def _get_commands_per_robot(self, actions):
+        """the reference's robot-by-robot form (vss_gym.py:119-142) through _actions_to_v_wheels — taken when a subclass overrides
+        that hook (another dead zone, another clipping); same sampling order of the noise as the array form"""
+        nb, ny = self.n_robots_blue, self.n_robots_yellow
+        rows = np.empty((nb + ny, 2), dtype=np.float64)
+        self.actions = {0: actions}
+        agent = np.asarray(self._actions_to_v_wheels(actions))
+        rows[0] = agent
+        if self._ou_bank is not None:
+            noise = self._ou_bank.sample()
+            for k in range(1, nb + ny):
+                rows[k] = self._actions_to_v_wheels(noise[k - 1])
+            for i in range(1, nb):
+                self.actions[i] = noise[i - 1]
+        commands = CommandRows(rows, lambda k, row: Robot(yellow=k >= nb, id=k - nb if k >= nb else k, v_wheel0=row[0], v_wheel1=row[1]))
+        commands.agent = agent
         return commands
 
     def _wheel_speeds(self, fractions):

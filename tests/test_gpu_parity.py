@@ -1333,3 +1333,55 @@ def test_piles_pressed_against_walls_fused_tasks_bitexact(oracle_mod, monkeypatc
                     pass
     assert seen or task == 2   # (1v6: the six defenders never drive — their piles are resolved once and stay apart)
     sim.close()
+
+
+@pytest.mark.parametrize("kind,ft,nb,ny", [(0, 0, 3, 3), (1, 2, 1, 6)])
+def test_host_format_step_with_and_without_zero_copy(oracle_mod, kind, ft, nb, ny):
+    """rsx_step / rsx_step_state of a small handle read the commands from, and mirror the state into, pinned host memory (one
+    launch, no copies); RSX_NO_ZERO_COPY=1 takes the copy path of the large handles.  Same results, bit for bit, also when host-
+    format and device-resident steps alternate (the device command buffer is the caller's between them: rsx.h)."""
+    import subprocess, sys, json
+    child = r'''
+import sys, os, json
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from rsoccer_amd import _lib as L
+kind, ft, nb, ny = map(int, sys.argv[1:5])
+B, N = 5, nb + ny
+sim = L.Sim(kind, ft, nb, ny, 25, B)
+rng = np.random.default_rng(4)
+out = []
+for t in range(30):
+    cm = rng.uniform(-1, 1, (B, N, sim.cmd_dim)) * (30.0 if kind == 0 else 1.5)
+    if kind == 1: cm[:, :, 0] = 0; cm[:, :, 4:] = 0
+    if t % 3 == 2:      # a device-resident step in between: the caller fills the command buffer
+        sim.cmds_tensor().copy_(torch.from_numpy(cm.transpose(1, 2, 0).reshape(N * sim.cmd_dim, B).astype(np.float32)))
+        sim.step_dev(); out.append(sim.get_state_full().tolist())
+    else:
+        out.append(sim.step_state(np.ascontiguousarray(cm)).tolist())
+print(json.dumps(out))
+'''
+    res = []
+    for env in ({}, {"RSX_NO_ZERO_COPY": "1"}):
+        r = subprocess.run([sys.executable, "-c", child, str(kind), str(ft), str(nb), str(ny)], env=dict(os.environ, **env),
+                           capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert res[0] == res[1]
+    # and the oracle agrees with the host-format steps
+    O = oracle_mod
+    rng = np.random.default_rng(4)
+    refs = _mk_oracles(O, kind, ft, nb, ny, 5)
+    N = nb + ny
+    cd = 2 if kind == 0 else 8
+    for t in range(30):
+        cm = rng.uniform(-1, 1, (5, N, cd)) * (30.0 if kind == 0 else 1.5)
+        if kind == 1:
+            cm[:, :, 0] = 0; cm[:, :, 4:] = 0
+        cm32 = cm.astype(np.float32).astype(np.float64)
+        for e in range(5):
+            refs[e].step(cm32[e] if t % 3 == 2 else cm[e])
+        got = np.array(res[0][t])
+        for e in range(5):
+            w = refs[e].get_state_full() if t % 3 == 2 else refs[e].get_state()
+            assert f32_equal(got[e][:len(w)], w), mismatch_report(got[e][:len(w)], w, f"env {e} step {t}")
