@@ -116,6 +116,18 @@ __device__ __forceinline__ bool near_walls(const Params& P, const float x, const
     return (fabsf(x) > P.half_len - K::r_robot) | (fabsf(y) > (P.half_wid + K::margin) - K::r_robot);
 }
 
+// The same gate without the loose strip — SSL: beyond a goal line, at a boundary wall, or within a robot's radius of a goal post.  For
+// the large-batch kernels of the many-robot tasks (one / four lanes per env), which are bound by instruction issue, not by the length of
+// a wave's dependent chain: there the extra instructions per body are cheaper than the eight (or twenty-three) clamps a wave runs when
+// some body sits in the strip before a goal line (SSLStaticDefenders: the ball on its way into the goal).
+template <int KIND>
+__device__ __forceinline__ bool near_walls_exact(const Params& P, const float x, const float y) {
+    using K = KC<KIND>;
+    if (KIND == RSX_KIND_VSS) return near_walls<KIND>(P, x, y);
+    return (fabsf(x) > P.half_len) | (fabsf(y) > (P.half_wid + K::margin) - K::r_robot) |
+           ((fabsf(x) > P.half_len - K::r_robot) & (fabsf(fabsf(y) - P.ghw) < K::r_robot));
+}
+
 // Is a robot's centre within 2 mm of where the wall clamp acts on it (or beyond)?  The probes of wall_shares lie within 1 mm of the
 // body, so a pair of which NEITHER body is at_wall has unblocked probes by construction and keeps the plain 1/2 : 1/2 shares —
 // the limits are those of the clamp minus 2 mm (one of them rounding slack).  (Computed from the fields the kernels hold anyway: two

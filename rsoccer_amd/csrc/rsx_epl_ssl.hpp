@@ -324,9 +324,11 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
             }
             // C: walls
             {   // only when some body of the wave is near a wall (near_walls, rsx_body.hpp: the clamp is the identity elsewhere)
-                bool nw = near_walls<KIND>(P, ball.x, ball.y);
+                // (the exact gate where eight clamps are at stake — 1v6, 1v4; the three-instruction one for the two-robot tasks)
+                constexpr bool XG = N >= 5;
+                bool nw = XG ? near_walls_exact<KIND>(P, ball.x, ball.y) : near_walls<KIND>(P, ball.x, ball.y);
 #pragma unroll
-                for (int k = 0; k < N; ++k) nw |= near_walls<KIND>(P, r[k].x, r[k].y);
+                for (int k = 0; k < N; ++k) nw |= XG ? near_walls_exact<KIND>(P, r[k].x, r[k].y) : near_walls<KIND>(P, r[k].x, r[k].y);
                 if (__any(nw)) {
 #pragma unroll
                     for (int k = 0; k < N; ++k) robot_walls<KIND>(P, r[k]);

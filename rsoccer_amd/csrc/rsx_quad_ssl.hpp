@@ -470,9 +470,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
         }
         // C: walls — only when some body of the wave is near one (near_walls, rsx_body.hpp: exact, the clamp is the identity elsewhere)
         {
-            bool nw = near_walls<KIND>(P, ball.x, ball.y);
+            bool nw = near_walls_exact<KIND>(P, ball.x, ball.y);
 #pragma unroll
-            for (int m = 0; m < R; ++m) nw |= near_walls<KIND>(P, r[m].x, r[m].y);
+            for (int m = 0; m < R; ++m) nw |= near_walls_exact<KIND>(P, r[m].x, r[m].y);
             if (__any(nw)) {
 #pragma unroll
                 for (int m = 0; m < R; ++m) { robot_walls<KIND>(P, r[m]); __builtin_amdgcn_sched_barrier(0); }
