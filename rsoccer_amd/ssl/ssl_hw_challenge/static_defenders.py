@@ -69,7 +69,8 @@ class SSLHWStaticDefendersEnv(SSLBaseEnv):
         return np.array(obs, dtype=np.float32)
 
     def _get_commands(self, actions):
-        heading = np.deg2rad(self.frame.robots_blue[0].theta)
+        st = self.frame.state          # the simulator's vector when the frame was parsed from one: no records are built
+        heading = np.deg2rad(st[7] if st is not None else self.frame.robots_blue[0].theta)
         v_x, v_y, v_theta = self.convert_actions(actions, heading)
         return [Robot(yellow=False, id=0, v_x=v_x, v_y=v_y, v_theta=v_theta,
                       kick_v_x=self.kick_speed_x if actions[3] > 0 else 0.0,
@@ -91,19 +92,24 @@ class SSLHWStaticDefendersEnv(SSLBaseEnv):
         total = self.reward_shaping_total
         fld = self.field
         half_len, half_wid = fld.length / 2, fld.width / 2
-        ball, robot = self.frame.ball, self.frame.robots_blue[0]
-        in_gk_area = robot.x > half_len - fld.penalty_length and abs(robot.y) < fld.penalty_width / 2
-        if robot.x < -0.2 or abs(robot.y) > half_wid:
+        st = self.frame.state
+        if st is not None:             # ball x, y = st[0], st[1]; blue 0 x, y = st[5], st[6] (Entities/Frame.py:55-92)
+            ball_x, ball_y, robot_x, robot_y = st[0], st[1], st[5], st[6]
+        else:
+            ball, robot = self.frame.ball, self.frame.robots_blue[0]
+            ball_x, ball_y, robot_x, robot_y = ball.x, ball.y, robot.x, robot.y
+        in_gk_area = robot_x > half_len - fld.penalty_length and abs(robot_y) < fld.penalty_width / 2
+        if robot_x < -0.2 or abs(robot_y) > half_wid:
             total["done_rbt_out"] += 1
             return 0, True
         if in_gk_area:
             total["rbt_in_gk_area"] += 1
             return 0, True
-        if ball.x < 0 or abs(ball.y) > half_wid:
+        if ball_x < 0 or abs(ball_y) > half_wid:
             total["done_ball_out"] += 1
             return 0, True
-        if ball.x > half_len:
-            if abs(ball.y) < fld.goal_width / 2:
+        if ball_x > half_len:
+            if abs(ball_y) < fld.goal_width / 2:
                 total["goal"] += 1
                 return 5, True
             total["done_ball_out_right"] += 1
@@ -145,21 +151,36 @@ class SSLHWStaticDefendersEnv(SSLBaseEnv):
     # ---- reward terms ----
     @staticmethod
     def _dist(ax, ay, bx, by):
-        return np.linalg.norm(np.array([ax, ay]) - np.array([bx, by]))
+        # = np.linalg.norm(np.array([ax, ay]) - np.array([bx, by])), spelled as what norm() does for a vector (sqrt of x.dot(x):
+        # the same two calls, without its argument handling)
+        d = np.array([ax, ay]) - np.array([bx, by])
+        return np.sqrt(d.dot(d))
+
+    @staticmethod
+    def _ball_and_robot(frame):
+        st = frame.state
+        if st is not None:
+            return st[0], st[1], st[5], st[6]
+        return frame.ball.x, frame.ball.y, frame.robots_blue[0].x, frame.robots_blue[0].y
 
     def _ball_dist_rw(self):
-        lf, f = self.last_frame, self.frame
-        before = self._dist(lf.robots_blue[0].x, lf.robots_blue[0].y, lf.ball.x, lf.ball.y)
-        after = self._dist(f.robots_blue[0].x, f.robots_blue[0].y, f.ball.x, f.ball.y)
+        lbx, lby, lrx, lry = self._ball_and_robot(self.last_frame)
+        bx, by, rx, ry = self._ball_and_robot(self.frame)
+        before = self._dist(lrx, lry, lbx, lby)
+        after = self._dist(rx, ry, bx, by)
         return np.clip(before - after, -1, 1)
 
     def _ball_grad_rw(self):
         goal_x = self.field.length / 2
-        lf, f = self.last_frame, self.frame
-        before = self._dist(goal_x, 0.0, lf.ball.x, lf.ball.y)
-        after = self._dist(goal_x, 0.0, f.ball.x, f.ball.y)
+        lbx, lby, _, _ = self._ball_and_robot(self.last_frame)
+        bx, by, _, _ = self._ball_and_robot(self.frame)
+        before = self._dist(goal_x, 0.0, lbx, lby)
+        after = self._dist(goal_x, 0.0, bx, by)
         return np.clip(before - after, -1, 1)
 
     def _energy_pen(self):
+        st = self.frame.state
+        if st is not None:
+            return abs(st[12]) + abs(st[13]) + abs(st[14]) + abs(st[15])   # blue 0: v_wheel0..3
         r = self.frame.robots_blue[0]
         return abs(r.v_wheel0) + abs(r.v_wheel1) + abs(r.v_wheel2) + abs(r.v_wheel3)
