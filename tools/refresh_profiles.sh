@@ -14,7 +14,7 @@ find $OUT/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/benc
 head -3 $OUT/bench_kernel_stats.csv
 # HBM traffic counters, one pass each, no tracing
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-rollout > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-rollout --no-extra > $OUT/pmc_$c.log 2>&1   # (--no-extra: counter collection does not survive the graph-capture legs)
 done
 python tools/pmc_summary.py $OUT > $OUT/hbm_traffic.json
 cat $OUT/hbm_traffic.json | head -12
