@@ -163,3 +163,42 @@ def test_refining_the_sub_step_changes_a_single_contact_trajectory_by_order_h(ba
     assert d1 < 3 * v * 4e-3 and d2 < 3 * v * 2e-3, (d1, d2)
     assert abs(a[3] - c[3]) < 0.05 * abs(c[3]), (a[3], c[3])
     assert abs(a[5] - c[5]) < 2e-3                           # the robot was pushed (then braked by its motors) the same way
+
+
+# ---- model v2 (round 5): piles pressed on walls, recorded from the float64 oracle by tests/golden/make_model_v2.py ----
+V2_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model_v2_piles.npz")
+V2_SHA256 = "c2330bf6be7dc3dc9e75242f533f79a5a94a71b29d5d25b6c91fbfa9a09a0943"
+
+
+def test_model_v2_regression_arrays_are_frozen():
+    z = np.load(V2_GOLDEN)
+    h = hashlib.sha256()
+    for k in sorted(z.files):
+        a = np.ascontiguousarray(z[k])
+        h.update(k.encode()); h.update(str(a.dtype).encode()); h.update(str(a.shape).encode()); h.update(a.tobytes())
+    assert len(z.files) == 6
+    assert h.hexdigest() == V2_SHA256, "the recorded wall-pile trajectories changed: model v2 of DESIGN.md 4 is frozen"
+
+
+@pytest.mark.parametrize("k", [0, 1])
+def test_model_v2_piles_are_reproduced_and_are_piles_at_walls(oracle_mod, k):
+    """the oracle reproduces the recorded 22-robot scrums (300 steps each, sampled every 20th), and the recordings ARE what they are
+    for: a pile at the walls (some robot at a boundary limit) that stays a pile of discs (overlap below 1 cm) — the wall-aware shares,
+    the third / fourth sweep and the wall clamp all take part in every sample"""
+    z = np.load(V2_GOLDEN)
+    e = oracle_mod.OracleEnv(1, 1, 11, 11, 25, "f64")
+    e.set_state_full(z[f"scrum{k}_reset_state"])
+    cmds, want = z[f"scrum{k}_cmds"].astype(np.float64), z[f"scrum{k}_states"]
+    f = e.field_params()
+    xl, yl = f[0] / 2 + 0.3 - 0.09, f[1] / 2 + 0.3 - 0.09
+    at_wall = 0
+    for t in range(len(cmds)):
+        e.step(cmds[t])
+        if t % 20 == 19:
+            got = e.get_state_full()
+            assert np.allclose(got, want[t // 20], rtol=0, atol=1e-12), (k, t)
+            x, y = got[5::11][:22], got[6::11][:22]
+            d = np.hypot(x[:, None] - x[None], y[:, None] - y[None]) + 9.0 * np.eye(22)
+            assert 0.18 - d.min() < 0.01
+            at_wall += int((np.abs(x).max() > xl - 1e-3) or (np.abs(y).max() > yl - 1e-3))
+    assert at_wall >= 10

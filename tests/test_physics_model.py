@@ -468,3 +468,93 @@ def test_contacts_never_add_kinetic_energy(backend, oracle_mod):
         assert cur <= prev * (1 + 1e-6) + 1e-9, (cur, prev)
         prev = cur
     assert touched and prev < 0.02          # only the ball still rolls
+
+
+# ---- model v2: wall-aware robot-robot contacts, goal posts (SSL) ----
+
+def _ssl_state(st, n):
+    return st[0:2], np.stack([st[5 + 11 * k: 7 + 11 * k] for k in range(n)])
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_goal_post_is_a_point_bodies_keep_their_radius_from(backend, oracle_mod):
+    """The open end of a goal's side wall at (L/2, goal_width/2).  A ball shot at it comes back (radial speed reversed, scaled by the
+    wall restitution) and never gets closer than its radius; a robot driven along the goal line through the post's neighbourhood slides
+    AROUND it: never closer than its radius, and never displaced by more than it can drive in a step (v1 threw a robot that had
+    overlapped the wall's end 4 cm sideways when it crossed the goal line)."""
+    s = _ssl(backend, [0.0, 0.0, 0.0, 0.0], [0.0, 0.0, 0.0], ft=2)
+    f = s.get_field_params()
+    hl, ghw, rb, rr = f["length"] / 2, f["goal_width"] / 2, f["ball_radius"], f["rbt_radius"]
+    post = np.array([hl, ghw])
+    # ball: from the field side, straight at the post, 45 degrees
+    start = post - np.array([0.3, 0.3])
+    s.reset(np.array([start[0], start[1], 2.0, 2.0]), np.array([[-1.0, -1.0, 0.0]]), np.zeros((0, 3)))
+    dmin, back = 9.0, False
+    for _ in range(20):
+        s.step(np.zeros((1, 8)))
+        st = s.get_state()
+        dmin = min(dmin, float(np.hypot(*(st[0:2] - post))))
+        back = back or (st[3] < 0.0 and st[4] < 0.0)
+    assert dmin >= rb - 1e-6 and back
+    # robot: along the goal line (x = L/2 - 0.03) towards the goal mouth, through the post's neighbourhood
+    s.reset(np.array([0.0, 0.0, 0.0, 0.0]), np.array([[hl - 0.03, ghw + 0.4, 0.0]]), np.zeros((0, 3)))
+    prev, dmin = None, 9.0
+    for _ in range(60):
+        s.step(_cmd(1, 8, {0: [0, 0.0, -1.5, 0.0]}))      # robot-local v_y = -1.5 m/s (heading 0: global -y)
+        st = s.get_state()
+        p = st[5:7].copy()
+        dmin = min(dmin, float(np.hypot(*(p - post))))
+        if prev is not None:
+            assert np.hypot(*(p - prev)) <= 1.6 * 0.025 + 1e-3, (prev, p)
+        prev = p
+    assert dmin >= rr - 1e-5
+    assert prev[1] < ghw - rr + 0.02          # it got past the post into the mouth's height
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_a_row_of_pushers_against_a_wall_does_not_telescope(backend, oracle_mod):
+    """Six robots in a row perpendicular to a side wall, the first one standing at the wall, all driving at it at full speed for a second
+    and a half: the wall holds the first one, so its neighbour takes the whole correction of their contact (and so on down the row, a
+    third and fourth sweep while the pile is deep) — no pair overlaps by more than 8 mm and nobody is beyond the wall.  (Model v1, which
+    split every correction in halves and clamped the outer robot back into its neighbour afterwards: 13 mm here; both: 5 mm in the open.)"""
+    n = 6
+    s = _make(backend, 1, 2, n, 0)
+    f = s.get_field_params()
+    hw, r = f["width"] / 2, f["rbt_radius"]
+    yl = hw + 0.3 - r
+    s.reset(np.array([-2.0, 0.0, 0.0, 0.0]), np.array([[0.5, yl - 0.001 - k * (2 * r + 0.005), 0.0] for k in range(n)]), np.zeros((0, 3)))
+    worst = 0.0
+    for t in range(60):
+        s.step(_cmd(n, 8, {k: [0, 0.0, 2.5, 0.0] for k in range(n)}))      # robot-local v_y (heading 0: global +y, at the wall)
+        _, p = _ssl_state(s.get_state(), n)
+        assert (p[:, 1] <= yl + 1e-5).all()
+        if t >= 10:
+            d = np.hypot(p[:, None, 0] - p[None, :, 0], p[:, None, 1] - p[None, :, 1]) + 9.0 * np.eye(n)
+            worst = max(worst, 2 * r - float(d.min()))
+    assert 0.002 < worst < 0.008, worst
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_a_pile_driven_into_a_corner_stays_a_pile_of_discs(backend, oracle_mod):
+    """Six robots driving into a field corner for two seconds (both wall normals blocked for the first one, a chain of pushers
+    behind it): no pair overlaps by more than 1.5 mm at any step after the pile has formed (model v1: 2 mm)."""
+    s = _make(backend, 1, 2, 6, 0)
+    f = s.get_field_params()
+    hl, hw, r = f["length"] / 2, f["width"] / 2, f["rbt_radius"]
+    xl, yl = hl + 0.3 - r, hw + 0.3 - r
+    pos = [[xl - 0.05 - 0.22 * (k % 3), yl - 0.05 - 0.22 * (k // 3), 30.0 * k] for k in range(6)]
+    s.reset(np.array([-2.0, 0.0, 0.0, 0.0]), np.array(pos), np.zeros((0, 3)))
+    worst = 0.0
+    for t in range(80):
+        st = s.get_state()
+        th = np.deg2rad(np.array([st[7 + 11 * k] for k in range(6)]))
+        cm = np.zeros((6, 8))
+        cm[:, 1] = 1.5 * (np.cos(th) + np.sin(th)); cm[:, 2] = 1.5 * (-np.sin(th) + np.cos(th))    # global (+1.5, +1.5) in the robot frame
+        s.step(cm)
+        st = s.get_state()
+        _, p = _ssl_state(st, 6)
+        assert (np.abs(p[:, 0]) <= xl + 1e-5).all() and (np.abs(p[:, 1]) <= yl + 1e-5).all()
+        if t >= 20:
+            d = np.hypot(p[:, None, 0] - p[None, :, 0], p[:, None, 1] - p[None, :, 1]) + 9.0 * np.eye(6)
+            worst = max(worst, 2 * r - float(d.min()))
+    assert 0.0 < worst < 0.0015, worst
