@@ -362,10 +362,13 @@ struct DeviceGuard {
     ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
 };
 
+// (the thread's last-error slot is cleared on the way in: the launch checks below report THIS call's errors, not one a caller's
+// other HIP work — e.g. torch ending an aborted stream capture — left behind)
 #define RSX_ENTER(h)                                              \
     if (!(h)) return fail(RSX_ERR_ARG, "null handle");            \
     DeviceGuard _guard;                                           \
-    if (int _rc = _guard.enter((h)->device)) return _rc
+    if (int _rc = _guard.enter((h)->device)) return _rc;          \
+    (void)hipGetLastError()
 
 #define RSX_ENTER_TASK(h)                                                                        \
     RSX_ENTER(h);                                                                                \

@@ -93,6 +93,24 @@ class _VecBaseEnv:
         self.last_frame = None
         self.steps = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
         self._device_placement = None   # whether _get_initial_positions() returns device tensors (learnt in _place())
+        self._graph_mode = False
+
+    def enable_graph_capture(self):
+        """Make ``step()`` capturable into a ``torch.cuda.CUDAGraph`` (hooks + raw step + device-side auto-reset as one graph, the
+        way ``VecFusedEnv.enable_graph_capture`` does for the fused tasks).  What changes: ``self.frame`` / ``self.last_frame`` stay
+        the SAME two buffers for good — the previous frame is kept by one device copy per step instead of by trading the buffers'
+        roles (a replayed graph would keep writing the buffer that was current when it was captured; ``rsx_step_dev_flip`` refuses
+        to be captured for that reason).  Requires placements that stay on the device: call after a ``reset()`` whose
+        ``_get_initial_positions`` returned device tensors (or with ``auto_reset=False``).  The raw step holds no host state and
+        draws nothing, so replays need no counter: results are those of the eager calls."""
+        if self.auto_reset and self._device_placement is not True:
+            raise RuntimeError("enable_graph_capture() needs device-side placement: reset() first, with _get_initial_positions() returning "
+                               "device tensors (host-array placement costs a synchronisation per episode end and cannot be captured)")
+        self._graph_mode = True
+        if self.keep_last_frame and self.last_frame is None:
+            self.last_frame = self._other
+            self._other.state.copy_(self.frame.state)
+        return self
 
     def _stream(self):
         return self._torch.cuda.current_stream(self.device).cuda_stream
@@ -114,7 +132,11 @@ class _VecBaseEnv:
         self.steps += 1
         self.commands.zero_()
         self._get_commands(action)          # fills self.commands
-        if self.keep_last_frame:
+        if self.keep_last_frame and self._graph_mode:
+            self._other.state.copy_(self.frame.state)     # fixed roles (see enable_graph_capture): the previous frame by copy
+            self.last_frame = self._other
+            self.sim.step_dev(self._stream())
+        elif self.keep_last_frame:
             self.sim.step_dev_flip(self._stream())
             self.frame, self._other = self._other, self.frame
             self.last_frame = self._other

@@ -163,6 +163,16 @@ def test_capture_without_enable_is_refused_loudly():
         with torch.cuda.graph(torch.cuda.CUDAGraph(), stream=side):
             env.enable_graph_capture()
     env.close()
+    # and so is the double-buffered raw step: which buffer is current is host state
+    sim = _lib.Sim(0, 0, 3, 3, 25, 8)
+    sim.state_buffers()
+    g2 = torch.cuda.CUDAGraph()
+    with pytest.raises(_lib.RsxError, match="cannot be captured"):
+        with torch.cuda.graph(g2, stream=side):
+            sim.step_dev_flip(side.cuda_stream)
+    sim.step_dev_flip(side.cuda_stream)               # eagerly it works
+    torch.cuda.synchronize()
+    sim.close()
 
 
 @pytest.mark.parametrize("cls,layout,B", [("VecVSSEnv", None, 96), ("VecSSLStaticDefendersEnv", None, 50), ("VecSSLScrimmageEnv", "quad", 20)])
@@ -222,4 +232,79 @@ def test_device_counter_refuses_to_wrap():
         env.sim.task_tick()
     with pytest.raises(_lib.RsxError, match="exhausted"):
         env.metrics()
+    env.close()
+
+
+def test_a_hook_written_task_replays_from_a_graph_like_it_steps_eagerly():
+    """The batched-hook layer (VecVSSBaseEnv: the reference's four hooks over [B] tensors — code the engine has never seen) captured
+    as ONE graph: policy -> hooks -> raw step -> reward / done -> TimeLimit -> device-side auto-reset.  After enable_graph_capture()
+    the frame buffers keep their roles (the previous frame by a copy instead of the buffer flip, which refuses to be captured);
+    60 replays give the state, observations, rewards and episode counters of 60 eager steps, bit for bit."""
+    import torch
+    from rsoccer_amd.vec import VecVSSBaseEnv
+
+    class Task(VecVSSBaseEnv):
+        def __init__(self, n):
+            super().__init__(0, 3, 3, 0.025, n, max_episode_steps=9)
+            self.count = torch.zeros((), dtype=torch.int64, device="cuda")     # placements are a function of this device counter
+
+        def _get_commands(self, action):
+            v = torch.clamp(action * self.max_v, -self.max_v, self.max_v) / self.field.rbt_wheel_radius
+            self.commands[0, 0].copy_(v[:, 0]); self.commands[0, 1].copy_(v[:, 1])
+
+        def _frame_to_observations(self):
+            f = self.frame
+            return torch.stack([self.norm_pos(f.ball.x), self.norm_pos(f.ball.y), self.norm_pos(f.robots_blue[0].x),
+                                self.norm_pos(f.robots_blue[0].y), torch.sin(torch.deg2rad(f.robots_blue[0].theta))], 1)
+
+        def _calculate_reward_and_done(self):
+            return self.frame.ball.x - self.last_frame.ball.x, self.frame.robots_blue[0].x > 0.2
+
+        def _get_initial_positions(self):
+            B = self.num_envs
+            self.count += 1
+            e = torch.arange(B, device="cuda", dtype=torch.float32)
+            jitter = torch.sin(e * 12.9898 + self.count.to(torch.float32) * 78.233) * 0.15
+            ball = torch.zeros(B, 4, device="cuda"); ball[:, 0] = jitter; ball[:, 1] = -jitter
+            blue = torch.zeros(B, 3, 3, device="cuda"); yellow = torch.zeros(B, 3, 3, device="cuda")
+            for k in range(3):
+                blue[:, k, 0] = -0.5; blue[:, k, 1] = 0.3 * (k - 1)
+                yellow[:, k, 0] = 0.5; yellow[:, k, 1] = 0.3 * (k - 1); yellow[:, k, 2] = 180.0
+            return ball, blue, yellow
+
+    B = 192
+    w = torch.tensor([[0.9, -0.4], [0.3, 0.8], [-0.7, 0.2], [0.5, 0.5], [0.1, -0.9]], device="cuda")
+    policy = lambda o: torch.tanh(o @ w + 0.4)
+
+    def eager():
+        env = Task(B)
+        obs, _ = env.reset()
+        ret = torch.zeros(B, device="cuda"); ends = torch.zeros(B, dtype=torch.int64, device="cuda")
+        for _ in range(63):
+            obs, rew, done, trunc, info = env.step(policy(obs))
+            ret += rew; ends += (done | trunc).to(torch.int64)
+        torch.cuda.synchronize()
+        out = (env.sim.get_state_full(), obs.cpu().numpy(), ret.cpu().numpy(), ends.cpu().numpy(), env.steps.cpu().numpy())
+        env.close()
+        return out
+
+    want = eager()
+    env = Task(B)
+    obs0, _ = env.reset()
+    env.enable_graph_capture()
+    obs = obs0.clone(); ret = torch.zeros(B, device="cuda"); ends = torch.zeros(B, dtype=torch.int64, device="cuda")
+    for _ in range(3):                                                  # eager steps in graph mode first (and torch's warm-up)
+        o, rew, done, trunc, info = env.step(policy(obs))
+        obs.copy_(o); ret += rew; ends += (done | trunc).to(torch.int64)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        o, rew, done, trunc, info = env.step(policy(obs))
+        obs.copy_(o); ret += rew; ends += (done | trunc).to(torch.int64)
+    for _ in range(60):
+        g.replay()
+    torch.cuda.synchronize()
+    got = (env.sim.get_state_full(), obs.cpu().numpy(), ret.cpu().numpy(), ends.cpu().numpy(), env.steps.cpu().numpy())
+    for a, b, name in zip(got, want, ("state", "obs", "return", "episode ends", "steps")):
+        assert np.array_equal(a, b), name
+    assert want[3].sum() > B                                            # episodes did end (TimeLimit 9, the done hook) and re-start
     env.close()
