@@ -1472,6 +1472,21 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
     // ---- load ----
     Body o; float od, wd, wheels[4];
     const RawBody raw = load_raw<KIND>(P, bufs.state, e, b, is_robot, is_ball);
+#ifndef RSX_CODE_PREFETCH
+#define RSX_CODE_PREFETCH 1   // development A/B
+#endif
+    // Every launch starts with a cold instruction cache (the first pass through the code costs ~1 k cycles more than the later ones,
+    // profiles/r04_timeline_4096.txt).  The VSS single-step kernels touch the 8 KB of their own code that follow the entry point with
+    // ONE data load — a lane per 128-byte line; it lands with the state loads, long before the wave gets there — so that those
+    // instruction fetches find their lines in the L2: VSS-v0 at 4096 envs 9.02 -> 8.88 us per step (three interleaved rounds).
+    // Measured per kernel: later windows (+4, +8, +12 KB) or 16 / 24 KB gain nothing; the SSL kernels lose (11v11 +4 %, 1v6 +0.5 %).
+    constexpr bool CODE_PF = RSX_CODE_PREFETCH != 0 && KIND == RSX_KIND_VSS && MODE == MODE_STEP;
+    uint32_t code_touch = 0;
+    if (CODE_PF) {
+        unsigned long long pc;
+        asm volatile("s_getpc_b64 %0" : "=s"(pc));
+        code_touch = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(pc) + 128u * (unsigned)lane));
+    }
     int steps = 0; uint32_t episode = 0;
     if (live) {
         steps = __float_as_int(auxe(ROW_STEPS));
@@ -1539,6 +1554,7 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
     // counters that wait also drains the previous trip's global STORES: one HBM write round
     // trip per env step in the multi-step (rollout) launches.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    if (CODE_PF) asm volatile("" :: "v"(code_touch));   // (the value itself is of no interest)
     interpret_body<KIND>(raw, is_robot, is_ball, o, od, wd, wheels);
     RSX_STAMP(1);
 
