@@ -49,6 +49,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 METRIC = "env-steps/sec (whole node), VSS-v0 3v3 @4096 envs, 1/2/4/8 GPU + CPU ref"
 ALLREDUCE_EVERY = 100           # steps between metrics all-reduces
 STEADY_STEPS, STEADY_WARMUP = 2000, 200
+EVENT_MIN_STEPS = 200           # shorter timed regions are measured by the wall clock alone (see timed())
 SWEEP_ENVS = (65536, 1048576, 4194304)
 HBM_ACHIEVABLE_GBS = 6290.0     # MI355X_MICROARCH.md: what a streaming kernel reaches of the 8 TB/s
 
@@ -361,15 +362,21 @@ def main():
         collective of ~50-100 us, comparable to a short timed region) is not part of any rank's n steps."""
         run(s, warm, mode) if warm else None
         barrier()
+        # HIP events bracket the launches of regions of >= EVENT_MIN_STEPS launches only: recording the pair costs ~14 us of
+        # stream time (tools/exp_sync_latency.py: 20 launches 190 us without, 204 us with), 7 % of the driver's --steps 20
+        # region and nothing of the 2000-launch leg `roofline` is computed from; a short region reports its wall clock
+        use_events = mode == "rollout" or n >= EVENT_MIN_STEPS
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        ev0.record()
+        if use_events:
+            ev0.record()
         run(s, n, mode)
-        ev1.record()
+        if use_events:
+            ev1.record()
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         barrier()
-        dev_ms = ev0.elapsed_time(ev1)
+        dev_ms = ev0.elapsed_time(ev1) if use_events else wall * 1e3
         if distributed:
             t = torch.tensor([wall], dtype=torch.float64, device=mbuf.device)
             coll.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -449,9 +456,11 @@ def main():
             line["roofline"]["source"] = f"steady leg: HIP-event average of {STEADY_STEPS} per-step launches after {max(W + K, STEADY_WARMUP)}"
             line["roofline"]["frac_timed_region"] = roofline_of(B, launch_us, units_per_launch, "step")["frac"]
             line["roofline"]["avg_launch_us_timed_region"] = launch_us
+            line["roofline"]["timed_region_clock"] = "HIP events" if K >= EVENT_MIN_STEPS else "wall clock of the bracket / steps (no events in a region this short)"
         else:
             line["roofline"] = roofline_of(B, launch_us, units_per_launch, args.mode, traffic, tsrc, layout)
-            line["roofline"]["source"] = f"timed region: HIP-event average of {K if args.mode == 'step' else 1} launch(es) after {W} steps"
+            line["roofline"]["source"] = (f"timed region: {'HIP-event' if args.mode == 'rollout' or K >= EVENT_MIN_STEPS else 'wall-clock'} average of "
+                                          f"{K if args.mode == 'step' else 1} launch(es) after {W} steps")
             if args.mode == "rollout":
                 line["roofline"]["notional"] = True
         if distributed:
