@@ -206,11 +206,9 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
             integrate_ball<KIND>(P, ball);
 
             // B: contacts, Jacobi over the post-integration snapshot.  Every pair once; the exact
-            // integer form of 0 < d2 < thr (see rsx_kernels.hpp) gives one bit per touching pair.
+            // compare d2 < thr gives one bit per touching pair (0 < d2: see find_touching).
             // A second sweep over the corrected snapshot runs in the envs where anything touched.
             const bool ball_low = ball.z < K::robot_h;
-            constexpr uint32_t T_RR = __builtin_bit_cast(uint32_t, K::rs_rr2) - 1u;
-            constexpr uint32_t T_RB = __builtin_bit_cast(uint32_t, K::rs_rb2) - 1u;
             // bits of `touching` that involve body k (pairs in lexicographic order, see epl_pair)
             constexpr unsigned PM[EPL_NB] = {epl_pair_mask<EPL_NB>(0), epl_pair_mask<EPL_NB>(1), epl_pair_mask<EPL_NB>(2), epl_pair_mask<EPL_NB>(3),
                                              epl_pair_mask<EPL_NB>(4), epl_pair_mask<EPL_NB>(5), epl_pair_mask<EPL_NB>(6)};
@@ -225,10 +223,12 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
                     for (int j = N; j > i; --j) {
                         const float xj = j == N ? ball.x : r[j < N ? j : 0].x, yj = j == N ? ball.y : r[j < N ? j : 0].y;
                         const float dx = xj - r[i].x, dy = yj - r[i].y;
-                        const uint32_t u = __float_as_uint(fma_(dx, dx, dy * dy)) - 1u;
-                        // (spelled as the two instructions it is: the compiler's own choice for `2 acc + (u < thr)` is a compare, a
-                        // select of the bit and a share of a shift and an OR)
-                        asm("v_cmp_gt_u32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(touching) : "v"(u), "s"(j == N ? T_RB : T_RR) : "vcc");
+                        // one compare per pair: d2 < thr.  The model's 0 < d2 (bodies in one place have no normal and are not a contact) is
+                        // applied where a pair is walked (epl_walk_pairs) — `bits(d2) - 1 < bits(thr) - 1` did both here, for one
+                        // more instruction on each of the 21 pairs of every sub-step.  (Spelled as the two instructions it is: the
+                        // compiler's own choice for `2 acc + (d2 < thr)` is a compare, a select of the bit and a share of a shift and an OR.)
+                        const float d2 = fma_(dx, dx, dy * dy);
+                        asm("v_cmp_gt_f32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(touching) : "v"(d2), "s"(j == N ? K::rs_rb2 : K::rs_rr2) : "vcc");
                     }
                 }
                 return ball_low ? touching : (touching & ~PM[N]);
@@ -238,14 +238,16 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
                 // second: envs with a deep pair only; third and fourth: envs whose last sweep also saw a wall pair (model v2)
                 const bool mine = sweep == 0 || (deep && (sweep == 1 || wallp));
                 if (sweep >= 1 && !__any(mine)) break;   // no env of the wave goes on: no further pair test either
-                const unsigned touching = mine ? find_touching() : 0u;
+                unsigned touching = mine ? find_touching() : 0u;
                 if (!__any(touching != 0)) break;
                 // some env of the wave has a contact: sums in LDS, pairs walked per lane, both sides of a pair from one normal
                 // (epl_walk_pairs, rsx_epl_common.hpp: the ball is body N, a circle like the robots)
                 epl_zero_sums(sh.c, lane);
                 wave_sync();
                 deep = false; wallp = false;
-                epl_walk_pairs<KIND, N, true>(P, r, ball, sh.c, lane, touching, deep, wallp);
+                unsigned dropped = 0u;   // pairs at zero distance: not a contact, and their bodies not "touched" by them
+                epl_walk_pairs<KIND, N, true, true>(P, r, ball, sh.c, lane, touching, deep, wallp, &dropped);
+                touching &= ~dropped;
                 wave_sync();
                 epl_apply_sums<N>(r, ball, sh.c, lane, [&](int k) { return (touching & PM[k]) != 0; });   // (the registers still held the snapshot)
                 wave_sync();

@@ -95,8 +95,11 @@ static_assert(epl_pair_mask<7>(0) == 0x00003Fu && epl_pair_mask<7>(3) == 0x03888
 // Each lane walks ITS touching pairs in pair order.  Bodies 0..N-1 are the robots r[] (picked out of the registers by
 // select chains: a snapshot in LDS would cost a wave of occupancy); BALL: body N is the ball as a circle (VSS).  Both sides
 // of a pair from one normal (contact_pair, rsx_body.hpp); each body's sums are read-modify-written in LDS.
-template <int KIND, int N, bool BALL>
-__device__ __forceinline__ void epl_walk_pairs(const Params& P, const Body* r, const Body& ball, EplSums<N + 1>& c, const int lane, unsigned todo, bool& deep, bool& wallp) {
+// ZCHK: the caller's pair bits come from `d2 < thr` alone (one compare per pair); the model's `0 < d2` is applied here, where a
+// pair is walked: a pair of bodies in one place is dropped and reported in `dropped` (the caller clears its bit before the sums
+// are applied).
+template <int KIND, int N, bool BALL, bool ZCHK = false>
+__device__ __forceinline__ void epl_walk_pairs(const Params& P, const Body* r, const Body& ball, EplSums<N + 1>& c, const int lane, unsigned todo, bool& deep, bool& wallp, unsigned* dropped = nullptr) {
     // does any robot of the wave's envs (with a touching pair) stand at a wall?  (wave-uniform, once per sweep: contact_pair, rsx_body.hpp)
     bool aw_ = false;
     if (KC<KIND>::wall_aware && todo) {
@@ -119,6 +122,10 @@ __device__ __forceinline__ void epl_walk_pairs(const Params& P, const Body* r, c
             { const bool m = j == k; bj.x = m ? r[k].x : bj.x; bj.y = m ? r[k].y : bj.y; bj.vx = m ? r[k].vx : bj.vx; bj.vy = m ? r[k].vy : bj.vy; wj = m ? r[k].om : wj; }
         }
         if (rb) { bj.x = ball.x; bj.y = ball.y; bj.vx = ball.vx; bj.vy = ball.vy; wj = ball.om; }
+        if (ZCHK) {
+            const float dx = bj.x - bi.x, dy = bj.y - bi.y;
+            if (__builtin_expect(fma_(dx, dx, dy * dy) == 0.0f, 0)) { *dropped |= 1u << p; continue; }
+        }
         const float lever_j = rb ? K::r_ball : K::r_robot;
         float ai[4] = {c.acc[0][i][lane], c.acc[1][i][lane], c.acc[2][i][lane], c.acc[3][i][lane]};
         float aj[4] = {c.acc[0][j][lane], c.acc[1][j][lane], c.acc[2][j][lane], c.acc[3][j][lane]};

@@ -630,6 +630,48 @@ def test_quad_layout_is_bit_identical(oracle_mod, monkeypatch, task):
     assert np.array_equal(outs["quad"], outs["lanes"], equal_nan=True)
 
 
+@pytest.mark.parametrize("layout", ["epl", "lanes"])
+def test_vss_ball_inside_a_resting_robot_is_not_a_contact(oracle_mod, monkeypatch, layout):
+    """VSS-v0: the ball EXACTLY at the centre of the agent's robot, which is fed zero actions and stays put — the pair has no
+    contact normal and the model skips it (0 < d2 < thr) in every sub-step.  The one-lane-per-env kernel finds pairs with one
+    float compare (d2 < thr) and applies 0 < d2 where a pair is walked (the dropped pair must not count as touched either:
+    a sum of +0 added to a velocity of -0 would change its bits); other robots pile onto the same spot to make real contacts."""
+    import torch
+    L = _lib()
+    O = oracle_mod
+    kind, ft, nb, ny = 0, 0, 3, 3
+    B = 70
+    monkeypatch.setenv("RSX_LAYOUT", layout)
+    sim = L.Sim(kind, ft, nb, ny, 25, B)
+    sim.task_attach(1, 3, 0, 0)
+    rng = np.random.default_rng(11)
+    ball = np.zeros((B, 4)); rob = np.zeros((B, 6, 3))
+    for e in range(B):
+        rob[e, :, 0] = rng.uniform(-0.6, 0.6, 6); rob[e, :, 1] = rng.uniform(-0.5, 0.5, 6)
+        rob[e, :, 2] = rng.uniform(-180, 180, 6)
+        ball[e, :2] = rob[e, 0, :2]                                # the ball in the agent's place
+        if e % 2: rob[e, 1 + e % 5, :2] = rob[e, 0, :2] + (0.05, 0.02)   # a neighbour overlapping robot 0 (and the ball)
+    rob = np.float32(rob).astype(np.float64); ball[:, :2] = rob[:, 0, :2]   # exactly representable: the float state holds the same bits
+    refs = _mk_oracles(O, kind, ft, nb, ny, B)
+    for e, r in enumerate(refs):
+        r.task_attach(1, 3, e, 0)
+        r.task_reset()
+        r.task_reset_to(ball[e], rob[e, :3], rob[e, 3:])
+    sim.task_reset()
+    sim.task_reset_to(ball, rob[:, :3], rob[:, 3:])
+    tens = sim.task_tensors()
+    a = np.zeros(tuple(tens["actions"].shape), np.float32)
+    for t in range(10):
+        if t >= 5:
+            a = rng.uniform(-1, 1, a.shape).astype(np.float32)
+        tens["actions"].copy_(torch.from_numpy(a))
+        sim.task_step(tens["actions"].data_ptr())
+        for e, r in enumerate(refs):
+            r.task_step(a[e])
+        _cmp_task(sim, refs, tens, t)
+    sim.close()
+
+
 @pytest.mark.parametrize("layout", ["quad", "lanes"])
 def test_scrimmage_robots_in_one_place_are_not_a_contact(oracle_mod, monkeypatch, layout):
     """Two robots at EXACTLY the same position have no contact normal: the model skips the pair (0 < d2 < (2 r)^2).  The
