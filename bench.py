@@ -49,6 +49,8 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 METRIC = "env-steps/sec (whole node), VSS-v0 3v3 @4096 envs, 1/2/4/8 GPU + CPU ref"
 ALLREDUCE_EVERY = 100           # steps between metrics all-reduces
 STEADY_STEPS, STEADY_WARMUP = 2000, 200
+LARGE_WARMUP = 200             # untimed steps before the large-batch legs of the registered tasks: steady state; the first ~150 steps
+                               # after a reset, with every env in the same early phase of its first episode, run 3-14 % slower (profiles/r05_leg_windows.txt)
 EVENT_MIN_STEPS = 200           # shorter timed regions are measured by the wall clock alone (see timed())
 SWEEP_ENVS = (65536, 1048576, 4194304)
 HBM_ACHIEVABLE_GBS = 6290.0     # MI355X_MICROARCH.md: what a streaming kernel reaches of the 8 TB/s
@@ -548,7 +550,7 @@ def evidence(line):
     return ev
 
 
-def sweep(L, torch, dev, timed, n=100, warm=30):
+def sweep(L, torch, dev, timed, n=100, warm=LARGE_WARMUP):
     """Where the path is bandwidth-bound: the same fused step at large batches, one launch per step
     and all steps in one launch, each with its own roofline fraction (HIP events on the launch stream)."""
     out = []
@@ -588,13 +590,13 @@ def other_configs(L, torch, dev, timed):
     SD = ssl_bytes(7, 24)      # 981
     SC = ssl_bytes(22, 46)     # 2869
     cases = (("configs[2] SSLStaticDefenders-v0 1v6", 1, 2, 1, 6, L.TASK_SSL_STATIC_DEFENDERS, 2048, SD, 2000, 200),
-             ("SSLStaticDefenders-v0 1v6, 262 144 envs (one-lane-per-env kernel)", 1, 2, 1, 6, L.TASK_SSL_STATIC_DEFENDERS, 262144, SD, 100, 30),
-             ("SSLStaticDefenders-v0 1v6, 1 048 576 envs (one-lane-per-env kernel)", 1, 2, 1, 6, L.TASK_SSL_STATIC_DEFENDERS, 1048576, SD, 60, 20),
+             ("SSLStaticDefenders-v0 1v6, 262 144 envs (one-lane-per-env kernel)", 1, 2, 1, 6, L.TASK_SSL_STATIC_DEFENDERS, 262144, SD, 100, LARGE_WARMUP),
+             ("SSLStaticDefenders-v0 1v6, 1 048 576 envs (one-lane-per-env kernel)", 1, 2, 1, 6, L.TASK_SSL_STATIC_DEFENDERS, 1048576, SD, 60, LARGE_WARMUP),
              ("SSLStaticDefenders-v0 1v6, 4 194 304 envs (1.4 GB of state: beyond the 256 MB memory-side cache)", 1, 2, 1, 6,
-              L.TASK_SSL_STATIC_DEFENDERS, 4194304, SD, 30, 10),
-             ("SSLDribbling-v0 1v4, 1 048 576 envs (one-lane-per-env kernel)", 1, 2, 1, 4, L.TASK_SSL_DRIBBLING, 1048576, ssl_bytes(5, 21), 60, 20),
-             ("SSLContestedPossession-v0 1v1, 1 048 576 envs (one-lane-per-env kernel)", 1, 2, 1, 1, L.TASK_SSL_CONTESTED, 1048576, ssl_bytes(2, 14), 60, 20),
-             ("SSLPassEndurance-v0 2v0, 1 048 576 envs (one-lane-per-env kernel)", 1, 2, 2, 0, L.TASK_SSL_PASS_ENDURANCE, 1048576, ssl_bytes(2, 16), 60, 20),
+              L.TASK_SSL_STATIC_DEFENDERS, 4194304, SD, 30, LARGE_WARMUP),
+             ("SSLDribbling-v0 1v4, 1 048 576 envs (one-lane-per-env kernel)", 1, 2, 1, 4, L.TASK_SSL_DRIBBLING, 1048576, ssl_bytes(5, 21), 60, LARGE_WARMUP),
+             ("SSLContestedPossession-v0 1v1, 1 048 576 envs (one-lane-per-env kernel)", 1, 2, 1, 1, L.TASK_SSL_CONTESTED, 1048576, ssl_bytes(2, 14), 60, LARGE_WARMUP),
+             ("SSLPassEndurance-v0 2v0, 1 048 576 envs (one-lane-per-env kernel)", 1, 2, 2, 0, L.TASK_SSL_PASS_ENDURANCE, 1048576, ssl_bytes(2, 16), 60, LARGE_WARMUP),
              ("configs[3] SSL 11v11 division-A, scrimmage task, spread line-up", 1, 1, 11, 11, L.TASK_SSL_SCRIMMAGE, 1024, SC, 1000, 100),
              ("configs[3] SSL 11v11 division-A, scrimmage task, crowded line-up (worst-case contacts)", 1, 1, 11, 11,
               L.TASK_SSL_SCRIMMAGE_CROWDED, 1024, SC, 1000, 100),
