@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define RSX_ABI_VERSION 4
+#define RSX_ABI_VERSION 5
 
 /* kind: which robosim class the handle stands for (rsim.py:116 robosim.VSS, :169 robosim.SSL) */
 #define RSX_KIND_VSS 0
@@ -83,8 +83,10 @@ extern "C" {
 
 typedef struct rsx_sim rsx_sim; /* opaque */
 
-/* Device-side views, zero-copy.  SoA: row f of an [F][B] array is the contiguous run
- * base + f*num_envs (one float per env).  state rows 0..state_dim-1 are exactly the reference's
+/* Device-side views, zero-copy.  SoA: row f of an [F][B] array is the contiguous run of B floats at
+ * base + f*row_stride (one float per env).  row_stride >= num_envs: handles of 786 432 envs and more pad their rows
+ * (64 KB + 256 B) so that the rows of an env do not all sit at the same address modulo a large power of two (DRAM banks;
+ * ABI 5).  Treat the arrays as strided 2-D views (torch: as_strided); a row by itself is dense.  state rows 0..state_dim-1 are exactly the reference's
  * get_state() layout (Entities/Frame.py:20-47 VSS, :55-92 SSL) transposed; rows state_dim and
  * state_dim + 1 hold the ball's vertical velocity and its spin (internal, needed to checkpoint
  * a chipped / spinning ball). */
@@ -95,6 +97,7 @@ typedef struct rsx_dev_view {
     int32_t cmd_dim;     /* C: 2 (VSS) | 8 (SSL)  — per robot                                */
     float*  state;       /* [state_dim + 2][B] f32 SoA                                       */
     float*  cmds;        /* [N*C][B] f32 SoA, row = robot*C + col; read by rsx_step_dev      */
+    int32_t row_stride;  /* floats from one row of state / cmds to the next (>= num_envs)    */
 } rsx_dev_view;
 
 typedef struct rsx_task_view {
@@ -120,6 +123,8 @@ typedef struct rsx_task_view {
                                (stream-ordered).  [0] is exact after every launch; the episode
                                counters [1..6] are exact after rsx_metrics_fold /
                                rsx_read_metrics (the kernels add into per-block partial sums) */
+    int32_t  row_stride;    /* floats from one row of `info` to the next (>= num_envs; the same value
+                               as rsx_dev_view.row_stride)                                   */
 } rsx_task_view;
 
 /* ---- diagnostics ---------------------------------------------------------------------- */

@@ -46,7 +46,7 @@ class RsxError(RuntimeError):
 
 class DevView(C.Structure):
     _fields_ = [("num_envs", C.c_int32), ("n_robots", C.c_int32), ("state_dim", C.c_int32),
-                ("cmd_dim", C.c_int32), ("state", C.c_void_p), ("cmds", C.c_void_p)]
+                ("cmd_dim", C.c_int32), ("state", C.c_void_p), ("cmds", C.c_void_p), ("row_stride", C.c_int32)]
 
 
 class TaskView(C.Structure):
@@ -54,7 +54,7 @@ class TaskView(C.Structure):
                 ("info_dim", C.c_int32), ("max_episode_steps", C.c_int32),
                 ("obs", C.c_void_p), ("reward", C.c_void_p), ("terminated", C.c_void_p),
                 ("truncated", C.c_void_p), ("info", C.c_void_p), ("final_obs", C.c_void_p),
-                ("steps", C.c_void_p), ("actions", C.c_void_p), ("metrics", C.c_void_p)]
+                ("steps", C.c_void_p), ("actions", C.c_void_p), ("metrics", C.c_void_p), ("row_stride", C.c_int32)]
 
 
 _lib = None
@@ -110,7 +110,7 @@ def load():
     lib.rsx_check_finite.argtypes = [vp, C.POINTER(C.c_int64), vp]
     lib.rsx_task_enable_capture.argtypes = [vp, vp]
     lib.rsx_task_tick.argtypes = [vp, C.POINTER(C.c_uint32), vp]
-    if lib.rsx_abi_version() != 4:
+    if lib.rsx_abi_version() != 5:
         raise RsxError("librsx_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -135,10 +135,10 @@ def _f64(a, shape):
 class _DevArray:
     """Minimal __cuda_array_interface__ carrier so torch can wrap library-owned memory."""
 
-    def __init__(self, ptr, shape, typestr, owner):
+    def __init__(self, ptr, shape, typestr, owner, strides=None):
         self.__cuda_array_interface__ = {
             "shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2,
-            "strides": None,
+            "strides": None if strides is None else tuple(int(x) for x in strides),   # bytes
         }
         self._owner = owner  # keeps the handle alive while a tensor views its memory
 
@@ -253,8 +253,7 @@ class Sim:
         that was current holds the previous frame."""
         cur, oth = C.c_void_p(), C.c_void_p()
         _chk(self._lib.rsx_state_buffers(self._h, C.byref(cur), C.byref(oth)))
-        shape = (self.state_dim + X_ROWS, self.num_envs)
-        return self._tensor(cur.value, shape, "<f4"), self._tensor(oth.value, shape, "<f4")
+        return self._rows(cur.value, self.state_dim + X_ROWS), self._rows(oth.value, self.state_dim + X_ROWS)
 
     def reset_dev(self, ball, blue, yellow, env_mask=None, stream=None):
         """reset() from device tensors: ball [B,4], blue [B,nb,3], yellow [B,ny,3] float32 CUDA,
@@ -280,18 +279,24 @@ class Sim:
         self._keep_reset = (ball, blue, yellow, m)   # alive until the launch has consumed them
         _chk(self._lib.rsx_reset_dev(self._h, ptr(ball), ptr(blue), ptr(yellow), ptr(m), self._stream(stream)))
 
-    def _tensor(self, ptr, shape, typestr):
+    def _tensor(self, ptr, shape, typestr, strides=None):
         import torch
-        return torch.as_tensor(_DevArray(ptr, shape, typestr, self),
+        return torch.as_tensor(_DevArray(ptr, shape, typestr, self, strides),
                                device=torch.device("cuda", self.device_id))
+
+    def _rows(self, ptr, n_rows, rs=None):
+        """[n_rows, B] float32 view of an SoA array whose rows are row_stride floats apart (dense unless the handle pads its rows:
+        rsx.h, rsx_dev_view)"""
+        rs = int(self._view.row_stride if rs is None else rs)
+        return self._tensor(ptr, (n_rows, self.num_envs), "<f4", None if rs == self.num_envs else (4 * rs, 4))
 
     def state_tensor(self):
         """[state_dim+2, B] float32, zero-copy view of the SoA state."""
-        return self._tensor(self._view.state, (self.state_dim + X_ROWS, self.num_envs), "<f4")
+        return self._rows(self._view.state, self.state_dim + X_ROWS)
 
     def cmds_tensor(self):
         """[N*C, B] float32, zero-copy view of the SoA command buffer read by step_dev()."""
-        return self._tensor(self._view.cmds, (self.n_robots * self.cmd_dim, self.num_envs), "<f4")
+        return self._rows(self._view.cmds, self.n_robots * self.cmd_dim)
 
     # ---- fused tasks ----
     def task_attach(self, task, seed=0, env_id_base=0, max_episode_steps=0):
@@ -322,7 +327,7 @@ class Sim:
             reward=self._tensor(t.reward, (B,), "<f4"),
             terminated=self._tensor(t.terminated, (B,), "|u1"),
             truncated=self._tensor(t.truncated, (B,), "|u1"),
-            info=self._tensor(t.info, (t.info_dim, B), "<f4"),
+            info=self._rows(t.info, t.info_dim, t.row_stride),
             final_obs=self._tensor(t.final_obs, (B, t.obs_dim), "<f4"),
             steps=self._tensor(t.steps, (B,), "<i4"),
             actions=self._tensor(t.actions, (B, t.act_dim), "<f4"),

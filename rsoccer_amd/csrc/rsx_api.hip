@@ -190,12 +190,12 @@ void pick_variant(rsx_sim* h) {
 
 // hot arguments first (preloaded into SGPRs, see RSX_HOT_ARGS), then the by-value structs
 #define RSX_LAUNCH_SIM(kernel, P, b) hipLaunchKernelGGL((kernel), grid, dim3(64), 0, s, (b).state, state_out, (b).cmds, (b).flags, \
-                                                        (P).num_envs, (P).state_dim, (int)(grid.x >> 3), rand_tick, (P), (b))
+                                                        (P).num_envs, RSX_HOT_DIM((P).state_dim, (P).row_stride, (P).num_envs), (int)(grid.x >> 3), rand_tick, (P), (b))
 #define RSX_LAUNCH(kernel, P, b, n) hipLaunchKernelGGL((kernel), grid, dim3(64), 0, s, (b).state, (b).aux, (b).actions, (b).flags, \
-                                                       (P).num_envs, (P).state_dim, (int)(grid.x >> 3), (n), (P), (b))
+                                                       (P).num_envs, RSX_HOT_DIM((P).state_dim, (P).row_stride, (P).num_envs), (int)(grid.x >> 3), (n), (P), (b))
 // the same with `extra` helper workgroups behind the tile workgroups (the tile map still sees the tile grid)
 #define RSX_LAUNCH_X(kernel, P, b, n, extra) hipLaunchKernelGGL((kernel), dim3(grid.x + (unsigned)(extra)), dim3(64), 0, s, (b).state, (b).aux, (b).actions, \
-                                                                (b).flags, (P).num_envs, (P).state_dim, (int)(grid.x >> 3), (n), (P), (b))
+                                                                (b).flags, (P).num_envs, RSX_HOT_DIM((P).state_dim, (P).row_stride, (P).num_envs), (int)(grid.x >> 3), (n), (P), (b))
 
 template <int KIND>
 void launch_sim_k(const rsx_sim* h, const Params& P_, float* state_out, int rand_tick, hipStream_t s,
@@ -230,17 +230,18 @@ void launch_sim(const rsx_sim* h, hipStream_t s, float* state_out = nullptr, int
 
 // teleport of rsim.py:52-75 from device arrays: one thread per env, rows are coalesced across threads
 __global__ void reset_dev_kernel(float* __restrict__ st, const float* __restrict__ ball, const float* __restrict__ blue,
-                                 const float* __restrict__ yellow, const uint8_t* __restrict__ mask, int B, int rows,
+                                 const float* __restrict__ yellow, const uint8_t* __restrict__ mask, int B, int S_, int rows,
                                  int rs, int nb, int ny, float r_ball) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= B || (mask && !mask[e])) return;
-    for (int f = 0; f < rows; ++f) st[(size_t)f * B + e] = 0.0f;
-    st[0 * (size_t)B + e] = ball[4 * (size_t)e + 0]; st[1 * (size_t)B + e] = ball[4 * (size_t)e + 1]; st[2 * (size_t)B + e] = r_ball;
-    st[3 * (size_t)B + e] = ball[4 * (size_t)e + 2]; st[4 * (size_t)B + e] = ball[4 * (size_t)e + 3];
+    const size_t S = (size_t)S_;   // floats per row
+    for (int f = 0; f < rows; ++f) st[(size_t)f * S + e] = 0.0f;
+    st[0 * S + e] = ball[4 * (size_t)e + 0]; st[1 * S + e] = ball[4 * (size_t)e + 1]; st[2 * S + e] = r_ball;
+    st[3 * S + e] = ball[4 * (size_t)e + 2]; st[4 * S + e] = ball[4 * (size_t)e + 3];
     for (int k = 0; k < nb + ny; ++k) {
         const float* src = k < nb ? blue + ((size_t)e * nb + k) * 3 : yellow + ((size_t)e * ny + (k - nb)) * 3;
         const size_t r = (size_t)(5 + rs * k);
-        st[(r + 0) * B + e] = src[0]; st[(r + 1) * B + e] = src[1]; st[(r + 2) * B + e] = src[2];
+        st[(r + 0) * S + e] = src[0]; st[(r + 1) * S + e] = src[1]; st[(r + 2) * S + e] = src[2];
     }
 }
 
@@ -387,7 +388,7 @@ int upload_state(rsx_sim* h, const std::vector<float>& soa, hipStream_t s) {
     return RSX_OK;
 }
 int download_state(rsx_sim* h, std::vector<float>& soa, hipStream_t s) {
-    soa.resize((size_t)(h->P.state_dim + X_ROWS) * h->P.num_envs);
+    soa.resize((size_t)(h->P.state_dim + X_ROWS) * h->P.row_stride);
     HIP_TRY(hipMemcpyAsync(soa.data(), h->d_state, soa.size() * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return RSX_OK;
@@ -397,20 +398,20 @@ int download_state(rsx_sim* h, std::vector<float>& soa, hipStream_t s) {
 void apply_reset(const rsx_sim* h, std::vector<float>& soa, const double* ball, const double* blue,
                  const double* yellow, const uint8_t* mask) {
     const Params& P = h->P;
-    const size_t B = (size_t)P.num_envs;
+    const size_t B = (size_t)P.num_envs, S = (size_t)P.row_stride;   // soa: [rows][S], the device layout
     for (size_t e = 0; e < B; ++e) {
         if (mask && !mask[e]) continue;
-        for (int f = 0; f < P.state_dim + X_ROWS; ++f) soa[(size_t)f * B + e] = 0.0f;
+        for (int f = 0; f < P.state_dim + X_ROWS; ++f) soa[(size_t)f * S + e] = 0.0f;
         const double* bl = ball + 4 * e;
-        soa[0 * B + e] = (float)bl[0]; soa[1 * B + e] = (float)bl[1]; soa[2 * B + e] = (float)h->M.field[6];
-        soa[3 * B + e] = (float)bl[2]; soa[4 * B + e] = (float)bl[3];
+        soa[0 * S + e] = (float)bl[0]; soa[1 * S + e] = (float)bl[1]; soa[2 * S + e] = (float)h->M.field[6];
+        soa[3 * S + e] = (float)bl[2]; soa[4 * S + e] = (float)bl[3];
         for (int k = 0; k < P.n_robots; ++k) {
             const double* src = k < P.n_blue ? blue + ((size_t)e * P.n_blue + k) * 3
                                              : yellow + ((size_t)e * P.n_yellow + (k - P.n_blue)) * 3;
             const size_t r = (size_t)(5 + h->M.rs * k);
-            soa[(r + 0) * B + e] = (float)src[0];
-            soa[(r + 1) * B + e] = (float)src[1];
-            soa[(r + 2) * B + e] = (float)src[2];
+            soa[(r + 0) * S + e] = (float)src[0];
+            soa[(r + 1) * S + e] = (float)src[1];
+            soa[(r + 2) * S + e] = (float)src[2];
         }
     }
 }
@@ -430,22 +431,40 @@ void free_all(rsx_sim* h) {
 
 size_t align_up(size_t n) { return (n + 255) & ~(size_t)255; }
 
+// Floats between the rows of the [rows][B] arrays (state, commands, per-env scalars) beyond B.  With rows exactly B floats apart
+// and B a power of two — every batch size anybody benchmarks — row f of an env sits at the same address modulo a large power of
+// two for every f, and the ~110 read and write streams of a large-batch launch (one per row) walk the same DRAM banks in step.
+// A pad of 64 KB + 256 B per row takes them apart: 4 M envs VSS-v0 150.7 -> 139.3 ps per env-step, 1v6 173.3 -> 150.8; 1 M envs 1v6
+// 163.5 -> 152.6; nothing at 262 144 envs and below (the arrays sit in the memory-side cache), where the rows stay dense
+// (profiles/r05_row_stride.txt: pads from 256 B to 1 MB; exactly 256 KB is the worst, 64 KB + 256 B and 256 KB + 256 B the best).
+// A multiple of 64 floats (rows stay 256-byte aligned; it travels in 16 bits of a hot kernel argument: RSX_HOT_DIM).
+// RSX_ROW_PAD=<floats> overrides (tests run every kernel family with padded rows at small batches).
+constexpr int RSX_ROW_PAD_MIN_ENVS = 786432, RSX_ROW_PAD_FLOATS = 16448;   // (524 288 envs measured: no gain yet)
+int row_pad_for(int num_envs) {
+    long pad = num_envs >= RSX_ROW_PAD_MIN_ENVS ? RSX_ROW_PAD_FLOATS : 0;
+    if (const char* v = std::getenv("RSX_ROW_PAD")) pad = std::atol(v);
+    if (pad < 0) pad = 0;
+    pad = (pad + 63) / 64 * 64;
+    if (pad > 65535l * 64) pad = 65535l * 64;
+    return (int)pad;
+}
+
 }  // namespace
 
 // state rows, and with a task attached observations, rewards and the cumulative info rows
 static int check_finite_impl(rsx_sim* h, int64_t* n_bad, hipStream_t s) {
     if (!h->d_check) HIP_TRY(hipMalloc((void**)&h->d_check, sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(h->d_check, 0, sizeof(unsigned long long), s));
-    const size_t B = (size_t)h->P.num_envs;
+    const size_t B = (size_t)h->P.num_envs, S = (size_t)h->P.row_stride;   // (the pad columns hold zeros)
     auto scan = [&](const float* p, size_t n) {
         const unsigned blocks = (unsigned)std::min<size_t>(2048, (n + 255) / 256);
         hipLaunchKernelGGL(count_nonfinite_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, p, n, h->d_check);
     };
-    scan(h->d_state, (size_t)(h->P.state_dim + X_ROWS) * B);
+    scan(h->d_state, (size_t)(h->P.state_dim + X_ROWS) * S);
     if (h->P.task != RSX_TASK_NONE) {
         scan(h->d_obs, B * (size_t)h->P.obs_dim);
-        scan(h->d_aux + (size_t)ROW_REWARD * B, B);
-        scan(h->d_aux + (size_t)ROW_INFO * B, B * (size_t)h->M.info_dim);
+        scan(h->d_aux + (size_t)ROW_REWARD * S, B);
+        scan(h->d_aux + (size_t)ROW_INFO * S, S * (size_t)h->M.info_dim);
     }
     HIP_TRY(hipGetLastError());
     unsigned long long bad = 0;
@@ -496,6 +515,7 @@ int rsx_create(rsx_sim** out, int kind, int field_type, int n_blue, int n_yellow
         delete h;
         return fail(RSX_ERR_ARG, "bad simulator configuration (kind / field_type / robot counts / time step / num_envs)");
     }
+    h->P.row_stride = num_envs + row_pad_for(num_envs);
     h->device = device_id;
     h->field_type = field_type; h->time_step_ms = time_step_ms;
     h->L = pick_lanes(h->P.n_robots + 1);
@@ -508,9 +528,9 @@ int rsx_create(rsx_sim** out, int kind, int field_type, int n_blue, int n_yellow
     hipError_t e;
     DeviceGuard guard;
     if (guard.enter(device_id)) { free_all(h); delete h; return RSX_ERR_HIP; }
-    const size_t B = (size_t)num_envs;
-    const size_t sbytes = (size_t)(h->P.state_dim + X_ROWS) * B * sizeof(float);
-    const size_t cbytes = (size_t)h->P.n_robots * h->M.cmd_dim * B * sizeof(float);
+    const size_t B = (size_t)num_envs, S = (size_t)h->P.row_stride;
+    const size_t sbytes = (size_t)(h->P.state_dim + X_ROWS) * S * sizeof(float);
+    const size_t cbytes = (size_t)h->P.n_robots * h->M.cmd_dim * S * sizeof(float);
     if (sbytes >= ((size_t)1 << 32)) {   // the kernels address a row of the state with a 32-bit byte offset (rsx_kernels.hpp: at_byte)
         free_all(h); delete h;
         return fail(RSX_ERR_ARG, "num_envs too large: the state array would reach 4 GB (see rsx.h, limits)");
@@ -532,12 +552,12 @@ int rsx_create(rsx_sim** out, int kind, int field_type, int n_blue, int n_yellow
         }
     }
     // the adapter's dummy line-up, rsim.py:20-24
-    std::vector<float> soa((size_t)(h->P.state_dim + X_ROWS) * B, 0.0f);
+    std::vector<float> soa((size_t)(h->P.state_dim + X_ROWS) * S, 0.0f);
     for (size_t i = 0; i < B; ++i) {
-        soa[2 * B + i] = (float)h->M.field[6];
+        soa[2 * S + i] = (float)h->M.field[6];
         for (int k = 0; k < h->P.n_robots; ++k) {
             const int j = k < n_blue ? k + 1 : k - n_blue + 1;
-            soa[(size_t)(5 + h->M.rs * k) * B + i] = (float)((k < n_blue ? -0.2 : 0.2) * j);
+            soa[(size_t)(5 + h->M.rs * k) * S + i] = (float)((k < n_blue ? -0.2 : 0.2) * j);
         }
     }
     if ((e = hipMemcpy(h->d_state, soa.data(), sbytes, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(state)");
@@ -570,7 +590,7 @@ int rsx_reset(rsx_sim* h, const double* ball, const double* blue, const double* 
     hipStream_t s = (hipStream_t)stream;
     std::vector<float> soa;
     if (env_mask) { if (int rc = download_state(h, soa, s)) return rc; }
-    else soa.assign((size_t)(h->P.state_dim + X_ROWS) * h->P.num_envs, 0.0f);
+    else soa.assign((size_t)(h->P.state_dim + X_ROWS) * h->P.row_stride, 0.0f);
     apply_reset(h, soa, ball, blue, yellow, env_mask);
     return upload_state(h, soa, s);
 }
@@ -580,19 +600,19 @@ int rsx_step(rsx_sim* h, const double* cmds, void* stream) {
     if (!cmds) return fail(RSX_ERR_ARG, "cmds is null");
     hipStream_t s = (hipStream_t)stream;
     const Params& P = h->P;
-    const size_t B = (size_t)P.num_envs, NC = (size_t)P.n_robots * h->M.cmd_dim;
+    const size_t B = (size_t)P.num_envs, S = (size_t)P.row_stride, NC = (size_t)P.n_robots * h->M.cmd_dim;
     for (size_t e = 0; e < B; ++e)
-        for (size_t j = 0; j < NC; ++j) h->pin_cmds[j * B + e] = (float)cmds[e * NC + j];
+        for (size_t j = 0; j < NC; ++j) h->pin_cmds[j * S + e] = (float)cmds[e * NC + j];
     h->host_state_valid = false;
     if (h->pin_cmds_dev) {   // small batch: no copies, the kernel talks to the pinned buffers
         launch_sim(h, s, nullptr, -1, 0, h->pin_cmds_dev, h->host_state_cache ? h->pin_state_dev : nullptr);
         HIP_TRY(hipGetLastError());
     } else {
-        HIP_TRY(hipMemcpyAsync(h->d_cmds, h->pin_cmds, NC * B * sizeof(float), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(h->d_cmds, h->pin_cmds, NC * S * sizeof(float), hipMemcpyHostToDevice, s));
         launch_sim(h, s);
         HIP_TRY(hipGetLastError());
         if (h->host_state_cache)
-            HIP_TRY(hipMemcpyAsync(h->pin_state, h->d_state, (size_t)(P.state_dim + X_ROWS) * B * sizeof(float), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(h->pin_state, h->d_state, (size_t)(P.state_dim + X_ROWS) * S * sizeof(float), hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(hipStreamSynchronize(s));
     h->host_state_valid = h->host_state_cache;
@@ -600,15 +620,15 @@ int rsx_step(rsx_sim* h, const double* cmds, void* stream) {
 }
 
 static int get_state_impl(rsx_sim* h, double* out, int rows, hipStream_t s) {
-    const size_t B = (size_t)h->P.num_envs;
+    const size_t B = (size_t)h->P.num_envs, S = (size_t)h->P.row_stride;
     if (!h->host_state_valid) {
-        HIP_TRY(hipMemcpyAsync(h->pin_state, h->d_state, (size_t)(h->P.state_dim + X_ROWS) * B * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(h->pin_state, h->d_state, (size_t)(h->P.state_dim + X_ROWS) * S * sizeof(float), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         h->host_state_valid = h->host_state_cache;
     }
     const float* soa = h->pin_state;
     for (size_t e = 0; e < B; ++e)
-        for (int f = 0; f < rows; ++f) out[e * rows + f] = (double)soa[(size_t)f * B + e];
+        for (int f = 0; f < rows; ++f) out[e * rows + f] = (double)soa[(size_t)f * S + e];
     return RSX_OK;
 }
 
@@ -633,11 +653,11 @@ int rsx_get_state_full(rsx_sim* h, double* out, void* stream) {
 int rsx_set_state(rsx_sim* h, const double* state, void* stream) {
     RSX_ENTER(h);
     if (!state) return fail(RSX_ERR_ARG, "state is null");
-    const size_t B = (size_t)h->P.num_envs;
+    const size_t B = (size_t)h->P.num_envs, S = (size_t)h->P.row_stride;
     const int rows = h->P.state_dim + X_ROWS;
-    std::vector<float> soa((size_t)rows * B);
+    std::vector<float> soa((size_t)rows * S);   // (zeros in the pad columns)
     for (size_t e = 0; e < B; ++e)
-        for (int f = 0; f < rows; ++f) soa[(size_t)f * B + e] = (float)state[e * rows + f];
+        for (int f = 0; f < rows; ++f) soa[(size_t)f * S + e] = (float)state[e * rows + f];
     return upload_state(h, soa, (hipStream_t)stream);
 }
 
@@ -645,7 +665,7 @@ int rsx_dev_view_get(rsx_sim* h, rsx_dev_view* out) {
     if (!h || !out) return fail(RSX_ERR_ARG, "null argument");
     out->num_envs = h->P.num_envs; out->n_robots = h->P.n_robots;
     out->state_dim = h->P.state_dim; out->cmd_dim = h->M.cmd_dim;
-    out->state = h->d_state; out->cmds = h->d_cmds;
+    out->state = h->d_state; out->cmds = h->d_cmds; out->row_stride = h->P.row_stride;
     h->host_state_cache = false; h->host_state_valid = false;   // the caller can now write the state behind our back
     return RSX_OK;
 }
@@ -660,7 +680,7 @@ int rsx_step_dev(rsx_sim* h, void* stream) {
 
 static int ensure_alt(rsx_sim* h) {
     if (h->d_state_alt) return RSX_OK;
-    const size_t sbytes = (size_t)(h->P.state_dim + X_ROWS) * h->P.num_envs * sizeof(float);
+    const size_t sbytes = (size_t)(h->P.state_dim + X_ROWS) * h->P.row_stride * sizeof(float);
     HIP_TRY(hipMalloc((void**)&h->d_state_alt, sbytes));
     HIP_TRY(hipMemset(h->d_state_alt, 0, sbytes));
     HIP_TRY(hipDeviceSynchronize());
@@ -708,7 +728,7 @@ int rsx_reset_dev(rsx_sim* h, const float* ball_dev, const float* blue_dev, cons
     h->host_state_valid = false;
     const int B = h->P.num_envs;
     hipLaunchKernelGGL(reset_dev_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->d_state, ball_dev, blue_dev,
-                       yellow_dev, env_mask_dev, B, h->P.state_dim + X_ROWS, h->M.rs, h->P.n_blue, h->P.n_yellow, (float)h->M.field[6]);
+                       yellow_dev, env_mask_dev, B, h->P.row_stride, h->P.state_dim + X_ROWS, h->M.rs, h->P.n_blue, h->P.n_yellow, (float)h->M.field[6]);
     HIP_TRY(hipGetLastError());
     return RSX_OK;
 }
@@ -725,8 +745,8 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
     if (P.obs_dim > 64) return fail(RSX_ERR_ARG, "observation wider than 64 floats is not supported");
     if (task >= RSX_TASK_SSL_DRIBBLING && task <= RSX_TASK_SSL_PASS_ENDURANCE && h->L != 8)
         return fail(RSX_ERR_ARG, "this task runs with 8 lanes per env only (unset RSX_LANES_PER_ENV)");
-    const size_t B = (size_t)P.num_envs;
-    const size_t n_aux = align_up((size_t)aux_rows(P.n_robots) * B * sizeof(float));
+    const size_t B = (size_t)P.num_envs, S = (size_t)P.row_stride;
+    const size_t n_aux = align_up((size_t)aux_rows(P.n_robots) * S * sizeof(float));
     if (n_aux >= ((size_t)1 << 32) || B * (size_t)P.obs_dim * sizeof(float) >= ((size_t)1 << 32))
         return fail(RSX_ERR_ARG, "num_envs too large for a fused task: the per-env scalar arena or the observation array would reach 4 GB (see rsx.h, limits)");
     const size_t n_obs = align_up(B * P.obs_dim * sizeof(float));
@@ -758,7 +778,7 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
     }
     if (n_pcs) h->d_pcstats = (unsigned long long*)p;
     // episode ids start at 0xFFFFFFFF so that the first reset() opens episode 0
-    HIP_TRY(hipMemset(h->d_aux + (size_t)ROW_EPISODE * B, 0xFF, B * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(h->d_aux + (size_t)ROW_EPISODE * S, 0xFF, B * sizeof(uint32_t)));
     h->P = P;
     // The five registered tasks: which tile layout steps the envs.  Both give identical results; the one-lane-
     // per-env kernel needs enough envs to fill the chip with its long waves.
@@ -770,7 +790,7 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
         // four lanes per env: 32-bit row offsets (arrays below 2 GB), a real time step (the infrared row is rewritten)
         const char* lay = std::getenv("RSX_LAYOUT");
         const size_t rows = (size_t)std::max(P.state_dim + X_ROWS, aux_rows(P.n_robots));
-        const bool fits = rows * (size_t)P.num_envs * sizeof(float) < ((size_t)1 << 31) && P.n_sub > 0 && P.n_blue == 11;
+        const bool fits = rows * (size_t)P.row_stride * sizeof(float) < ((size_t)1 << 31) && P.n_sub > 0 && P.n_blue == 11;
         // measured crossovers (profiles/LABBOOK.md): the spread line-up from 32 768 envs, the crowded one (contacts in every
         // sub-step: the six robots of a lane are walked one after the other) from 65 536 (RSX_QUAD_MIN_ENVS_CROWDED);
         // multi-step calls on a crowded handle stay with the 32-lane kernel below 262 144 envs (rsx_task_rollout)
@@ -786,7 +806,7 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
                                      : task == RSX_TASK_SSL_DRIBBLING ? 49152 : 32768);
         // those kernels address rows with 32-bit byte offsets (buffer instructions): arrays of 2 GB and more stay with the lane-group kernels
         const size_t rows = (size_t)std::max(P.state_dim + X_ROWS, aux_rows(P.n_robots));
-        if (rows * (size_t)P.num_envs * sizeof(float) >= ((size_t)1 << 31) || (size_t)P.num_envs * P.obs_dim * sizeof(float) >= ((size_t)1 << 31)) h->epl = false;
+        if (rows * (size_t)P.row_stride * sizeof(float) >= ((size_t)1 << 31) || (size_t)P.num_envs * P.obs_dim * sizeof(float) >= ((size_t)1 << 31)) h->epl = false;
     }
     h->task_ready = false;
     h->tick_dev = false;
@@ -851,11 +871,12 @@ int rsx_task_view_get(rsx_sim* h, rsx_task_view* out) {
     const size_t B = (size_t)h->P.num_envs;
     out->task = h->P.task; out->obs_dim = h->P.obs_dim; out->act_dim = h->M.act_dim;
     out->info_dim = h->M.info_dim; out->max_episode_steps = h->P.max_steps;
-    out->obs = h->d_obs; out->reward = h->d_aux + (size_t)ROW_REWARD * B;
+    const size_t S = (size_t)h->P.row_stride;
+    out->obs = h->d_obs; out->reward = h->d_aux + (size_t)ROW_REWARD * S;
     out->terminated = h->d_flags; out->truncated = h->d_flags + B;
-    out->info = h->d_aux + (size_t)ROW_INFO * B; out->final_obs = h->d_final_obs;
-    out->steps = (int32_t*)(h->d_aux + (size_t)ROW_STEPS * B); out->actions = h->d_actions;
-    out->metrics = (int64_t*)h->d_metrics;
+    out->info = h->d_aux + (size_t)ROW_INFO * S; out->final_obs = h->d_final_obs;
+    out->steps = (int32_t*)(h->d_aux + (size_t)ROW_STEPS * S); out->actions = h->d_actions;
+    out->metrics = (int64_t*)h->d_metrics; out->row_stride = h->P.row_stride;
     return RSX_OK;
 }
 
@@ -1003,8 +1024,10 @@ int rsx_task_checkpoint_save(rsx_sim* h, void* blob, size_t bytes, void* stream)
     hipLaunchKernelGGL(fold_metrics_kernel, dim3(1), dim3(64), 0, s, h->d_metrics, h->d_mslots);
     HIP_TRY(hipGetLastError());
     char* p = (char*)blob + sizeof(CkptHeader);
-    HIP_TRY(hipMemcpyAsync(p, h->d_state, k.state_bytes, hipMemcpyDeviceToHost, s)); p += k.state_bytes;
-    HIP_TRY(hipMemcpyAsync(p, h->d_aux, k.aux_bytes, hipMemcpyDeviceToHost, s)); p += k.aux_bytes;
+    // (the blob's rows are dense — B floats — whatever the row pad of this handle: it restores into any layout)
+    const size_t rowb = (size_t)h->P.num_envs * sizeof(float), pitch = (size_t)h->P.row_stride * sizeof(float);
+    HIP_TRY(hipMemcpy2DAsync(p, rowb, h->d_state, pitch, rowb, (size_t)k.state_rows, hipMemcpyDeviceToHost, s)); p += k.state_bytes;
+    HIP_TRY(hipMemcpy2DAsync(p, rowb, h->d_aux, pitch, rowb, (size_t)k.aux_rows, hipMemcpyDeviceToHost, s)); p += k.aux_bytes;
     HIP_TRY(hipMemcpyAsync(p, h->d_obs, k.obs_bytes, hipMemcpyDeviceToHost, s)); p += k.obs_bytes;
     HIP_TRY(hipMemcpyAsync(p, h->d_final_obs, k.obs_bytes, hipMemcpyDeviceToHost, s)); p += k.obs_bytes;
     HIP_TRY(hipMemcpyAsync(p, h->d_flags, k.flag_bytes, hipMemcpyDeviceToHost, s));
@@ -1053,8 +1076,9 @@ int rsx_task_checkpoint_load(rsx_sim* h, const void* blob, size_t bytes, void* s
     hipStream_t s = (hipStream_t)stream;
     const char* p = (const char*)blob + sizeof(CkptHeader);
     h->host_state_valid = false;
-    HIP_TRY(hipMemcpyAsync(h->d_state, p, k.state_bytes, hipMemcpyHostToDevice, s)); p += k.state_bytes;
-    HIP_TRY(hipMemcpyAsync(h->d_aux, p, k.aux_bytes, hipMemcpyHostToDevice, s)); p += k.aux_bytes;
+    const size_t rowb = (size_t)h->P.num_envs * sizeof(float), pitch = (size_t)h->P.row_stride * sizeof(float);
+    HIP_TRY(hipMemcpy2DAsync(h->d_state, pitch, p, rowb, rowb, (size_t)k.state_rows, hipMemcpyHostToDevice, s)); p += k.state_bytes;
+    HIP_TRY(hipMemcpy2DAsync(h->d_aux, pitch, p, rowb, rowb, (size_t)k.aux_rows, hipMemcpyHostToDevice, s)); p += k.aux_bytes;
     HIP_TRY(hipMemcpyAsync(h->d_obs, p, k.obs_bytes, hipMemcpyHostToDevice, s)); p += k.obs_bytes;
     HIP_TRY(hipMemcpyAsync(h->d_final_obs, p, k.obs_bytes, hipMemcpyHostToDevice, s)); p += k.obs_bytes;
     HIP_TRY(hipMemcpyAsync(h->d_flags, p, k.flag_bytes, hipMemcpyHostToDevice, s));

@@ -18,10 +18,10 @@ void launch_scrimmage_big(bool rollout, const Params& P, const Buffers& b, int n
     const dim3 grid((unsigned)(((tiles + 7) / 8) * 8));
     if (rollout)
         hipLaunchKernelGGL((task_step_kernel_big<RSX_KIND_SSL, 32, RSX_TASK_SSL_SCRIMMAGE, 22, MODE_ROLLOUT>), grid, dim3(64), 0, s, b.state, b.aux,
-                           b.actions, b.flags, P.num_envs, P.state_dim, (int)(grid.x >> 3), n_steps, P, b);
+                           b.actions, b.flags, P.num_envs, RSX_HOT_DIM(P.state_dim, P.row_stride, P.num_envs), (int)(grid.x >> 3), n_steps, P, b);
     else
         hipLaunchKernelGGL((task_step_kernel_big<RSX_KIND_SSL, 32, RSX_TASK_SSL_SCRIMMAGE, 22, MODE_STEP>), grid, dim3(64), 0, s, b.state, b.aux,
-                           b.actions, b.flags, P.num_envs, P.state_dim, (int)(grid.x >> 3), n_steps, P, b);
+                           b.actions, b.flags, P.num_envs, RSX_HOT_DIM(P.state_dim, P.row_stride, P.num_envs), (int)(grid.x >> 3), n_steps, P, b);
 }
 
 }  // namespace rsx

@@ -41,10 +41,10 @@ void launch_vss_epl(bool rollout, const Params& P, const Buffers& b, int n_steps
     const dim3 grid((unsigned)(((tiles + 7) / 8) * 8));
     if (rollout)
         hipLaunchKernelGGL(vss_epl_rollout_kernel, grid, dim3(64), 0, s, b.state, b.aux, b.actions, b.flags,
-                           P.num_envs, P.state_dim, (int)(grid.x >> 3), n_steps, P, b);
+                           P.num_envs, RSX_HOT_DIM(P.state_dim, P.row_stride, P.num_envs), (int)(grid.x >> 3), n_steps, P, b);
     else
         hipLaunchKernelGGL((vss_epl_kernel<MODE_STEP>), grid, dim3(64), epl_lds_pad(), s, b.state, b.aux, b.actions, b.flags,
-                           P.num_envs, P.state_dim, step_per_xcd(P, grid, n_steps), n_steps, P, b);
+                           P.num_envs, RSX_HOT_DIM(P.state_dim, P.row_stride, P.num_envs), step_per_xcd(P, grid, n_steps), n_steps, P, b);
 }
 
 template <int TASK>
@@ -53,7 +53,7 @@ static void launch_ssl_epl_t(bool rollout, const Params& P, const Buffers& b, in
     const dim3 grid((unsigned)(((tiles + 7) / 8) * 8));
     if (rollout)
         hipLaunchKernelGGL((ssl_epl_kernel<TASK, MODE_ROLLOUT>), grid, dim3(64), 0, s, b.state, b.aux, b.actions, b.flags,
-                           P.num_envs, P.state_dim, (int)(grid.x >> 3), n_steps, P, b);
+                           P.num_envs, RSX_HOT_DIM(P.state_dim, P.row_stride, P.num_envs), (int)(grid.x >> 3), n_steps, P, b);
     else {
         // the lean single-step form (rsx_epl_ssl.hpp): 1v6 below RSX_SD_LEAN_MAX_ENVS (occupancy-bound there: 262 144 envs 52 -> 47 us;
         // at 1 M envs, bandwidth-bound, the classic form is 4-7 % faster), contested possession always (-5 %); measured equal
@@ -64,17 +64,17 @@ static void launch_ssl_epl_t(bool rollout, const Params& P, const Buffers& b, in
                                      : TASK == RSX_TASK_SSL_CONTESTED || (TASK == RSX_TASK_SSL_STATIC_DEFENDERS && P.num_envs < RSX_SD_LEAN_MAX_ENVS);
         if (lean && (TASK == RSX_TASK_SSL_CONTESTED || TASK == RSX_TASK_SSL_STATIC_DEFENDERS))
             hipLaunchKernelGGL((ssl_epl_kernel<TASK, MODE_STEP, (TASK == RSX_TASK_SSL_CONTESTED || TASK == RSX_TASK_SSL_STATIC_DEFENDERS)>), grid, dim3(64), 0, s,
-                               b.state, b.aux, b.actions, b.flags, P.num_envs, P.state_dim, step_per_xcd(P, grid, n_steps), n_steps, P, b);
+                               b.state, b.aux, b.actions, b.flags, P.num_envs, RSX_HOT_DIM(P.state_dim, P.row_stride, P.num_envs), step_per_xcd(P, grid, n_steps), n_steps, P, b);
         else
             hipLaunchKernelGGL((ssl_epl_kernel<TASK, MODE_STEP>), grid, dim3(64), 0, s, b.state, b.aux, b.actions, b.flags,
-                               P.num_envs, P.state_dim, step_per_xcd(P, grid, n_steps), n_steps, P, b);
+                               P.num_envs, RSX_HOT_DIM(P.state_dim, P.row_stride, P.num_envs), step_per_xcd(P, grid, n_steps), n_steps, P, b);
     }
 }
 
 void launch_ssl_quad(const Params& P, const Buffers& b, int n_steps, hipStream_t s) {   // SSL 11v11 scrimmage, four lanes per env, single-step launches (n_steps = 1 | flags)
     const dim3 grid((unsigned)ssl_quad_grid(P.num_envs));
     hipLaunchKernelGGL((ssl_quad_kernel<MODE_STEP>), grid, dim3(64), 0, s, b.state, b.aux, b.actions, b.flags,
-                       P.num_envs, P.state_dim, step_per_xcd(P, grid, n_steps), n_steps, P, b);
+                       P.num_envs, RSX_HOT_DIM(P.state_dim, P.row_stride, P.num_envs), step_per_xcd(P, grid, n_steps), n_steps, P, b);
 }
 
 // workgroups of a launch (the host sizes the per-workgroup tick slots from these: rsx_kernels.hpp, step_tick)

@@ -66,7 +66,7 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
     using K = KC<KIND>;
     using T = TC<TASK>;
     constexpr int ID = T::info_dim;
-    Params P = P_; P.num_envs = hp_num_envs; P.state_dim = hp_state_dim;
+    Params P = P_; RSX_UNPACK_HOT(P);
     Buffers bufs = bufs_; bufs.state = hp_state; bufs.aux = hp_aux; bufs.actions = hp_in; bufs.flags = hp_flags;
     const int n_steps = MODE == MODE_ROLLOUT ? (hp_n_steps & RSX_N_STEPS_MASK) : 1;
     __shared__ EplShared sh;
@@ -84,7 +84,7 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
     const int e = live ? e_raw : P.num_envs - 1;
     const size_t B = (size_t)P.num_envs;
     const uint32_t env_id = P.env_id_base + (uint32_t)e;   // (the reset path derives its own copy from eo)
-    const EplIO io(bufs.state, bufs.aux, P.num_envs, e);   // this lane's column of the [rows][B] arrays (rsx_epl_common.hpp)
+    const EplIO io(bufs.state, bufs.aux, P.row_stride, e);   // this lane's column of the [rows][B] arrays (rsx_epl_common.hpp)
     const uint32_t eo = io.eo;
     const __amdgpu_buffer_rsrc_t S = io.S, A = io.A;
 

@@ -14,9 +14,9 @@ struct EplIO {
     __amdgpu_buffer_rsrc_t S, A;   // state, aux
     uint32_t eo;                   // 4 * env
     int B4;                        // bytes per row
-    __device__ __forceinline__ EplIO(float* state, float* aux, int num_envs, int e)
+    __device__ __forceinline__ EplIO(float* state, float* aux, int row_stride, int e)
         : S(__builtin_amdgcn_make_buffer_rsrc(state, 0, -1, 0x00020000)), A(__builtin_amdgcn_make_buffer_rsrc(aux, 0, -1, 0x00020000)),
-          eo(4u * (uint32_t)e), B4(4 * num_envs) {}
+          eo(4u * (uint32_t)e), B4(4 * row_stride) {}
     __device__ __forceinline__ float ld(const __amdgpu_buffer_rsrc_t rs, int row) const {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)eo, row * B4, 0));
     }

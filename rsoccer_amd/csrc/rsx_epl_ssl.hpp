@@ -60,7 +60,7 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
     // physics, robot rows are stored robot by robot while the observation is assembled — 151 -> 128 VGPRs for 1v6 (4 waves per
     // SIMD), at the price of a second set of row stores in the lanes that reset and of loads nothing can hide behind
     constexpr bool LATE = LEAN;
-    Params P = P_; P.num_envs = hp_num_envs; P.state_dim = hp_state_dim;
+    Params P = P_; RSX_UNPACK_HOT(P);
     Buffers bufs = bufs_; bufs.state = hp_state; bufs.aux = hp_aux; bufs.actions = hp_in; bufs.flags = hp_flags;
     const int n_steps = MODE == MODE_ROLLOUT ? (hp_n_steps & RSX_N_STEPS_MASK) : 1;
     __shared__ SeplShared<N> sh;
@@ -76,7 +76,7 @@ void ssl_epl_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
     const int e = live ? e_raw : P.num_envs - 1;   // lanes beyond the batch shadow its last env (loads valid and unconditional; stores, counters masked)
     const size_t B = (size_t)P.num_envs;
     const uint32_t env_id = P.env_id_base + (uint32_t)e;
-    EplIO io(bufs.state, bufs.aux, P.num_envs, e);   // this lane's column of the [rows][B] arrays (rsx_epl_common.hpp)
+    EplIO io(bufs.state, bufs.aux, P.row_stride, e);   // this lane's column of the [rows][B] arrays (rsx_epl_common.hpp)
     asm volatile("" : "+v"(io.eo));   // THE per-lane offset of the step: everything later derives from it, not from the env index
     const uint32_t eo = io.eo;
     const __amdgpu_buffer_rsrc_t S = io.S, A = io.A;

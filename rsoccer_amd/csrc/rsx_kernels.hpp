@@ -638,7 +638,7 @@ template <int KIND>
 __device__ __forceinline__ RawBody load_raw(const Params& P, const float* __restrict__ st, int e,
                                             int b, bool is_robot, bool is_ball) {
     constexpr int RS = ModelD<KIND>::rs;
-    const ix_t B4 = (ix_t)4 * (ix_t)P.num_envs, e4 = (ix_t)4 * (ix_t)e;   // bytes per row, this env's column
+    const ix_t B4 = (ix_t)4 * (ix_t)P.row_stride, e4 = (ix_t)4 * (ix_t)e;   // bytes per row, this env's column
     RawBody r{};
     if (is_robot || is_ball) {
         const int row0 = is_ball ? 0 : 5 + RS * b;
@@ -705,7 +705,7 @@ __device__ __forceinline__ void store_body(const Params& P, float* __restrict__ 
                                            bool write_ir) {
     using K = KC<KIND>;
     constexpr int RS = ModelD<KIND>::rs;
-    const ix_t B4 = (ix_t)4 * (ix_t)P.num_envs, e4 = (ix_t)4 * (ix_t)e;
+    const ix_t B4 = (ix_t)4 * (ix_t)P.row_stride, e4 = (ix_t)4 * (ix_t)e;
     if (is_robot || is_ball) {
         const int row0 = is_ball ? 0 : 5 + RS * b;
         const int row5 = is_ball ? P.state_dim : row0 + 5;
@@ -752,6 +752,11 @@ __device__ __forceinline__ int zigzag_per(const bool dev, const uint32_t tick, c
 // follow carry everything else and are fetched while the state loads are in flight.
 #define RSX_HOT_ARGS float* hp_state, float* hp_aux, const float* hp_in, uint8_t* hp_flags, \
                      const int hp_num_envs, const int hp_state_dim, const int hp_per_xcd, const int hp_n_steps
+// The two counts of the batch travel in the hot dwords: hp_num_envs = B, and the row pad of the [rows][B] arrays (a multiple of 64
+// floats, rsx_api.hip: row_pad_for) in the upper half of hp_state_dim — scalar shifts, no wait for the parameter block.
+#define RSX_HOT_DIM(state_dim, row_stride, num_envs) ((int)((unsigned)(state_dim) | ((unsigned)(((row_stride) - (num_envs)) >> 6) << 16)))
+#define RSX_UNPACK_HOT(P) do { (P).num_envs = hp_num_envs; (P).state_dim = hp_state_dim & 0xFFFF; \
+                               (P).row_stride = hp_num_envs + (int)(((unsigned)hp_state_dim >> 16) << 6); } while (0)
 // bytes of the kernarg segment RSX_HOT_ARGS occupies: the by-value Params block starts at the next multiple of its alignment
 // (the late parameter fetch below and in rsx_quad_ssl.hpp reads it from there — keep the two in step when a hot argument is added)
 constexpr size_t RSX_HOT_ARGS_BYTES = 4 * sizeof(void*) + 4 * sizeof(int);
@@ -767,7 +772,7 @@ static_assert(bytes_of(&probe) == RSX_HOT_ARGS_BYTES, "RSX_HOT_ARGS changed: upd
 // =============================================================================================
 template <int KIND, int L, int NR>
 __global__ __launch_bounds__(64) void sim_step_kernel(RSX_HOT_ARGS, const Params P_, const Buffers bufs_) {
-    Params P = P_; P.num_envs = hp_num_envs; P.state_dim = hp_state_dim;
+    Params P = P_; RSX_UNPACK_HOT(P);
     Buffers bufs = bufs_; bufs.state = hp_state; bufs.cmds = hp_in;   // hp_in: the command buffer
     float* const state_out = hp_aux;   // this kernel's second pointer slot: where the new state goes (== hp_state: in place)
     // fourth pointer slot: a second copy of the new state, or nullptr.  The host-format calls of small batches
@@ -800,7 +805,7 @@ __global__ __launch_bounds__(64) void sim_step_kernel(RSX_HOT_ARGS, const Params
             if (KIND == RSX_KIND_SSL) { q[1] = a0 * 2.5f; q[2] = a1 * 2.5f; q[3] = a2 * 10.0f; }
             else { q[0] = a0 * K::w_max; q[1] = a1 * K::w_max; }
         } else {
-            const ix_t B4 = (ix_t)4 * (ix_t)P.num_envs, c0 = (ix_t)(b * CD) * B4 + (ix_t)4 * (ix_t)e;
+            const ix_t B4 = (ix_t)4 * (ix_t)P.row_stride, c0 = (ix_t)(b * CD) * B4 + (ix_t)4 * (ix_t)e;
 #pragma unroll
             for (int i = 0; i < CD; ++i) q[i] = at_byte(bufs.cmds, c0 + (ix_t)i * B4);
         }
@@ -1362,7 +1367,7 @@ __device__ __forceinline__ void placement_helper(const Params& P, const Buffers&
     uint32_t ep_next = 0;
     bool stale = false;
     if (e0 < P.num_envs) {
-        ep_next = __float_as_uint(bufs.aux[(size_t)ROW_EPISODE * B + e0]) + 1u;
+        ep_next = __float_as_uint(bufs.aux[(size_t)ROW_EPISODE * (size_t)P.row_stride + e0]) + 1u;
         stale = __float_as_uint(pw[(size_t)(3 * NBD) * B + e0]) != ep_next;
     }
     unsigned long long todo = __ballot(stale);
@@ -1411,7 +1416,7 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
     Params P = P_;
     Buffers bufs = bufs_;
     if (HOT) {
-        P.num_envs = hp_num_envs; P.state_dim = hp_state_dim;
+        RSX_UNPACK_HOT(P);
         bufs.state = hp_state; bufs.aux = hp_aux; bufs.actions = hp_in; bufs.flags = hp_flags;
     }
     const int n_steps_arg = hp_n_steps & RSX_N_STEPS_MASK;
@@ -1458,7 +1463,7 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
         : TASK == RSX_TASK_SSL_SCRIMMAGE ? 2 + 2 * NR
         : TASK == RSX_TASK_SSL_DRIBBLING ? 21 : TASK == RSX_TASK_SSL_CONTESTED ? 14 : 16;
     const int OD = OD_C ? OD_C : P.obs_dim;
-#define auxe(ROW) at_byte(bufs.aux, (ix_t)(ROW) * ((ix_t)4 * (ix_t)P.num_envs) + (ix_t)4 * (ix_t)e)   // row ROW of this env in the scalar arena
+#define auxe(ROW) at_byte(bufs.aux, (ix_t)(ROW) * ((ix_t)4 * (ix_t)P.row_stride) + (ix_t)4 * (ix_t)e)   // row ROW of this env in the scalar arena
 
 #ifdef RSX_TIMING
 #define RSX_STAMP(i) do { if (lane == 0) bufs.dbg[(size_t)(i) * gridDim.x + blockIdx.x] = __builtin_readcyclecounter(); } while (0)
@@ -1648,7 +1653,7 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
 #pragma unroll
                 for (size_t i = 0; i < sizeof(Params) / 4; ++i) raw.w[i] = pk[i];
                 P = __builtin_bit_cast(Params, raw);
-                P.num_envs = hp_num_envs; P.state_dim = hp_state_dim;
+                RSX_UNPACK_HOT(P);
             }
 #endif
 

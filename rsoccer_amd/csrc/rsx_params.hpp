@@ -165,6 +165,7 @@ template <> struct TC<RSX_TASK_SSL_SCRIMMAGE> : TCSslBase {   // both line-ups r
 // ---------------------------------------------------------------------------------------------
 struct Params {
     int kind, n_blue, n_yellow, n_robots, n_sub, state_dim, num_envs;
+    int row_stride;   // floats between consecutive rows of the [rows][B] arrays state / cmds / aux: num_envs + a pad (rsx_api.hip: row_pad_for)
     // sub-step and field dependent
     float h, h_deg, a_lin_h, a_lin_h2, a_lat_h, a_ang_h, mu_g_dt, g_h, drib_gain, spin_dec_dt;
     float half_len, half_wid, ghw, gd;
@@ -260,7 +261,7 @@ inline int derive_model(int kind, int field_type, int nb, int ny, int ts_ms, int
     std::memset(&M, 0, sizeof(M));
     if (kind != RSX_KIND_VSS && kind != RSX_KIND_SSL) return -1;
     if (nb < 0 || ny < 0 || nb + ny < 1 || nb + ny > MAX_ROBOTS || ts_ms < 0 || num_envs < 1) return -1;
-    P.kind = kind; P.n_blue = nb; P.n_yellow = ny; P.n_robots = nb + ny; P.num_envs = num_envs;
+    P.kind = kind; P.n_blue = nb; P.n_yellow = ny; P.n_robots = nb + ny; P.num_envs = num_envs; P.row_stride = num_envs;
     const int rc = kind == RSX_KIND_VSS ? derive_model_k<RSX_KIND_VSS>(field_type, ts_ms, P, M)
                                         : derive_model_k<RSX_KIND_SSL>(field_type, ts_ms, P, M);
     if (rc) return rc;

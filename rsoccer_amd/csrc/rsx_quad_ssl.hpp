@@ -76,7 +76,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
     constexpr int KIND = RSX_KIND_SSL, TASK = RSX_TASK_SSL_SCRIMMAGE, N = Q_N, R = Q_R, RS = 11;
     using K = KC<KIND>;
     using T = TC<TASK>;
-    Params P = P_; P.num_envs = hp_num_envs; P.state_dim = hp_state_dim;
+    Params P = P_; RSX_UNPACK_HOT(P);
     Buffers bufs = bufs_; bufs.state = hp_state; bufs.aux = hp_aux; bufs.actions = hp_in; bufs.flags = hp_flags;
     __shared__ QuadShared sh;
     const int lane = threadIdx.x;
@@ -95,10 +95,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
     const uint32_t env_id = P.env_id_base + (uint32_t)e;
     // buffer addressing (rsx_epl.hpp): resource per array, row as the scalar offset, one 32-bit lane offset per array
     const uint32_t eo = 4u * (uint32_t)e;                                              // the env's column
-    const uint32_t ro = eo + 4u * (uint32_t)(5 + RS * R * p) * (uint32_t)P.num_envs;     // ... from this lane's first robot row
+    const uint32_t ro = eo + 4u * (uint32_t)(5 + RS * R * p) * (uint32_t)P.row_stride;     // ... from this lane's first robot row
     const __amdgpu_buffer_rsrc_t S = __builtin_amdgcn_make_buffer_rsrc(bufs.state, 0, -1, 0x00020000);
     const __amdgpu_buffer_rsrc_t A = __builtin_amdgcn_make_buffer_rsrc(bufs.aux, 0, -1, 0x00020000);
-    const int B4 = 4 * P.num_envs;
+    const int B4 = 4 * P.row_stride;
     auto ld = [](const __amdgpu_buffer_rsrc_t rs, int row_off, uint32_t off) -> float {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, row_off, 0));
     };
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
 #pragma unroll
     for (int m = 0; m < R; ++m) {
         // (ghost slots read the rows of robots 16, 17 — valid memory — and are overwritten below)
-        const uint32_t rom = (m >= N - R * 3 && bl) ? ro - 4u * (uint32_t)(RS * 2) * (uint32_t)P.num_envs : ro;
+        const uint32_t rom = (m >= N - R * 3 && bl) ? ro - 4u * (uint32_t)(RS * 2) * (uint32_t)P.row_stride : ro;
 #pragma unroll
         for (int f = 0; f < 6; ++f) raw[m][f] = ld(S, (RS * m + f) * B4, rom);
     }
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
 #pragma unroll
         for (size_t i = 0; i < sizeof(Params) / 4; ++i) raww.w[i] = pk[i];
         P = __builtin_bit_cast(Params, raww);
-        P.num_envs = hp_num_envs; P.state_dim = hp_state_dim;
+        RSX_UNPACK_HOT(P);
     }
 #endif
     // ---- wire-format values, state rows, observation ----
