@@ -85,7 +85,7 @@ typedef struct rsx_sim rsx_sim; /* opaque */
 
 /* Device-side views, zero-copy.  SoA: row f of an [F][B] array is the contiguous run of B floats at
  * base + f*row_stride (one float per env).  row_stride >= num_envs: handles of 786 432 envs and more pad their rows
- * (64 KB + 256 B) so that the rows of an env do not all sit at the same address modulo a large power of two (DRAM banks;
+ * (64 KB + 256 B, 256 KB + 256 B from 1 572 864 envs) so that the rows of an env do not all sit at the same address modulo a large power of two (DRAM banks;
  * ABI 5).  Treat the arrays as strided 2-D views (torch: as_strided); a row by itself is dense.  state rows 0..state_dim-1 are exactly the reference's
  * get_state() layout (Entities/Frame.py:20-47 VSS, :55-92 SSL) transposed; rows state_dim and
  * state_dim + 1 hold the ball's vertical velocity and its spin (internal, needed to checkpoint

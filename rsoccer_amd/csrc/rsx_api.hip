@@ -439,9 +439,12 @@ size_t align_up(size_t n) { return (n + 255) & ~(size_t)255; }
 // (profiles/r05_row_stride.txt: pads from 256 B to 1 MB; exactly 256 KB is the worst, 64 KB + 256 B and 256 KB + 256 B the best).
 // A multiple of 64 floats (rows stay 256-byte aligned; it travels in 16 bits of a hot kernel argument: RSX_HOT_DIM).
 // RSX_ROW_PAD=<floats> overrides (tests run every kernel family with padded rows at small batches).
-constexpr int RSX_ROW_PAD_MIN_ENVS = 786432, RSX_ROW_PAD_FLOATS = 16448;   // (524 288 envs measured: no gain yet)
+constexpr int RSX_ROW_PAD_MIN_ENVS = 786432;   // (524 288 envs measured: no gain yet)
 int row_pad_for(int num_envs) {
-    long pad = num_envs >= RSX_ROW_PAD_MIN_ENVS ? RSX_ROW_PAD_FLOATS : 0;
+    // 64 KB + 256 B up to 1.5 M envs, 256 KB + 256 B beyond: at 2 M envs the smaller pad is no better than none (us per step, pads 0 /
+    // 16 448 / 65 600 floats: 1 M envs VSS 164 / 148 / 155, 1v6 169 / 157 / 166; 2 M envs VSS 312 / 314 / 286; 4 M envs VSS 638 / 587 / 585,
+    // 1v6 730 / 633 / 623)
+    long pad = num_envs < RSX_ROW_PAD_MIN_ENVS ? 0 : num_envs < 1572864 ? 16448 : 65600;
     if (const char* v = std::getenv("RSX_ROW_PAD")) pad = std::atol(v);
     if (pad < 0) pad = 0;
     pad = (pad + 63) / 64 * 64;

@@ -1,5 +1,5 @@
 """Padded rows (ABI 5): handles of 786 432 envs and more keep their [rows][B] arrays (state, commands, per-env scalars) with rows
-B + 16 448 floats apart (rsx_api.hip: row_pad_for — DRAM banks); RSX_ROW_PAD=<floats> forces a pad at any batch size, which is how
+B + 16 448 floats apart (+ 65 600 from 1.5 M envs; rsx_api.hip: row_pad_for — DRAM banks); RSX_ROW_PAD=<floats> forces a pad at any batch size, which is how
 every kernel family is exercised with padded rows here.  Results must not depend on the pad."""
 import os
 import subprocess
@@ -70,6 +70,9 @@ def test_default_pad_applies_to_large_batches_only():
     big.task_attach(1, 0, 0, 0); big.task_reset(); big.task_step_n(3)
     assert big.check_finite() == 0
     big.close()
+    huge = L.Sim(0, 0, 3, 3, 25, 1 << 21)
+    assert huge._view.row_stride == (1 << 21) + 65600
+    huge.close()
 
 
 def test_parity_suites_with_padded_rows():
