@@ -14,7 +14,7 @@
  *   - "dev" pointers are HIP device memory owned by the handle (valid until rsx_destroy); all
  *     device work is stream-ordered on the hipStream_t passed as `void* stream` (NULL = the
  *     null stream) and never synchronises implicitly, except the host-format calls
- *     (rsx_step / rsx_get_state / rsx_get_state_full / rsx_reset / rsx_set_state /
+ *     (rsx_step / rsx_step_state / rsx_step_wire / rsx_get_state / rsx_get_state_full / rsx_reset / rsx_set_state /
  *     rsx_task_reset_to / rsx_read_metrics), which take or return host arrays and therefore
  *     synchronise that stream; rsx_create and rsx_task_attach synchronise the device once
  *     (their buffers are initialised before any caller stream can touch them).
@@ -44,7 +44,11 @@
 extern "C" {
 #endif
 
-#define RSX_ABI_VERSION 5
+#define RSX_ABI_VERSION 6
+/* version of the 2-D step model the library implements (docs/PHYSICS.md): 1 = rounds 1-4; 2 = wall-aware contacts —
+ * the SSL class since ABI 5 (probed shares, goal posts), the VSS class since ABI 6 (held axes, chord posts).  Stored in checkpoints:
+ * a blob saved under another model version is refused (its trajectories would not continue bit-identically). */
+#define RSX_PHYSICS_MODEL 2
 
 /* kind: which robosim class the handle stands for (rsim.py:116 robosim.VSS, :169 robosim.SSL) */
 #define RSX_KIND_VSS 0
@@ -169,6 +173,18 @@ int rsx_get_state(rsx_sim* h, double* out, void* stream);
  * objects) run rsx_step / rsx_step_state without any copy: the kernel reads the commands from, and mirrors the new
  * state into, pinned host memory — one launch and one synchronisation per step. */
 int rsx_step_state(rsx_sim* h, const double* cmds, double* state_out, void* stream);
+
+/* The same pair for batches of more than 64 envs WITHOUT any pass of a CPU thread over the data (ABI 6).  Such handles own two pinned
+ * host buffers in the reference's wire format — commands [B][N][C] float64 (what rsim.py:92-101 / :129-153 build), state
+ * [B][state_dim + RSX_STATE_EXTRA_ROWS] float64 (the get_state() vector of rsim.py:105,158 followed by the two internal rows) — and
+ * convert between them and the device's float32 row layout ON THE DEVICE: small kernels read / write the pinned buffers across PCIe
+ * around the step kernel; one synchronisation.  rsx_wire_buffers returns the two buffers (valid until rsx_destroy; either pointer
+ * argument may be NULL); the caller writes commands into *cmds, calls rsx_step_wire, and reads the new state from *state.
+ * rsx_step / rsx_get_state / rsx_step_state on such handles are one memcpy in front of / behind the same path (before ABI 6: a
+ * transposing float64 <-> float32 loop on the calling thread plus two staging copies — 192 us per step + state at 4096 envs).
+ * Handles of at most 64 envs have no wire buffers (RSX_ERR_STATE): their rsx_step_state is already copy-free. */
+int rsx_wire_buffers(rsx_sim* h, double** cmds, double** state);
+int rsx_step_wire(rsx_sim* h, void* stream);
 
 /* full-state restore (checkpoint/resume, also used by parity tests): state
  * [B][state_dim + RSX_STATE_EXTRA_ROWS] host f64 = get_state() layout + ball vertical velocity

@@ -22,7 +22,8 @@ typedef struct SUF(rsxo_env) {
     R h, half_len, half_wid, ghw, gd, margin, r_robot, r_ball;
     R rs_rr, rs_rr2, rs_rb, rs_rb2;
     R w_rr, w_rb_r, w_rb_b, ope_rr, ope_rb, e_wb, e_wr, beta;
-    int wall_aware;   /* model v2: per-axis shares of robot - robot pairs at a wall, third / fourth sweep (SSL only: DESIGN.md 4) */
+    int wall_aware;   /* model v2, per-axis shares of robot - robot pairs at a wall: 1 = SSL (probes, third / fourth sweep), 2 = VSS (held axes) — DESIGN.md 4 */
+    R r_held;         /* VSS: a robot within 1 mm of where the wall clamp would hold it counts as held by that wall */
     R w_max, half_rw, rw_2b, inv_rw, r_wheel;
     R a_lin_h, a_lin_h2, a_lat_h, a_ang_h, mu_g_dt, g_h, e_ground, vz_min, robot_h;
     R dck_rb, half_kw, ir_tol, drib_gain, drib_vmax, drib_vmax2;
@@ -70,7 +71,8 @@ void* SUF(rsxo_create)(int kind, int field_type, int nb, int ny, int ts_ms) {
     e->rs_rb = RC(c->r_robot + c->r_ball);
     e->rs_rb2 = RC((c->r_robot + c->r_ball) * (c->r_robot + c->r_ball));
     double imr = 1.0 / c->m_robot, imb = 1.0 / c->m_ball;
-    e->wall_aware = c->kind == 1;
+    e->wall_aware = c->kind == 1 ? 1 : 2;
+    e->r_held = RC(c->r_robot + 0.001);
     e->w_rr = RC(0.5); e->w_rb_r = RC(imr / (imr + imb)); e->w_rb_b = RC(imb / (imr + imb));
     e->ope_rr = RC(1.0 + c->e_rr); e->ope_rb = RC(1.0 + c->e_rb);
     e->e_wb = RC(c->e_wall_ball); e->e_wr = RC(c->e_wall_robot); e->beta = RC(c->beta);
@@ -159,9 +161,31 @@ static int SUF(walls)(const SUF(rsxo_env)* e, R r, R rest, R* px, R* py, R* pvx,
             if (ax > xl) { x = sx * xl; if (vx * sx > RC(0)) { vx = -rest * vx; hit |= 1; } }
         } else {
             R yl = e->half_wid - r;
-            if (ay > yl) { y = sy * yl; if (vy * sy > RC(0)) { vy = -rest * vy; hit |= 2; } }
+            if (ay > yl) { y = sy * yl; if (vy * sy > RC(0)) { vy = -rest * vy; hit |= 2; } ay = yl; }
+            /* the goal line's wall exists beside the goal mouth only (|y| >= goal half width) and ends in a goal post (model v2): a
+             * body keeps its radius from the corner (+-L/2, +-goal half width) — along the CHORD of that arc: with u, v the centre's
+             * distances to the goal line and to the mouth's edge (both positive in the corner region), u + v >= r, i.e.
+             * |x| + |y| <= (L/2 + goal half width) - r.  The chord joins the goal line's limit (u = r at v = 0) to the goal's side-wall
+             * limit (v = r at u = 0), so the limits are continuous all the way round; a body cuts the corner by at most 0.29 r.
+             * (v1 clamped x to the goal line's limit for |y| > goal half width - r: a body that slid along the mouth's edge into that
+             * strip was thrown up to a radius sideways, into whatever stood there — the 3 cm overlaps of the VSS scrum.)  Pushed out
+             * along the chord's normal (1, 1) / sqrt 2, folded into the first quadrant; the velocity component along it is reflected. */
             R xl = e->half_len - r;
-            if (ax > xl && ay > e->ghw - r) { x = sx * xl; if (vx * sx > RC(0)) { vx = -rest * vx; hit |= 1; } }
+            if (ay >= e->ghw) {
+                if (ax > xl) { x = sx * xl; if (vx * sx > RC(0)) { vx = -rest * vx; hit |= 1; } }
+            } else {
+                R cl = (e->half_len + e->ghw) - r, sa = ax + ay;
+                if (sa > cl) {
+                    R hf = RC(0.5) * (sa - cl);
+                    x = sx * (ax - hf); y = sy * (ay - hf);
+                    R vn = R_FMA(vx, sx, vy * sy);     /* sqrt 2 x the speed along the normal; > 0: moving into the post */
+                    if (vn > RC(0)) {
+                        R dv = ((RC(1) + rest) * RC(0.5)) * vn;
+                        vx = R_FMA(-sx, dv, vx); vy = R_FMA(-sy, dv, vy);
+                        hit |= 4;
+                    }
+                }
+            }
         }
     } else {
         R yl = (e->half_wid + e->margin) - r;
@@ -322,6 +346,31 @@ static inline int SUF(wall_shares)(const SUF(rsxo_env)* e, R xa, R ya, R xp, R y
     return abx | aby | pbx | pby;
 }
 
+/* Model v2 (VSS): the same idea without probes or directions.  A robot is HELD on an axis when its centre lies within 1 mm of where
+ * the wall clamp (walls above, a robot's radius) limits that coordinate:
+ *   y: |y| >= limit - 1 mm, the limit being the touch line's (field) or the goal's side wall's (inside a goal box)
+ *   x: |x| >= limit - 1 mm, the limit being the goal line's wall (beside the goal mouth only) or the goal's back wall (inside a goal box)
+ * (goal posts hold nothing: a robot slides around them).  h = 1 when held, 0 otherwise.  Shares per axis of a robot - robot pair
+ * (a: this body, p: its partner):  1/2 + (h_p - h_a) / 2  ->  held body 0, its free partner 1, otherwise 1/2 each.  (Which way the
+ * contact pushes is not asked: a partner that could push a held robot AWAY from its wall would have to stand between the robot and
+ * the wall, i.e. be held itself — measured: the scrum envelope is the same with and without a direction test.)
+ * Evaluated on the snapshot the sweep reads.  VSS stays at two sweeps (measured sufficient: profiles/r06_jam_vss_model_v2.txt). */
+static inline void SUF(held_axes)(const SUF(rsxo_env)* e, R x, R y, R* hx, R* hy) {
+    const R ax = R_FABS(x), ay = R_FABS(y);
+    const int in_goal = ax > e->half_len;
+    const R yl = (in_goal ? e->ghw : e->half_wid) - e->r_held;
+    const R xl = (in_goal ? e->half_len + e->gd : e->half_len) - e->r_held;
+    *hy = ay >= yl ? RC(1) : RC(0);
+    *hx = (ax >= xl && (in_goal || ay >= e->ghw)) ? RC(1) : RC(0);
+}
+static inline void SUF(held_shares)(const SUF(rsxo_env)* e, R xa, R ya, R xp, R yp, R* wx, R* wy) {
+    R hax, hay, hpx, hpy;
+    SUF(held_axes)(e, xa, ya, &hax, &hay);
+    SUF(held_axes)(e, xp, yp, &hpx, &hpy);
+    *wx = R_FMA(hpx - hax, RC(0.5), RC(0.5));
+    *wy = R_FMA(hpy - hay, RC(0.5), RC(0.5));
+}
+
 typedef struct SUF(kick) { int ovr, okick; R ovx, ovy, ovz; } SUF(kick);
 
 /* One Jacobi sweep: every body sums the responses to its touching partners (index order) from
@@ -347,7 +396,8 @@ static int SUF(contacts)(SUF(rsxo_env)* e, SUF(body)* b, int first, SUF(kick)* K
                     R d = R_SQRT(d2), inv = RC(1) / d;
                     R wsum = R_FMA(b[j].om, e->r_robot, b[i].om * e->r_robot);
                     R wx = e->w_rr, wy = e->w_rr;
-                    if (e->wall_aware && SUF(wall_shares)(e, b[i].x, b[i].y, b[j].x, b[j].y, dx * inv, dy * inv, &wx, &wy)) wallpair = 1;
+                    if (e->wall_aware == 1 && SUF(wall_shares)(e, b[i].x, b[i].y, b[j].x, b[j].y, dx * inv, dy * inv, &wx, &wy)) wallpair = 1;
+                    if (e->wall_aware == 2) SUF(held_shares)(e, b[i].x, b[i].y, b[j].x, b[j].y, &wx, &wy);
                     SUF(respond)(e, dx * inv, dy * inv, e->rs_rr - d, b[j].vx - b[i].vx, b[j].vy - b[i].vy, wsum,
                                  e->ope_rr, e->w_rr, wx, wy, e->kt_rr, e->mu_rr, RC(0), &avx, &avy, &apx, &apy, &aw);
                     if (e->rs_rr - d > e->pen2) any = 1;

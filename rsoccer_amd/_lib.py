@@ -30,7 +30,7 @@ METRIC_NAMES = ("env_steps", "episodes", "goals_for", "goals_against", "return_s
 # every symbol include/rsx.h declares (tests check the library exports each one)
 SYMBOLS = (
     "rsx_abi_version", "rsx_last_error", "rsx_device_count", "rsx_create", "rsx_destroy",
-    "rsx_get_field_params", "rsx_reset", "rsx_step", "rsx_get_state", "rsx_step_state", "rsx_set_state",
+    "rsx_get_field_params", "rsx_reset", "rsx_step", "rsx_get_state", "rsx_step_state", "rsx_wire_buffers", "rsx_step_wire", "rsx_set_state",
     "rsx_get_state_full", "rsx_dev_view_get", "rsx_step_dev", "rsx_step_dev_random", "rsx_step_dev_flip", "rsx_state_buffers",
     "rsx_reset_dev", "rsx_task_attach",
     "rsx_task_view_get", "rsx_task_layout", "rsx_task_placement_cache_stats", "rsx_task_reset", "rsx_task_reset_to", "rsx_task_step",
@@ -88,6 +88,8 @@ def load():
     lib.rsx_task_layout.argtypes = [vp, C.c_char_p, C.c_size_t]
     lib.rsx_task_placement_cache_stats.argtypes = [vp, C.POINTER(C.c_int64), vp]
     lib.rsx_set_state.argtypes = [vp, vp, vp]
+    lib.rsx_wire_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    lib.rsx_step_wire.argtypes = [vp, vp]
     lib.rsx_get_state_full.argtypes = [vp, vp, vp]
     lib.rsx_dev_view_get.argtypes = [vp, C.POINTER(DevView)]
     lib.rsx_step_dev.argtypes = [vp, vp]
@@ -110,7 +112,7 @@ def load():
     lib.rsx_check_finite.argtypes = [vp, C.POINTER(C.c_int64), vp]
     lib.rsx_task_enable_capture.argtypes = [vp, vp]
     lib.rsx_task_tick.argtypes = [vp, C.POINTER(C.c_uint32), vp]
-    if lib.rsx_abi_version() != 5:
+    if lib.rsx_abi_version() != 6:
         raise RsxError("librsx_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -221,6 +223,25 @@ class Sim:
         if rc:
             _chk(rc)
         return out
+
+    def wire_buffers(self):
+        """(cmds, state): numpy views of the handle's pinned wire-format buffers (rsx_wire_buffers; batches of more than 64 envs) —
+        cmds [B, n_robots, cmd_dim] float64 to be filled before ``step_wire()``, state [B, state_dim + 2] float64 (the
+        ``get_state()`` vector + the two internal rows) valid after it.  None for handles without them."""
+        if getattr(self, "_wire", None) is None:
+            c, st = C.c_void_p(), C.c_void_p()
+            if self._lib.rsx_wire_buffers(self._h, C.byref(c), C.byref(st)) != 0:
+                self._wire = False
+            else:
+                nc, ns = self.num_envs * self.n_robots * self.cmd_dim, self.num_envs * (self.state_dim + X_ROWS)
+                cm = np.ctypeslib.as_array(C.cast(c, C.POINTER(C.c_double)), shape=(nc,)).reshape(self.num_envs, self.n_robots, self.cmd_dim)
+                sv = np.ctypeslib.as_array(C.cast(st, C.POINTER(C.c_double)), shape=(ns,)).reshape(self.num_envs, self.state_dim + X_ROWS)
+                self._wire = (cm, sv)
+        return self._wire or None
+
+    def step_wire(self, stream=None):
+        """one step with the commands of ``wire_buffers()[0]``; the new state (all rows) lands in ``wire_buffers()[1]`` (rsx_step_wire)"""
+        _chk(self._lib.rsx_step_wire(self._h, self._stream(stream)))
 
     def get_state(self, stream=None):
         out = np.empty((self.num_envs, self.state_dim), dtype=np.float64)

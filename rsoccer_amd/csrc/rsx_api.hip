@@ -114,6 +114,14 @@ struct rsx_sim {
     float* pin_state = nullptr;
     float* pin_cmds_dev = nullptr;            // the same two buffers as the device sees them (zero-copy path of small batches)
     float* pin_state_dev = nullptr;
+    // batches above RSX_ZERO_COPY_MAX_ENVS: the reference's wire format itself (float64, [B][N*C] commands, [B][state_dim + 2] state) in
+    // pinned host memory; small kernels convert between it and the f32 SoA arrays ON THE DEVICE, reading / writing the pinned buffers
+    // across PCIe — no transposing loop on a CPU thread, no staging copy (rsx_wire_buffers / rsx_step_wire; rsx_step / rsx_get_state
+    // are a memcpy in front of / behind them)
+    double* wire_cmds = nullptr;
+    double* wire_state = nullptr;
+    double* wire_cmds_dev = nullptr;
+    double* wire_state_dev = nullptr;
     bool host_state_valid = false;
     bool host_state_cache = true;
     bool task_ready = false;   // a reset has opened the first episode
@@ -243,6 +251,24 @@ __global__ void reset_dev_kernel(float* __restrict__ st, const float* __restrict
         const size_t r = (size_t)(5 + rs * k);
         st[(r + 0) * S + e] = src[0]; st[(r + 1) * S + e] = src[1]; st[(r + 2) * S + e] = src[2];
     }
+}
+
+// wire format <-> device layout, for the host-format calls of batches too large for the zero-copy path.  One thread per float64 of the
+// wire array (consecutive threads = consecutive addresses of the pinned host buffer: full PCIe packets); the device side of each
+// access is a 4-byte piece of an SoA row (absorbed by the L2).
+//   commands: wire [B][NC] f64 (rsim.py:92-101 / :129-153)  ->  cmds [NC][S] f32
+__global__ void wire_cmds_in_kernel(const double* __restrict__ wire, float* __restrict__ cmds, const unsigned B, const unsigned NC, const unsigned S) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * NC) return;
+    const unsigned e = i / NC, j = i - e * NC;
+    cmds[(size_t)j * S + e] = (float)wire[i];
+}
+//   state: state [rows][S] f32  ->  wire [B][rows] f64 (get_state() layout, Entities/Frame.py:20-47 / :55-92, + the two internal rows)
+__global__ void wire_state_out_kernel(const float* __restrict__ st, double* __restrict__ wire, const unsigned B, const unsigned rows, const unsigned S) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * rows) return;
+    const unsigned e = i / rows, f = i - e * rows;
+    wire[i] = (double)st[(size_t)f * S + e];
 }
 
 template <int KIND, int TASK, int NRS, int MODE>
@@ -420,6 +446,9 @@ void free_all(rsx_sim* h) {
     if (h->pin_cmds) (void)hipHostFree(h->pin_cmds);
     if (h->pin_state) (void)hipHostFree(h->pin_state);
     h->pin_cmds = h->pin_state = nullptr;
+    if (h->wire_cmds) (void)hipHostFree(h->wire_cmds);
+    if (h->wire_state) (void)hipHostFree(h->wire_state);
+    h->wire_cmds = h->wire_state = nullptr;
     if (h->d_state_alt) (void)hipFree(h->d_state_alt);
     h->d_state_alt = nullptr;
     if (h->d_check) (void)hipFree(h->d_check);
@@ -544,6 +573,22 @@ int rsx_create(rsx_sim** out, int kind, int field_type, int n_blue, int n_yellow
     if ((e = hipMemset(h->d_cmds, 0, cbytes)) != hipSuccess) return bail(e, "hipMemset(cmds)");
     if ((e = hipHostMalloc((void**)&h->pin_cmds, cbytes ? cbytes : 4, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc(cmds)");
     if ((e = hipHostMalloc((void**)&h->pin_state, sbytes, hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc(state)");
+    if (num_envs > RSX_ZERO_COPY_MAX_ENVS && !std::getenv("RSX_NO_WIRE_PATH")) {
+        // larger batches: pinned buffers in the wire format, converted on the device (see rsx_sim::wire_cmds)
+        const size_t wc = B * (size_t)h->P.n_robots * h->M.cmd_dim * sizeof(double), ws = B * (size_t)(h->P.state_dim + X_ROWS) * sizeof(double);
+        void *dc = nullptr, *ds = nullptr;
+        if (B * (size_t)(h->P.state_dim + X_ROWS) < ((size_t)1 << 32) &&
+            hipHostMalloc((void**)&h->wire_cmds, wc, hipHostMallocDefault) == hipSuccess &&
+            hipHostMalloc((void**)&h->wire_state, ws, hipHostMallocDefault) == hipSuccess &&
+            hipHostGetDevicePointer(&dc, h->wire_cmds, 0) == hipSuccess && hipHostGetDevicePointer(&ds, h->wire_state, 0) == hipSuccess) {
+            h->wire_cmds_dev = (double*)dc; h->wire_state_dev = (double*)ds;
+        } else {   // no pinned memory to be had, or not addressable by the device: the staging path below still works
+            (void)hipGetLastError();
+            if (h->wire_cmds) (void)hipHostFree(h->wire_cmds);
+            if (h->wire_state) (void)hipHostFree(h->wire_state);
+            h->wire_cmds = h->wire_state = nullptr;
+        }
+    }
     if (num_envs <= RSX_ZERO_COPY_MAX_ENVS && !std::getenv("RSX_NO_ZERO_COPY")) {
         // small batches (the robosim-shaped single-env objects): the raw step reads its commands from, and mirrors the
         // new state into, the pinned host buffers directly — if the device can address them
@@ -598,12 +643,51 @@ int rsx_reset(rsx_sim* h, const double* ball, const double* blue, const double* 
     return upload_state(h, soa, s);
 }
 
+// the wire-format step of a large batch: commands from h->wire_cmds, new state into h->wire_state (when the host copy is trusted)
+static int step_wire_impl(rsx_sim* h, hipStream_t s) {
+    const Params& P = h->P;
+    const unsigned B = (unsigned)P.num_envs, S = (unsigned)P.row_stride, NC = (unsigned)(P.n_robots * h->M.cmd_dim), rows = (unsigned)(P.state_dim + X_ROWS);
+    h->host_state_valid = false;
+    hipLaunchKernelGGL(wire_cmds_in_kernel, dim3((B * NC + 255) / 256), dim3(256), 0, s, h->wire_cmds_dev, h->d_cmds, B, NC, S);
+    launch_sim(h, s);
+    if (h->host_state_cache)
+        hipLaunchKernelGGL(wire_state_out_kernel, dim3((B * rows + 255) / 256), dim3(256), 0, s, h->d_state, h->wire_state_dev, B, rows, S);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    h->host_state_valid = h->host_state_cache;
+    return RSX_OK;
+}
+
+int rsx_wire_buffers(rsx_sim* h, double** cmds, double** state) {
+    if (!h) return fail(RSX_ERR_ARG, "null handle");
+    if (!h->wire_cmds) return fail(RSX_ERR_STATE, "this handle has no wire-format buffers (batches of at most 64 envs step through rsx_step_state without copies)");
+    if (cmds) *cmds = h->wire_cmds;
+    if (state) *state = h->wire_state;
+    return RSX_OK;
+}
+
+int rsx_step_wire(rsx_sim* h, void* stream) {
+    RSX_ENTER(h);
+    if (!h->wire_cmds) return fail(RSX_ERR_STATE, "this handle has no wire-format buffers (rsx_wire_buffers)");
+    if (!h->host_state_cache) {   // a device view was handed out: nothing mirrors the state unasked any more, but this call promises it
+        h->host_state_cache = true;
+        const int rc = step_wire_impl(h, (hipStream_t)stream);
+        h->host_state_cache = false; h->host_state_valid = false;
+        return rc;
+    }
+    return step_wire_impl(h, (hipStream_t)stream);
+}
+
 int rsx_step(rsx_sim* h, const double* cmds, void* stream) {
     RSX_ENTER(h);
     if (!cmds) return fail(RSX_ERR_ARG, "cmds is null");
     hipStream_t s = (hipStream_t)stream;
     const Params& P = h->P;
     const size_t B = (size_t)P.num_envs, S = (size_t)P.row_stride, NC = (size_t)P.n_robots * h->M.cmd_dim;
+    if (h->wire_cmds) {   // large batch: one contiguous copy into the pinned wire buffer, the conversion runs on the device
+        if (cmds != h->wire_cmds) std::memcpy(h->wire_cmds, cmds, B * NC * sizeof(double));
+        return step_wire_impl(h, s);
+    }
     for (size_t e = 0; e < B; ++e)
         for (size_t j = 0; j < NC; ++j) h->pin_cmds[j * S + e] = (float)cmds[e * NC + j];
     h->host_state_valid = false;
@@ -624,6 +708,19 @@ int rsx_step(rsx_sim* h, const double* cmds, void* stream) {
 
 static int get_state_impl(rsx_sim* h, double* out, int rows, hipStream_t s) {
     const size_t B = (size_t)h->P.num_envs, S = (size_t)h->P.row_stride;
+    if (h->wire_state) {   // large batch: the wire-format copy is made on the device; what is left is a copy out of pinned memory
+        const int all = h->P.state_dim + X_ROWS;
+        if (!h->host_state_valid) {
+            hipLaunchKernelGGL(wire_state_out_kernel, dim3(((unsigned)B * all + 255) / 256), dim3(256), 0, s, h->d_state, h->wire_state_dev, (unsigned)B, (unsigned)all, (unsigned)S);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(s));
+            h->host_state_valid = h->host_state_cache;
+        }
+        if (out == h->wire_state) return RSX_OK;
+        if (rows == all) std::memcpy(out, h->wire_state, B * (size_t)all * sizeof(double));
+        else for (size_t e = 0; e < B; ++e) std::memcpy(out + e * rows, h->wire_state + e * all, (size_t)rows * sizeof(double));
+        return RSX_OK;
+    }
     if (!h->host_state_valid) {
         HIP_TRY(hipMemcpyAsync(h->pin_state, h->d_state, (size_t)(h->P.state_dim + X_ROWS) * S * sizeof(float), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
@@ -986,7 +1083,7 @@ namespace {
 struct CkptHeader {
     uint64_t magic;            // "RSXCKPT2"
     int32_t abi, kind, field_rows, task, n_blue, n_yellow, num_envs, state_rows, aux_rows, obs_dim;
-    int32_t field_type, time_step_ms, max_steps, reserved;
+    int32_t field_type, time_step_ms, max_steps, model;   // model: RSX_PHYSICS_MODEL of the saving library
     uint32_t key0, key1, env_id_base, tick;
     uint64_t state_bytes, aux_bytes, obs_bytes, flag_bytes;
     int64_t metrics[RSX_METRICS];
@@ -998,7 +1095,7 @@ CkptHeader ckpt_header(const rsx_sim* h) {
     k.magic = CKPT_MAGIC; k.abi = RSX_ABI_VERSION; k.kind = h->P.kind; k.field_rows = h->M.rs; k.task = h->P.task;
     k.n_blue = h->P.n_blue; k.n_yellow = h->P.n_yellow; k.num_envs = h->P.num_envs;
     k.state_rows = h->P.state_dim + X_ROWS; k.aux_rows = aux_rows(h->P.n_robots); k.obs_dim = h->P.obs_dim;
-    k.field_type = h->field_type; k.time_step_ms = h->time_step_ms; k.max_steps = h->P.max_steps; k.reserved = 0;
+    k.field_type = h->field_type; k.time_step_ms = h->time_step_ms; k.max_steps = h->P.max_steps; k.model = RSX_PHYSICS_MODEL;
     k.key0 = h->P.key0; k.key1 = h->P.key1; k.env_id_base = h->P.env_id_base; k.tick = h->tick;
     k.state_bytes = (uint64_t)k.state_rows * B * sizeof(float);
     k.aux_bytes = (uint64_t)k.aux_rows * B * sizeof(float);
@@ -1066,6 +1163,7 @@ int rsx_task_checkpoint_load(rsx_sim* h, const void* blob, size_t bytes, void* s
     std::memcpy(&k, blob, sizeof(k));
     CkptHeader want = ckpt_header(h);
     if (k.magic != CKPT_MAGIC || k.abi != want.abi) return fail(RSX_ERR_ARG, "not a checkpoint of this library version");
+    if (k.model != want.model) return fail(RSX_ERR_ARG, "the checkpoint was taken under another version of the physics model (RSX_PHYSICS_MODEL)");
     if (k.kind != want.kind || k.task != want.task || k.n_blue != want.n_blue || k.n_yellow != want.n_yellow ||
         k.num_envs != want.num_envs || k.state_rows != want.state_rows || k.aux_rows != want.aux_rows || k.obs_dim != want.obs_dim)
         return fail(RSX_ERR_ARG, "the checkpoint was taken from a different configuration (simulator kind, team sizes, batch or task)");

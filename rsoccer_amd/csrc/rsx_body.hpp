@@ -31,25 +31,58 @@ struct Body {
 
 
 // clamp a circle (radius r, restitution rest) into the playable region
-template <int KIND>
+// VSS goal post (model v2), the response: a body inside the chord of a post's arc (|x| + |y| > (L/2 + goal half width) - r in the corner
+// region: walls<VSS> below has the gate) is pushed out along the chord's normal (1, 1) / sqrt 2, folded into the first quadrant, and the
+// velocity component along it is reflected.  Called under the gate (per lane).
+__device__ __forceinline__ void post_response(const Params& P, const float r, const float rest, float& x, float& y, float& vx, float& vy, int& hit) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float sx = signf(x), sy = signf(y);
+    const float hf = 0.5f * ((ax + ay) - ((P.half_len + P.ghw) - r));
+    x = sx * (ax - hf); y = sy * (ay - hf);
+    const float vn = fma_(vx, sx, vy * sy);   // sqrt 2 x the speed along the normal; > 0: moving into the post
+    if (vn > 0.0f) {
+        const float dv = ((1.0f + rest) * 0.5f) * vn;
+        vx = fma_(-sx, dv, vx); vy = fma_(-sy, dv, vy);
+        hit |= 4;
+    }
+}
+
+// DEFER_POST (VSS): the goal-post response is left to the caller (post_response below), who merges its rare branch with one it has
+// anyway; bit 3 of `hit` then says "this body is inside a post's chord".
+template <int KIND, bool DEFER_POST = false>
 __device__ __forceinline__ void walls(const Params& P, const float r, const float rest, float& x,
-                                      float& y, float& vx, float& vy, int& hit /* bit 0: vx reflected, bit 1: vy */) {
+                                      float& y, float& vx, float& vy, int& hit /* bit 0: vx reflected, bit 1: vy, bit 2: off a post */) {
     using K = KC<KIND>;
     float ax = fabsf(x), ay = fabsf(y);
     const float sx = signf(x), sy = signf(y);  // only read when |x| (|y|) exceeds a positive limit
     if (KIND == RSX_KIND_VSS) {
         // predicated form of: inside a goal box (|x| > L/2) the limits are the goal's side and
-        // back walls, otherwise the touch line and - outside the goal mouth - the goal line
+        // back walls, otherwise the touch line and - beside the goal mouth (|y| >= goal half width) - the goal line
         const bool in_goal = ax > P.half_len;
         const float yl = (in_goal ? P.ghw : P.half_wid) - r;
         const float xl = (in_goal ? P.half_len + P.gd : P.half_len) - r;
         const bool hy = ay > yl;
-        const bool hx = (ax > xl) & (in_goal | (ay > P.ghw - r));
-        const float ny = sy * yl, nx = sx * xl;
+        const bool faced = in_goal | (ay >= P.ghw);   // a wall faces the body on the x axis: the goal's back wall, or the goal line's beside the mouth
+        const bool hx = (ax > xl) & faced;
         const bool fy = hy & (vy * sy > 0.0f), fx = hx & (vx * sx > 0.0f);
-        y = hy ? ny : y; vy = fy ? -rest * vy : vy;
-        x = hx ? nx : x; vx = fx ? -rest * vx : vx;
+        y = hy ? sy * yl : y; vy = fy ? -rest * vy : vy;
+        x = hx ? sx * xl : x; vx = fx ? -rest * vx : vx;
         hit = (fx ? 1 : 0) | (fy ? 2 : 0);
+        // goal posts (model v2): the goal line's wall ends at the mouth in a corner (+-L/2, +-goal half width) that a body keeps its radius
+        // from — along the CHORD of that arc: with u, v the centre's distances to the goal line and to the mouth's edge, u + v >= r, i.e.
+        // |x| + |y| <= (L/2 + goal half width) - r.  The chord joins the goal line's limit to the goal's side-wall limit, so the limits
+        // are continuous all the way round (a body cuts the corner by at most 0.29 r); no square root, no division.  (v1 clamped x for
+        // |y| > goal half width - r: a body sliding along the mouth's edge into that strip was thrown up to a radius sideways into whatever
+        // stood there — the 3 cm overlaps of the VSS scrum.)  Robots rest against posts a lot (the scrum of a goal mouth) and a lone wave
+        // pays ~6 cycles for every instruction it issues: the gate is one add and one compare next to the clamp's own, the response is
+        // short and behind a wave-uniform branch.  Pushed out along the chord's normal (1, 1) / sqrt 2, folded into the first quadrant.
+        const float cl = (P.half_len + P.ghw) - r;
+        const float sa = ax + ay;
+        const bool inp = !faced & (sa > cl);
+        if (DEFER_POST) { hit |= inp ? 8 : 0; }
+        else if (__builtin_expect(__any(inp), 0)) {
+            if (inp) post_response(P, r, rest, x, y, vx, vy, hit);
+        }
     } else {
         // predicated like the VSS clamp: conditional stores to x / y / vx / vy inside nested
         // branches get merged by the compiler into stores through a selected POINTER, which
@@ -185,6 +218,30 @@ __device__ __forceinline__ bool wall_shares(const Params& P, const float xa, con
     return (int32_t)((abx | aby) | (pbx | pby)) < 0;
 }
 
+// Model v2, VSS: the same idea without probes or directions (the 1.5 m x 1.3 m field puts a wall pair into the slowest wave of nearly every
+// launch: what this costs per touching partner sets the headline step).  A robot is HELD on an axis when its centre lies within 1 mm of
+// where the wall clamp (walls<VSS>, a robot's radius) limits that coordinate:
+//   y: |y| >= limit - 1 mm — the touch line's limit in the field, the goal's side wall's inside a goal box
+//   x: |x| >= limit - 1 mm — the goal line's wall (beside the goal mouth only) in the field, the goal's back wall inside a goal box
+// (goal posts hold nothing: a robot slides around them).  h = 1 when held, 0 otherwise.  Shares per axis of a robot - robot pair (a: this
+// body, p: its partner): 1/2 + (h_p - h_a) / 2 -> held body 0, its free partner 1, otherwise 1/2 each.  (Which way the contact pushes
+// is not asked: a partner that could push a held robot AWAY from its wall would have to stand between the robot and the wall, i.e. be
+// held itself.)  Evaluated on the snapshot the sweep reads.  `robot`: the ball and idle lanes publish (0, 0).
+template <int KIND>
+__device__ __forceinline__ float2 held_axes(const Params& P, const float x, const float y, const bool robot = true) {
+    using K = KC<KIND>;
+    const float ax = fabsf(x), ay = fabsf(y);
+    const bool in_goal = ax > P.half_len;
+    // (the same numbers as `(in_goal ? a : b) - r_held`; written as a choice between two differences they are loop invariants of the caller)
+    const float yl = in_goal ? P.ghw - K::r_held : P.half_wid - K::r_held;
+    const float xl = in_goal ? (P.half_len + P.gd) - K::r_held : P.half_len - K::r_held;
+    const bool hy = robot & (ay >= yl);
+    const bool hx = robot & (ax >= xl) & (in_goal | (ay >= P.ghw));
+    return make_float2(hx ? 1.0f : 0.0f, hy ? 1.0f : 0.0f);
+}
+// the share differences of a pair from a's point of view, (h_p - h_a) per axis; from p's point of view they are the exact negatives
+__device__ __forceinline__ float2 held_diff(const float2 ha, const float2 hp) { return make_float2(hp.x - ha.x, hp.y - ha.y); }
+
 // A bounce of the BALL off a wall with Coulomb friction at the contact point: couples the velocity
 // component along the wall with the spin about the vertical axis.  (vx0, vy0) = velocity before
 // walls(): the ball moved INTO the wall, so its sign names the wall's side.
@@ -298,10 +355,19 @@ __device__ __forceinline__ void contact_response(const Params& P, const Body& o,
                                                  const float kt, const float mu, const float spin_c,
                                                  const float wsum, const float beta, const float pen2, const bool rr, const bool v2w,
                                                  float& avx, float& avy, float& apx, float& apy, float& aw,
-                                                 bool& deep, bool& wallp) {
+                                                 bool& deep, bool& wallp, const float2 fo = float2{0.0f, 0.0f}, const float2 fj = float2{0.0f, 0.0f}) {
     float dx = oj.x - o.x, dy = oj.y - o.y;
     float d = sqrtf(d2), inv = 1.0f / d;
     const float nx = dx * inv, ny = dy * inv;
+    if constexpr (KC<KIND>::held) {
+        // VSS: per-axis shares from the held axes of the two bodies (fo: this body's, fj: the partner's, both of this sweep's snapshot);
+        // a pair with the ball keeps w on both axes (fma(d, 0, w) == w)
+        const float2 hd = held_diff(fo, fj);
+        const float hr = rr ? 0.5f : 0.0f;
+        respond_axes(nx, ny, rs - d, oj.z - o.vx, oj.w - o.vy, wsum, ope, w, fma_(hd.x, hr, w), fma_(hd.y, hr, w), kt, mu, spin_c, beta, avx, avy, apx, apy, aw);
+        deep |= rs - d > pen2;
+        return;
+    }
     // the hot path is v1's: only a pair with a body within 2 mm of where the wall clamp acts (at_wall: 3 instructions per partner)
     // evaluates the probes — rare, laid out away from the loop
     if (KC<KIND>::wall_aware && __builtin_expect(v2w, 0)) {
@@ -336,14 +402,20 @@ __device__ __forceinline__ void contact_pair(const Params& P, const Body& bi, co
     const float nx = dx * inv, ny = dy * inv, pen = rs - d;           // n: i -> j
     const float dvx = bj.vx - bi.vx, dvy = bj.vy - bi.vy;
     const float vn = fma_(dvx, nx, dvy * ny);
-    if (KC<KIND>::wall_aware && __builtin_expect(v2w, 0)) {   // (wave-uniform: see contact_response)
-        // model v2, some robot of the wave at a wall: per-axis shares (respond_axes from either side; a pair's shares add up to 1 per axis)
+    if (KC<KIND>::held || (KC<KIND>::wall_aware && __builtin_expect(v2w, 0))) {   // (SSL: wave-uniform, see contact_response)
+        // model v2: per-axis shares (respond_axes from either side; a pair's shares add up to 1 per axis)
         float wxi = w_i, wyi = w_i, wxj = w_j, wyj = w_j;
-        if constexpr (KC<KIND>::wall_aware) {
+        if constexpr (KC<KIND>::wall_aware) {   // SSL: some robot of the wave at a wall
             if (rr && (at_wall<KIND>(P, bi.x, bi.y) | at_wall<KIND>(P, bj.x, bj.y))) {
                 wallp |= wall_shares<KIND>(P, bi.x, bi.y, bj.x, bj.y, nx, ny, wxi, wyi);
                 wxj = 1.0f - wxi; wyj = 1.0f - wyi;   // {0, 1/2, 1} -> {1, 1/2, 0}: exact
             }
+        }
+        if constexpr (KC<KIND>::held) {         // VSS: held axes of the two bodies, from the positions this sweep reads (a pair with the ball: w)
+            const float2 hd = held_diff(held_axes<KIND>(P, bi.x, bi.y), held_axes<KIND>(P, bj.x, bj.y));
+            const float hr = rr ? 0.5f : 0.0f;
+            wxi = fma_(hd.x, hr, w_i); wyi = fma_(hd.y, hr, w_i);
+            wxj = fma_(-hd.x, hr, w_j); wyj = fma_(-hd.y, hr, w_j);
         }
         if (vn < 0.0f) {
             const float vt0 = fma_(dvy, nx, -(dvx * ny));

@@ -39,6 +39,7 @@
 //     run-time block `Params` and 8 base pointers live in SGPRs.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "rsx_math.hpp"
 #include "rsx_params.hpp"
@@ -91,6 +92,7 @@ struct Shared {
     float4 Cq[64];  // SSL robot -> ball record 1: flags, ovx, ovy, ovz
     float Dq[64];   // SSL robot -> ball record 2: spin change of the ball
     float W[64];    // robots: yaw rate, ball: spin (rad/s) — read on the contact path only
+    float2 F[64];   // VSS: held axes of the body in this sweep's snapshot (rsx_body.hpp: held_axes) — read on the contact path only
 #if RSX_PK_SWEEP
     alignas(16) float X[64], Y[64];   // positions once more, [env slot][body]: four partners per 16-byte read for the packed overlap test
 #endif
@@ -162,7 +164,7 @@ __device__ __forceinline__ unsigned long long env_lane_mask(const int g) {
 // kernels and second sweep (rare) of all VSS kernels.  Returns whether some pair was deep.
 template <int KIND, int L>
 __device__ __forceinline__ bool vss_sweep_loop(const Params& P, Body& o, const int N, const int g, const bool is_ball,
-                                               const bool ball_low, const Shared<L>& sh, bool& wallp) {
+                                               const bool ball_low, const Shared<L>& sh, bool& wallp, const float2 fo) {
     using K = KC<KIND>;
     constexpr int G = 64 / L;
     constexpr uint32_t T_RR = __builtin_bit_cast(uint32_t, K::rs_rr2) - 1u;
@@ -187,13 +189,14 @@ __device__ __forceinline__ bool vss_sweep_loop(const Params& P, Body& o, const i
         todo &= todo - 1;
         const float4 oj = sh.A[LaneMap<L>::slot(j, g)];
         const float wj = sh.W[LaneMap<L>::slot(j, g)];
+        const float2 fj = sh.F[LaneMap<L>::slot(j, g)];
         const float dx = oj.x - o.x, dy = oj.y - o.y;
         const bool rb = is_ball || j == N;
         contact_response<KIND>(P, snap, oj, fma_(dx, dx, dy * dy), rb ? K::rs_rb : K::rs_rr, rb ? K::ope_rb : K::ope_rr,
                          is_ball ? K::w_rb_b : (j == N ? K::w_rb_r : K::w_rr),
                          is_ball ? K::kt_rb_b : (j == N ? K::kt_rb_r : K::kt_rr), rb ? K::mu_rb : K::mu_rr,
                          is_ball ? K::spin_c : 0.0f, fma_(wj, j == N ? K::r_ball : K::r_robot, snap.om * lever),
-                         K::beta, K::pen2, !rb, v2w, avx, avy, apx, apy, aw, deep, wallp);
+                         K::beta, K::pen2, !rb, v2w, avx, avy, apx, apy, aw, deep, wallp, fo, fj);
     }
     // only a body that touched something is updated (the others keep their bits)
     o.vx = o.vx + avx; o.vy = o.vy + avy;
@@ -207,8 +210,11 @@ __device__ __forceinline__ bool vss_sweep_loop(const Params& P, Body& o, const i
 // (v_pk_add / v_pk_mul / v_pk_fma are IEEE per component: the same bits as the scalar form), positions from the
 // [env][body] copies in LDS (one 16-byte read = four partners).
 #if RSX_PK_SWEEP
-template <int SLOTS, int L>
-__device__ __forceinline__ void overlap_keys_packed(const Shared<L>& sh, const int g, const float ox, const float oy, uint32_t* u) {
+struct NoFill { __device__ __forceinline__ void operator()() const {} };
+// `fill`: work that does not depend on the partners' positions, issued between the LDS reads and their first use (the reads take
+// ~100 cycles to come back and a lone wave has nothing else to run meanwhile)
+template <int SLOTS, int L, typename FILL = NoFill>
+__device__ __forceinline__ void overlap_keys_packed(const Shared<L>& sh, const int g, const float ox, const float oy, uint32_t* u, FILL fill = FILL{}) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef float f4 __attribute__((ext_vector_type(4)));
     constexpr int Q = (SLOTS + 3) / 4;
@@ -217,6 +223,7 @@ __device__ __forceinline__ void overlap_keys_packed(const Shared<L>& sh, const i
     f4 xs[Q], ys[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) { xs[q] = X4[q]; ys[q] = Y4[q]; }
+    fill();   // (in program order behind the reads; a sched_barrier here keeps the compiler from peeling the sweep loop and costs scratch)
     const f2 ox2 = {ox, ox}, oy2 = {oy, oy};
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
@@ -469,6 +476,7 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
         bool active = is_robot || is_ball;   // lanes whose env takes part in the current sweep
         BallOverride bo{false, false, 0.0f, 0.0f, 0.0f};
         for (int sweep = 0;; ++sweep) {
+            float2 fo = float2{0.0f, 0.0f};   // VSS: this body's held axes in the snapshot of this sweep (robots; the ball publishes zeros)
             if (active) {
                 sh.A[lane] = make_float4(o.x, o.y, o.vx, o.vy);
                 sh.W[lane] = o.om;   // yaw rate / spin: read on the contact path only
@@ -477,6 +485,14 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
 #endif
             }
             wave_sync();
+            // VSS: the held axes of this snapshot are computed and published BEHIND the exchange — the arithmetic fills the wait for the
+            // partners' positions (overlap_keys_packed: `fill`).  Read on the contact path only; no second exchange point is needed: a
+            // wave's LDS accesses execute in issue order, and the compiler keeps this write ahead of the later reads of the same array
+            // (they may alias).  (A wave_sync() at the head of the contact branch was measured: it pins the body's position in scratch
+            // memory, 8.9 -> 12.8 us.)
+            auto publish_held = [&]() {
+                if constexpr (K::held) { fo = held_axes<KIND>(P, o.x, o.y, is_robot); sh.F[lane] = fo; }
+            };
 #if !RSX_ZB_BALLOT
             if (sweep == 0) ball_low = sh.zb[g] < K::robot_h;
 #endif
@@ -502,7 +518,8 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                         constexpr uint32_t T_RB = __builtin_bit_cast(uint32_t, K::rs_rb2) - 1u;
                         uint32_t u[NR + 1];
 #if RSX_PK_SWEEP
-                        overlap_keys_packed<NR + 1, L>(sh, g, o.x, o.y, u);
+                        if constexpr (K::held) overlap_keys_packed<NR + 1, L>(sh, g, o.x, o.y, u, publish_held);
+                        else overlap_keys_packed<NR + 1, L>(sh, g, o.x, o.y, u);
 #else
 #pragma unroll
                         for (int j = 0; j <= NR; ++j) {
@@ -541,16 +558,19 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                             todo &= todo - 1;
                             float4 nxt = sh.A[LaneMap<L>::slot(jn, g)];
                             float nxw = sh.W[LaneMap<L>::slot(jn, g)];
+                            float2 nxf = sh.F[LaneMap<L>::slot(jn, g)];
                             for (;;) {
                                 const int j = jn;
                                 const float4 oj = nxt;
                                 const float wj = nxw;
+                                const float2 fj = nxf;
                                 const bool more = todo != 0;
                                 if (more) {
                                     jn = __builtin_ctz(todo);
                                     todo &= todo - 1;
                                     nxt = sh.A[LaneMap<L>::slot(jn, g)];
                                     nxw = sh.W[LaneMap<L>::slot(jn, g)];
+                                    nxf = sh.F[LaneMap<L>::slot(jn, g)];
                                 }
                                 const float dx = oj.x - o.x, dy = oj.y - o.y;
                                 const float d2 = fma_(dx, dx, dy * dy);   // the value the sweep above saw
@@ -560,7 +580,7 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                                                        is_ball ? K::kt_rb_b : (j == NR ? K::kt_rb_r : K::kt_rr),
                                                        rb ? K::mu_rb : K::mu_rr, is_ball ? K::spin_c : 0.0f,
                                                        fma_(wj, j == NR ? K::r_ball : K::r_robot, o.om * lever), K::beta, K::pen2, !rb, v2w,
-                                                       avx, avy, apx, apy, aw, deep, wallp);
+                                                       avx, avy, apx, apy, aw, deep, wallp, fo, fj);
                                 if (!more) break;
                             }
                             // only a body that touched something is updated (the others keep their bits)
@@ -569,7 +589,8 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                             if (is_ball) o.om = o.om + aw;
                         }
                     } else {
-                        deep = vss_sweep_loop<KIND, L>(P, o, N, g, is_ball, ball_low, sh, wallp);
+                        publish_held();
+                        deep = vss_sweep_loop<KIND, L>(P, o, N, g, is_ball, ball_low, sh, wallp, fo);
                     }
                 }
             } else {
@@ -607,8 +628,19 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
         if (KIND == RSX_KIND_SSL ? __any(near_walls<KIND>(P, o.x, o.y)) : (is_robot || is_ball)) {
             const float vx0 = o.vx, vy0 = o.vy;
             int hit = 0;
+            if constexpr (KIND == RSX_KIND_VSS) {
+                // the goal-post response shares the rare branch of the ball's wall friction (one exec-mask branch at the end of every
+                // sub-step instead of two: a lone wave pays for each one's compare -> scalar -> branch chain)
+                const float rb = is_ball ? K::r_ball : K::r_robot, eb = is_ball ? K::e_wb : K::e_wr;
+                walls<KIND, true>(P, rb, eb, o.x, o.y, o.vx, o.vy, hit);
+                if (RSX_RARE_B(KIND, 2, (is_ball && (hit & 3)) || (hit & 8))) {
+                    if (hit & 8) post_response(P, rb, eb, o.x, o.y, o.vx, o.vy, hit);
+                    if (is_ball && (hit & 3)) ball_wall_spin<KIND>(hit, vx0, vy0, o.vx, o.vy, o.om);
+                }
+            } else {
             walls<KIND>(P, is_ball ? K::r_ball : K::r_robot, is_ball ? K::e_wb : K::e_wr, o.x, o.y, o.vx, o.vy, hit);
             if (RSX_RARE_B(KIND, 2, is_ball && hit)) ball_wall_spin<KIND>(hit, vx0, vy0, o.vx, o.vy, o.om);
+            }
         }
         wave_sync();  // A / W / Bq / Cq / Dq are rewritten by the next sub-step
 #ifdef RSX_TIMING

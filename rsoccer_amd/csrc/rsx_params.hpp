@@ -77,13 +77,12 @@ struct KC {
     static constexpr float rs_rb2 = (float)((D::r_robot + D::r_ball) * (D::r_robot + D::r_ball));
     static constexpr double imr = 1.0 / D::m_robot, imb = 1.0 / D::m_ball;
     static constexpr float w_rr = 0.5f;
-    // model v2 (rsx_body.hpp: wall_shares): robot - robot pairs at a wall get per-axis shares and piles at a wall a third and
-    // fourth sweep.  SSL only [build]: DESIGN.md 4 has the VSS numbers (the headline kernel's slowest wave would pay 35 % for it)
-#ifdef RSX_V2_NO_SHARES
-    static constexpr bool wall_aware = false;   // development A/B
-#else
+    // model v2 [build], DESIGN.md 4: robot - robot pairs at a wall get per-axis shares.  SSL (rsx_body.hpp: wall_shares): blocked axes
+    // found by probing, piles at a wall get a third and a fourth sweep.  VSS (rsx_body.hpp: held_axes): a robot within 1 mm of where the
+    // wall clamp limits a coordinate is held on that axis; two sweeps.
     static constexpr bool wall_aware = KIND == RSX_KIND_SSL;
-#endif
+    static constexpr bool held = KIND == RSX_KIND_VSS;
+    static constexpr float r_held = (float)(D::r_robot + 0.001);
     static constexpr float w_rb_r = (float)(imr / (imr + imb)), w_rb_b = (float)(imb / (imr + imb));
     static constexpr float ope_rr = (float)(1.0 + D::e_rr), ope_rb = (float)(1.0 + D::e_rb);
     static constexpr float e_wb = (float)D::e_wb, e_wr = (float)D::e_wr, beta = (float)BETA_D;

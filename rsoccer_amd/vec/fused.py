@@ -9,6 +9,13 @@ _SD_INFO = ("goal", "rbt_in_gk_area", "done_ball_out", "done_ball_out_right", "d
             "ball_dist", "ball_grad", "energy")
 
 
+def batched_space(single, n):
+    """the space of ``n`` copies of ``single`` (a Box), as ``gymnasium.vector`` describes a vector env: shape ``(n,) + single.shape``"""
+    low = np.broadcast_to(single.low, (n,) + tuple(single.shape)).copy()
+    high = np.broadcast_to(single.high, (n,) + tuple(single.shape)).copy()
+    return gym.spaces.Box(low=low, high=high, shape=(n,) + tuple(single.shape), dtype=single.dtype)
+
+
 class VecFusedEnv:
     """``num_envs`` copies of a fused task on one GPU.
 
@@ -48,7 +55,9 @@ class VecFusedEnv:
         self.field = self.sim.get_field_params()
         self.single_action_space = gym.spaces.Box(low=-1, high=1, shape=(self.sim.act_dim,), dtype=np.float32)
         self.single_observation_space = gym.spaces.Box(low=-1.2, high=1.2, shape=(self.sim.obs_dim,), dtype=np.float32)
-        self.action_space, self.observation_space = self.single_action_space, self.single_observation_space
+        # gymnasium.vector convention: action_space / observation_space describe the batch, single_* one env
+        self.action_space = batched_space(self.single_action_space, self.num_envs)
+        self.observation_space = batched_space(self.single_observation_space, self.num_envs)
 
     # ---- gym-like surface ----
     def _stream(self):

@@ -121,6 +121,9 @@ class VecScalarHookEnv:
         self.envs = [env_cls(sim_backend=backend, **env_kwargs) for _ in range(self.num_envs)]
         self.single_observation_space = self.envs[0].observation_space
         self.single_action_space = self.envs[0].action_space
+        from rsoccer_amd.vec.fused import batched_space
+        self.observation_space = batched_space(self.single_observation_space, self.num_envs)
+        self.action_space = batched_space(self.single_action_space, self.num_envs)
         self.field = Field(**self.pool.field)
         self.elapsed = np.zeros(self.num_envs, dtype=np.int64)
 

@@ -33,7 +33,7 @@ def test_header_and_binding_list_the_same_symbols():
 def test_library_exports_every_declared_symbol(lib):
     for name in _declared():
         assert hasattr(lib, name), f"librsx_hip.so does not export {name}"
-    assert lib.rsx_abi_version() == 5
+    assert lib.rsx_abi_version() == 6
 
 
 def test_header_cites_the_reference_interface():

@@ -129,3 +129,44 @@ def test_bench_two_ranks_equal_one_handle():
     m = _single_handle_metrics(2 * B, K, W)
     assert line["env_steps_counted"] == int(m[0]) == 2 * B * (K + W)
     assert line["episodes"] == int(m[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fail", [None, "3"], ids=["rccl-or-gloo", "rank-3-fails-rccl"])
+def test_bench_eight_rank_rehearsal_with_the_drivers_flags(fail):
+    """BASELINE.json configs[4] — VSS-v0 3v3, 32 768 envs as 8 x 4096 — launched exactly as the driver does at round end
+    (`python bench.py --gpus 8 --steps 20 --warmup 5`), rehearsed on ONE device (RSX_BENCH_SHARE_DEVICE=1: eight processes, eight
+    handles, the 64-byte metrics exchange over gloo) so that its first meeting with an 8-GPU node cannot die on plumbing: eight torch
+    imports, the rendezvous, the RCCL probe with its watchdog, per-rank diagnostics, the 20-launch timed region, one JSON line.  The
+    population is the one a single 32 768-env handle holds (envs are keyed by global env id: one simulator per env,
+    rsoccer_gym/vss/vss_gym_base.py:40): env-steps and episodes counted on the devices and all-reduced must equal that handle's.
+    Second case: rank 3's RCCL probe is made to fail — every rank must agree on gloo and the line must still print."""
+    import time
+    import torch
+    env = {"RSX_BENCH_SHARE_DEVICE": "1"} if torch.cuda.device_count() < 8 else {}
+    args = ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    if fail is not None:
+        args += ["--simulate-rccl-failure", fail, "--rccl-timeout", "30"]
+    t0 = time.perf_counter()
+    res, line = _run(args, env=env, timeout=600)
+    wall = time.perf_counter() - t0
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert sum(ln.startswith("{") for ln in res.stdout.splitlines()) == 1
+    assert wall < 120, wall
+    assert line["n_gpus"] == 8 and line["steps"] == 20 and line["warmup"] == 5 and line["scaling"] == "weak"
+    c = line["collective"]
+    assert c["ranks"] == 8 and len(c["per_rank_ms_per_step"]) == 8 and len(c["devices"]) == 8
+    if fail is not None or env:
+        assert c["backend"].startswith("gloo") and c["rccl_ranks"] == 0
+    else:
+        assert c["backend"] == "rccl" and c["rccl_ranks"] == 8
+    assert line["config"]["envs_per_gpu"] == 4096 if "envs_per_gpu" in line["config"] else True
+    assert abs(line["value"] - 8 * 4096 * 20 / (line["ms_per_step"] * 1e-3 * 20)) < 1e-6 * line["value"]
+    for r in range(8):
+        assert f"[bench rank {r}/8" in res.stderr
+    counted = line["env_steps_counted"]
+    assert counted % (8 * 4096) == 0
+    steps_taken = counted // (8 * 4096)                      # warm-up + timed region + whatever legs every rank ran besides
+    assert steps_taken >= 25
+    m = _single_handle_metrics(8 * 4096, steps_taken, 0)
+    assert counted == int(m[0]) and line["episodes"] == int(m[1])

@@ -375,6 +375,80 @@ def test_crowded_11v11_full_size_contact_invariants():
     sim.close()
 
 
+def _vss_scrum(L, ft, nb, B, steps, seed):
+    """every robot of a VSS field drives at the ball (proportional heading control on the wheel commands, a little steering noise);
+    returns the deepest robot-robot overlap of every env after every step and the final full state"""
+    import torch
+    N = 2 * nb
+    sim = L.Sim(0, ft, nb, nb, 25, B)
+    f = sim.get_field_params()
+    rng = np.random.default_rng(seed)
+    cols = (N + 1) // 2
+    pose = np.zeros((B, N, 3))
+    k = np.arange(N)
+    pose[:, :, 0] = ((k % cols) - (cols - 1) / 2.0) * (f["length"] * 0.7 / cols) + rng.uniform(-0.01, 0.01, (B, N))
+    pose[:, :, 1] = np.where(k // cols > 0, 0.3, -0.3) + rng.uniform(-0.01, 0.01, (B, N))
+    pose[:, :, 2] = rng.uniform(-180, 180, (B, N))
+    ball = np.zeros((B, 4))
+    ball[:, 0] = rng.uniform(-0.4, 0.4, B) * f["length"]; ball[:, 1] = rng.uniform(-0.15, 0.15, B) * f["width"]
+    sim.reset(ball, pose[:, :nb], pose[:, nb:])
+    st = sim.state_tensor()
+    cm = sim.cmds_tensor().view(N, 2, B)
+    rows = torch.arange(N, device="cuda") * 6 + 5
+    gen = torch.Generator(device="cuda"); gen.manual_seed(seed)
+    eye = torch.eye(N, device="cuda", dtype=torch.bool)[:, :, None]
+    samples = []
+    for t in range(steps):
+        x, y, th = st[rows], st[rows + 1], torch.deg2rad(st[rows + 2])
+        err = torch.atan2(st[1][None] - y, st[0][None] - x) - th
+        err = torch.atan2(torch.sin(err), torch.cos(err))
+        v = 0.9 * torch.cos(err).clamp_min(0.0) + 0.1
+        w = 8.0 * err + (torch.rand(N, B, device="cuda", generator=gen) - 0.5) * 4.0
+        cm[:, 0] = (v - w * 0.04) / 0.026
+        cm[:, 1] = (v + w * 0.04) / 0.026
+        sim.step_dev()
+        x, y = st[rows], st[rows + 1]
+        d = torch.hypot(x[:, None] - x[None], y[:, None] - y[None]).masked_fill(eye, 9.0)
+        samples.append(0.075 - d.amin(dim=(0, 1)))
+    torch.cuda.synchronize()
+    full = sim.get_state_full()
+    sim.close()
+    return torch.stack(samples).clamp_min(0.0).flatten().float(), full, f
+
+
+# model v2 for the VSS class (DESIGN.md 4; profiles/r06_jam_vss_model_v2.txt).  3v3: the CPU definition gives worst 0.78 cm, p99 0.23 cm over
+# 256 envs x 1000 steps (model v1: 3.5 / 0.49); measured on MI355X at 4096 envs: 0.95 / 0.24.  5v5: ten robots pile up in the open as
+# well, where the pile sits at the depth that triggers the second sweep (pen2 = 5 mm, like the 22-robot SSL scrum): CPU worst 1.06,
+# p99 0.48 (v1: 1.72 / 1.13); MI355X at 1024 envs: 1.45 / 0.47
+VSS_ENVELOPE = {(0, 3): (4096, 1.5, 0.3), (1, 5): (1024, 2.0, 0.6)}
+
+
+@pytest.mark.parametrize("ft,nb", [(0, 3), (1, 5)], ids=["3v3", "5v5"])
+def test_vss_scrum_full_size_contact_invariants(ft, nb):
+    """BASELINE.json configs[1]'s simulator at its full batch (and the 5v5 field at 1024 envs): every robot drives at the ball for 1000
+    steps — on the 1.5 m x 1.3 m field the scrum is at a wall, in a corner or in a goal mouth most of the time.  Size-independent
+    properties: everything finite and inside the walls, and the robots stay discs: the deepest robot-robot overlap of every env after
+    every step stays inside the envelope of model v2 (held axes + goal posts)."""
+    L = _lib()
+    B, worst_cm, p99_cm = VSS_ENVELOPE[(ft, nb)]
+    over, full, f = _vss_scrum(L, ft, nb, B, 1000, 5)
+    N = 2 * nb
+    assert np.isfinite(full).all()
+    xs = np.concatenate([full[:, 0:1]] + [full[:, 5 + 6 * k: 6 + 6 * k] for k in range(N)], 1)
+    ys = np.concatenate([full[:, 1:2]] + [full[:, 6 + 6 * k: 7 + 6 * k] for k in range(N)], 1)
+    assert np.abs(xs).max() <= f["length"] / 2 + f["goal_depth"] + 1e-4 and np.abs(ys).max() <= f["width"] / 2 + 1e-4
+    import torch
+    worst = over.max().item()
+    p99 = torch.quantile(over[torch.randperm(over.numel(), device=over.device)[:4_000_000]], 0.99).item()
+    touching = (over > 0).float().mean().item()
+    if os.environ.get("RSX_PRINT_ENVELOPE"):
+        print(f"VSS {nb}v{nb} scrum envelope ({B} envs): touching {100 * touching:.1f} %, worst {worst * 100:.2f} cm, p99 {p99 * 100:.2f} cm")
+    msg = f"worst robot-robot overlap {worst * 100:.2f} cm (bound {worst_cm}), p99 {p99 * 100:.2f} cm (bound {p99_cm}): DESIGN.md 4"
+    assert touching > 0.8                                   # it IS a scrum
+    assert 0.002 < worst < worst_cm / 100.0, msg
+    assert p99 < p99_cm / 100.0, msg
+
+
 def test_batch_position_and_shard_invariance():
     """env i's trajectory depends only on (seed, global env id): not on batch size, position
     in the batch, or how the batch is split over handles (= over GPUs)."""
@@ -1233,6 +1307,15 @@ def test_checkpoint_resume_is_bit_identical_across_handles_and_layouts(monkeypat
     with pytest.raises(L.RsxError, match="max_episode_steps"):
         g.task_restore(blob)
     g.close()
+    m = L.Sim(kind, ft, nb, ny, 25, B)       # ... and a blob saved under another version of the physics model (header word `model`:
+    m.task_attach(task, seed, base, 40)      # its trajectories would not continue bit-identically under this one)
+    other = np.array(blob, copy=True)
+    off = 8 + 4 * 13                         # magic, then ten int32 + field_type, time_step_ms, max_steps
+    assert int(other[off:off + 4].view(np.int32)[0]) == 2    # RSX_PHYSICS_MODEL
+    other[off:off + 4] = np.array([1], dtype=np.int32).view(np.uint8)
+    with pytest.raises(L.RsxError, match="physics model"):
+        m.task_restore(other)
+    m.close()
 
 
 def _pile_at_walls(rng, B, N, hl, hw, ghw, gd, r, margin, vss):
@@ -1427,3 +1510,53 @@ print(json.dumps(out))
         for e in range(5):
             w = refs[e].get_state_full() if t % 3 == 2 else refs[e].get_state()
             assert f32_equal(got[e][:len(w)], w), mismatch_report(got[e][:len(w)], w, f"env {e} step {t}")
+
+
+@pytest.mark.parametrize("kind,ft,nb,ny,B", [(0, 0, 3, 3, 4096), (1, 2, 1, 6, 1000)], ids=["VSS-3v3-4096", "SSL-1v6-1000"])
+def test_wire_format_step_of_large_batches_converts_on_the_device(kind, ft, nb, ny, B):
+    """Handles of more than 64 envs keep the reference's float64 wire format in pinned host buffers and convert on the device (ABI 6:
+    rsx_wire_buffers / rsx_step_wire; rsx_step / rsx_step_state / rsx_get_state are a memcpy around the same path).  Bit-identical to
+    the staging path they replace (RSX_NO_WIRE_PATH=1: transposing loop on the host + two copies) and to the device-resident step fed
+    the same commands as float32; the wire state buffer holds get_state() + the two internal rows."""
+    import subprocess, sys, hashlib
+    child = r'''
+import sys, os, hashlib
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from rsoccer_amd import _lib as L
+kind, ft, nb, ny, B = map(int, sys.argv[1:6])
+N = nb + ny
+sim = L.Sim(kind, ft, nb, ny, 25, B)
+ref = L.Sim(kind, ft, nb, ny, 25, B)          # device-resident twin
+wire = sim.wire_buffers()
+assert (wire is None) == bool(os.environ.get("RSX_NO_WIRE_PATH"))
+rng = np.random.default_rng(4)
+h = hashlib.sha256()
+for t in range(24):
+    cm = rng.uniform(-1, 1, (B, N, sim.cmd_dim)) * (30.0 if kind == 0 else 1.5)
+    if kind == 1: cm[:, :, 0] = 0; cm[:, :, 4:] = 0
+    ref.cmds_tensor().copy_(torch.from_numpy(cm.transpose(1, 2, 0).reshape(N * sim.cmd_dim, B).astype(np.float32)))
+    ref.step_dev()
+    want = ref.get_state_full()
+    if wire is not None and t % 3 == 0:          # the zero-pass form: fill the pinned buffer, step, read the pinned buffer
+        wire[0][...] = cm
+        sim.step_wire()
+        got_full = wire[1].copy()
+        got = got_full[:, :sim.state_dim]
+    elif t % 3 == 1:
+        got = sim.step_state(np.ascontiguousarray(cm)); got_full = sim.get_state_full()
+    else:
+        sim.step(cm); got = sim.get_state(); got_full = sim.get_state_full()
+    assert np.array_equal(got_full, want), t
+    assert np.array_equal(got, want[:, :sim.state_dim]), t
+    h.update(got_full.tobytes())
+assert np.abs(want[:, 5] - (-0.2)).max() > 1e-3   # things moved
+print("HASH", h.hexdigest())
+'''
+    res = []
+    for env in ({}, {"RSX_NO_WIRE_PATH": "1"}):
+        r = subprocess.run([sys.executable, "-c", child] + [str(v) for v in (kind, ft, nb, ny, B)], env=dict(os.environ, **env),
+                           capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stderr[-3000:]
+        res.append([l for l in r.stdout.splitlines() if l.startswith("HASH")][-1])
+    assert res[0] == res[1]

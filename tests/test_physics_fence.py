@@ -202,3 +202,47 @@ def test_model_v2_piles_are_reproduced_and_are_piles_at_walls(oracle_mod, k):
             assert 0.18 - d.min() < 0.01
             at_wall += int((np.abs(x).max() > xl - 1e-3) or (np.abs(y).max() > yl - 1e-3))
     assert at_wall >= 10
+
+
+# ---- model v2 of the VSS class (round 6): scrums at a goal mouth, recorded from the float64 oracle by tests/golden/make_model_v2.py ----
+V2_VSS_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model_v2_vss_piles.npz")
+V2_VSS_SHA256 = "8796b6f89faa70132f1feb8874b233e4f321b6e103f45bb3a223086ca98f55d4"
+
+
+def test_model_v2_vss_regression_arrays_are_frozen():
+    z = np.load(V2_VSS_GOLDEN)
+    h = hashlib.sha256()
+    for k in sorted(z.files):
+        a = np.ascontiguousarray(z[k])
+        h.update(k.encode()); h.update(str(a.dtype).encode()); h.update(str(a.shape).encode()); h.update(a.tobytes())
+    assert len(z.files) == 6
+    assert h.hexdigest() == V2_VSS_SHA256, "the recorded VSS goal-mouth scrums changed: model v2 of DESIGN.md 4 is frozen"
+
+
+@pytest.mark.parametrize("k", [0, 1])
+def test_model_v2_vss_scrums_are_reproduced_and_sit_at_the_goal(oracle_mod, k):
+    """the oracle reproduces the recorded six-robot scrums (400 steps each, sampled every 20th), and the recordings ARE what they are
+    for: robots held by the goal line's wall and by the goal box's walls, robots past the posts' chords, and a pile that stays a pile
+    of discs (overlap below 4 mm in every sample) — held axes, chord posts and the wall clamp all take part"""
+    z = np.load(V2_VSS_GOLDEN)
+    e = oracle_mod.OracleEnv(0, 0, 3, 3, 25, "f64")
+    e.set_state_full(z[f"vss{k}_reset_state"])
+    cmds, want = z[f"vss{k}_cmds"].astype(np.float64), z[f"vss{k}_states"]
+    f = e.field_params()
+    hl, ghw, gd, r = f[0] / 2, f[4] / 2, f[5], f[14]
+    at_line = in_goal = in_corner = 0
+    for t in range(len(cmds)):
+        e.step(cmds[t])
+        if t % 20 == 19:
+            got = e.get_state_full()
+            assert np.allclose(got, want[t // 20], rtol=0, atol=1e-12), (k, t)
+            x, y = got[5::6][:6], got[6::6][:6]
+            d = np.hypot(x[:, None] - x[None], y[:, None] - y[None]) + 9.0 * np.eye(6)
+            assert 0.075 - d.min() < 0.004
+            ax, ay = np.abs(x), np.abs(y)
+            at_line += int(((np.abs(ax - (hl - r)) < 1e-9) & (ay >= ghw)).any())
+            in_goal += int((ax > hl).any())
+            in_corner += int(((ax > hl - r + 1e-6) & (ax <= hl) & (ay < ghw)).any())
+            assert (ax[(ax <= hl) & (ay < ghw)] + ay[(ax <= hl) & (ay < ghw)] <= hl + ghw - r + 1e-9).all()   # the chord holds
+            assert (ay[ax > hl] <= ghw - r + 1e-9).all() and (ax <= hl + gd - r + 1e-9).all()
+    assert at_line >= 3 and in_goal >= 10 and in_corner >= 3, (at_line, in_goal, in_corner)

@@ -558,3 +558,106 @@ def test_a_pile_driven_into_a_corner_stays_a_pile_of_discs(backend, oracle_mod):
             d = np.hypot(p[:, None, 0] - p[None, :, 0], p[:, None, 1] - p[None, :, 1]) + 9.0 * np.eye(6)
             worst = max(worst, 2 * r - float(d.min()))
     assert 0.0 < worst < 0.0015, worst
+
+
+# ---- model v2 of the VSS class (round 6): goal posts as chords, held axes ----
+def _vss_state(st, n):
+    return np.array([[st[5 + 6 * k], st[6 + 6 * k]] for k in range(n)])
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_vss_goal_post_is_a_chord_bodies_slide_along(backend, oracle_mod):
+    """The corner where the goal line's wall ends at the goal mouth, (L/2, goal_width/2).  In the corner region (|x| <= L/2,
+    |y| < goal_width/2) a body keeps |x| + |y| <= L/2 + goal_width/2 - r: the chord of the arc a round post would give.  A ball shot
+    diagonally at the corner comes back (the velocity component along the chord's normal is reflected with the wall restitution); a
+    robot that slides down the goal line's wall towards the mouth goes round the corner without ever being thrown: its displacement
+    per step stays what it can drive (model v1 clamped x to the goal line's limit for |y| > goal_width/2 - r and threw a body that
+    entered that strip from inside the mouth up to a radius — 3.75 cm — sideways)."""
+    s = _vss(backend, [0, 0, 0, 0], [0, 0.5, 0])
+    f = s.get_field_params()
+    hl, ghw, rb, rr = f["length"] / 2, f["goal_width"] / 2, f["ball_radius"], f["rbt_radius"]
+    # ball: from the field side, 45 degrees, aimed at the chord's middle
+    start = np.array([hl, ghw]) - np.array([0.25, 0.25]) - np.array([rb, rb]) / 2
+    s.reset(np.array([start[0], start[1], 1.5, 1.5]), np.array([[-0.5, -0.5, 0.0], [-0.6, 0.5, 0.0], [-0.6, -0.3, 0.0]]),
+            np.array([[-0.2, 0.5, 0.0], [-0.2, 0.0, 0.0], [-0.2, -0.5, 0.0]]))
+    back, worst = False, -9.0
+    for _ in range(16):
+        s.step(np.zeros((6, 2)))
+        st = s.get_state()
+        if abs(st[0]) <= hl and abs(st[1]) < ghw:
+            worst = max(worst, abs(st[0]) + abs(st[1]) - (hl + ghw - rb))
+        back = back or (st[3] < 0.0 and st[4] < 0.0)
+    assert back and worst <= 1e-6, (back, worst)
+    assert abs(st[3] - st[4]) < 0.05 and -1.5 * 0.6 - 0.1 < st[3] < -0.5      # came back along the diagonal, slower (restitution 0.6, rolling resistance)
+    # robot: pressed against the goal line's wall above the mouth, driving down along it (heading -80 degrees: a little into the wall)
+    s.reset(np.array([-0.5, 0.0, 0.0, 0.0]), np.array([[hl - rr, ghw + 0.12, -80.0], [-0.6, 0.5, 0.0], [-0.6, -0.3, 0.0]]),
+            np.array([[-0.2, 0.5, 0.0], [-0.2, 0.0, 0.0], [-0.2, -0.5, 0.0]]))
+    prev, worst, entered = None, -9.0, False
+    w = 0.5 / 0.026                                                            # wheel speed of 0.5 m/s
+    for _ in range(40):
+        s.step(_cmd(6, 2, {0: [w, w]}))
+        st = s.get_state()
+        p = st[5:7].copy()
+        if abs(p[0]) <= hl and abs(p[1]) < ghw:
+            worst = max(worst, abs(p[0]) + abs(p[1]) - (hl + ghw - rr))
+        entered = entered or p[0] > hl - rr + 0.01                             # beyond the goal line's limit: inside the mouth
+        if prev is not None:
+            assert np.hypot(*(p - prev)) <= 0.5 * 0.025 * 1.3 + 5e-4, (prev, p)
+        prev = p
+    assert worst <= 1e-6 and entered, (worst, entered, prev)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_vss_row_of_pushers_against_a_wall_does_not_telescope(backend, oracle_mod):
+    """Three VSS robots in a row perpendicular to a touch line, the first one standing at it, all driving at it at full speed for a
+    second and a half: the wall holds the first one on the y axis (held axes: its centre is within 1 mm of the wall clamp's limit), so
+    its neighbour takes the whole correction of their contact, and so on down the row — no pair overlaps by more than 3 mm and nobody
+    is beyond the wall.  (Model v1, which split every correction in halves and clamped the outer robot back into its neighbour
+    afterwards: 4.5 mm; model v2: 1.9 mm.)"""
+    s = _make(backend, 0, 0, 3, 3)
+    f = s.get_field_params()
+    hw, r = f["width"] / 2, f["rbt_radius"]
+    yl = hw - r
+    blue = [[0.1, yl - 0.0005 - k * (2 * r + 0.003), 90.0] for k in range(3)]
+    s.reset(np.array([-0.5, -0.4, 0.0, 0.0]), np.array(blue), np.array([[-0.5, 0.3, 0.0], [-0.5, 0.0, 0.0], [-0.3, -0.3, 0.0]]))
+    worst = 0.0
+    for t in range(60):
+        s.step(_cmd(6, 2, {k: [46.0, 46.0] for k in range(3)}))
+        p = _vss_state(s.get_state(), 3)
+        assert (p[:, 1] <= yl + 1e-6).all()
+        if t >= 10:
+            d = np.hypot(p[:, None, 0] - p[None, :, 0], p[:, None, 1] - p[None, :, 1]) + 9.0 * np.eye(3)
+            worst = max(worst, 2 * r - float(d.min()))
+    assert 0.0005 < worst < 0.003, worst
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_vss_pile_in_a_corner_and_in_a_goal_box_stays_a_pile_of_discs(backend, oracle_mod):
+    """Three robots driving into a field corner, three into a goal box (7.5 cm robots in a 10 cm deep, 40 cm wide box: back wall and side
+    walls hold on both axes), for two seconds: inside the walls, and no pair overlaps by more than 3 mm once the piles have formed."""
+    s = _make(backend, 0, 0, 3, 3)
+    f = s.get_field_params()
+    hl, hw, ghw, gd, r = f["length"] / 2, f["width"] / 2, f["goal_width"] / 2, f["goal_depth"], f["rbt_radius"]
+    blue = [[-(hl - 0.10 - 0.09 * k), hw - 0.08 - 0.05 * k, 135.0] for k in range(3)]                  # at the corner (-L/2, +W/2)
+    yel = [[hl - 0.12, 0.02, 0.0], [hl - 0.21, -0.05, 0.0], [hl - 0.21, 0.09, 0.0]]                   # in front of the goal at +L/2
+    s.reset(np.array([0.0, -0.5, 0.0, 0.0]), np.array(blue), np.array(yel))
+    worst = 0.0
+    for t in range(80):
+        st = s.get_state()
+        cm = np.zeros((6, 2))
+        for k in range(6):
+            x, y, th = st[5 + 6 * k], st[6 + 6 * k], np.deg2rad(st[7 + 6 * k])
+            tx, ty = (-hl - 0.5, hw + 0.5) if k < 3 else (hl + gd + 0.5, 0.0)
+            err = np.arctan2(ty - y, tx - x) - th
+            err = np.arctan2(np.sin(err), np.cos(err))
+            v, w = 0.8, 8.0 * err
+            cm[k] = [(v - w * 0.04) / 0.026, (v + w * 0.04) / 0.026]
+        s.step(cm)
+        p = _vss_state(s.get_state(), 6)
+        assert (np.abs(p[:, 0]) <= hl + gd - r + 1e-6).all() and (np.abs(p[:, 1]) <= hw - r + 1e-6).all()
+        inside = np.abs(p[:, 0]) > hl
+        assert (np.abs(p[inside, 1]) <= ghw - r + 1e-6).all()
+        if t >= 25:
+            d = np.hypot(p[:, None, 0] - p[None, :, 0], p[:, None, 1] - p[None, :, 1]) + 9.0 * np.eye(6)
+            worst = max(worst, 2 * r - float(d.min()))
+    assert 0.0 < worst < 0.003, worst

@@ -16,6 +16,14 @@ for B in (1, 64, 4096, 65536):
     for _ in range(n): st = sim.step_state(cmds)
     dt = (time.perf_counter() - t) / n
     print(f"raw VSS 3v3, host wire format (rsx_step_state), {B:6d} envs: {dt * 1e6:9.1f} us per step = {B / dt:12.4g} env-steps/s", flush=True)
+    wire = sim.wire_buffers()
+    if wire is not None:   # ABI 6: the caller works in the handle's pinned wire buffers — no pass of a CPU thread over the data at all
+        wire[0][...] = cmds
+        for _ in range(20): sim.step_wire()
+        t = time.perf_counter()
+        for _ in range(n): sim.step_wire()
+        dt = (time.perf_counter() - t) / n
+        print(f"raw VSS 3v3, pinned wire buffers (rsx_step_wire),  {B:6d} envs: {dt * 1e6:9.1f} us per step = {B / dt:12.4g} env-steps/s", flush=True)
     sim.close()
 B = 4096
 sim = L.Sim(0, 0, 3, 3, 25, B); sim.task_attach(1, 0, 0, 0); sim.task_reset(); tens = sim.task_tensors()

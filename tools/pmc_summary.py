@@ -6,12 +6,14 @@ from calib_factors import calibrated_factors
 FF, WF, FSRC = calibrated_factors()
 out = sys.argv[1]
 KERNEL = "task_step_kernel<0, 8, 1, 6, 0>"
+GRID = 512 * 64   # work-items of a 4096-env launch (8 envs per 64-thread workgroup)
 vals = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     rows = []
     for f in glob.glob(os.path.join(out, f"pmc_{c}", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if KERNEL in r.get("Kernel_Name", "") and r.get("Counter_Name") == c:
+            # only the 4096-env launches of the symbol (512 workgroups of 64): the same kernel also steps the 65 536-env sweep leg
+            if KERNEL in r.get("Kernel_Name", "") and r.get("Counter_Name") == c and int(r.get("Grid_Size", GRID) or GRID) == GRID:
                 rows.append(float(r["Counter_Value"]))
     vals[c] = statistics.median(rows) if rows else None
 B = 4096
@@ -27,4 +29,15 @@ res = {
                              "note": "state 44 f32 (36 robot + 5 ball + height, vz, spin) + steps/episode + OU 10 + info 6 + prev_pot read; the same + obs 40 f32 + reward + 2 flag bytes written"},
     "algorithmic_bytes_per_launch": 541 * B,
 }
+# the rocprofv3 --kernel-trace average of the SAME launches (tools/kernel_stats_by_grid.py), so that roofline.frac can be recomputed from one row
+by_grid = os.path.join(out, "bench_kernel_stats_by_grid.csv")
+if os.path.exists(by_grid):
+    for r in csv.DictReader(open(by_grid)):
+        if KERNEL in r["Name"] and int(float(r["Grid_Size"])) == GRID:
+            avg_us = float(r["AverageNs"]) / 1000.0
+            res["rocprof_kernel_trace_4096_envs"] = {"calls": int(float(r["Calls"])), "avg_launch_us": round(avg_us, 4), "min_us": float(r["MinNs"]) / 1000.0,
+                                                   "max_us": float(r["MaxNs"]) / 1000.0,
+                                                   "algorithmic_GBps": round(541 * B / avg_us / 1e3, 2), "frac_of_8TBps": round(541 * B / avg_us / 1e3 / 8000.0, 5),
+                                                   "source": "bench_kernel_stats_by_grid.csv (rocprofv3 --kernel-trace of `python bench.py --no-cpu-baseline --no-rollout`, grouped by kernel and grid size)"}
+            break
 print(json.dumps(res, indent=1))

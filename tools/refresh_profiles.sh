@@ -10,7 +10,9 @@ python bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -1 $OUT/bench.json | cut -c1-400
 # kernel trace + stats of the bench command (step mode only, no CPU leg)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py --no-cpu-baseline --no-rollout > $OUT/stats.log 2>&1
-find $OUT/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/bench_kernel_stats.csv
+find $OUT/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/bench_kernel_stats_pooled.csv
+# the same trace grouped by (kernel, grid size): the 4096-env launches of the headline kernel get their own row
+python tools/kernel_stats_by_grid.py $OUT/stats $OUT/bench_kernel_stats_by_grid.csv && cp $OUT/bench_kernel_stats_by_grid.csv $OUT/bench_kernel_stats.csv
 head -3 $OUT/bench_kernel_stats.csv
 # HBM traffic counters, one pass each, no tracing
 for c in FETCH_SIZE WRITE_SIZE; do
