@@ -437,10 +437,18 @@ def main():
                                    if args.mode == "step" else
                                    f"VSS-v0 3v3 fused step, {B} envs per GPU, random actions, all {K} steps in one launch",
                        "envs_per_gpu": B, "launch_mode": args.mode, "sub_steps": 5, "time_step_ms": 25,
-                       "physics": "project-defined 2-D rigid-body model (DESIGN.md 4); not validated against rc-robosim, "
-                                  "whose sources are not part of the reference tree"},
+                       "physics": "project-defined 2-D rigid-body model, version 2 (docs/PHYSICS.md, DESIGN.md 4: wall-aware contacts — VSS: held "
+                                  "axes + goal posts as chords, since round 6; the headline step was 8.8 us under model v1, 9.4-9.5 under v2); "
+                                  "not validated against rc-robosim, whose sources are not part of the reference tree"},
             "episodes": int(metrics[1]), "env_steps_counted": int(metrics[0]),
         }
+        # which clock and which window every top-level figure uses (rounds 1-4 printed the steady leg as `value`; since round 5
+        # `value` is the flag-defined region, and a region of fewer than EVENT_MIN_STEPS launches is timed by the host clock)
+        line["value_clock"] = ("host wall clock around the timed region (barrier + synchronize on both sides), max over ranks"
+                               + ("" if K >= EVENT_MIN_STEPS or args.mode == "rollout" else
+                                  f"; no HIP events inside a region of {K} < {EVENT_MIN_STEPS} launches (the pair costs ~14 us of stream time)"))
+        line["value_window"] = f"{K} steps after {W} warm-up steps (the flags)"
+        line["value_timed_region"] = value                     # the same number under the name round 5 introduced it with
         # `value` / `ms_per_step` are ALWAYS the timed region the flags ask for (the contract; comparable across rounds).  A region
         # of fewer than 200 launches (the driver's --steps 20 is 0.2 ms of wall clock: +-10 % from run to run, early-episode
         # steps) is a noisy sample of the steady rate, which is published beside it.

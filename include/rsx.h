@@ -20,6 +20,12 @@
  *     (their buffers are initialised before any caller stream can touch them).
  *   - no call changes the calling thread's current HIP device: the handle's device is made
  *     current for the duration of the call and the previous one is restored on return.
+ *   - a caller compiled against this header checks rsx_abi_version() == RSX_ABI_VERSION BEFORE any other call: rsx_dev_view_get /
+ *     rsx_task_view_get fill the caller's struct in the LIBRARY's layout (ABI 5 appended row_stride to both views — a caller built
+ *     against an older header would have its stack overwritten), and every entry point assumes this header's argument lists.
+ *   - rows of the device arrays are dense (row_stride == num_envs) below 786 432 envs; consumers that index base + f * num_envs on
+ *     larger handles either use row_stride or set RSX_ROW_PAD=0 in the environment before rsx_create (dense rows at every batch,
+ *     at the measured cost of DESIGN.md 3).
  *   - a handle is not thread-safe; distinct handles are independent.
  *   - there is NO CPU fallback: creation fails (RSX_ERR_NO_DEVICE) without a gfx950 device.
  *

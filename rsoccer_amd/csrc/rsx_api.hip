@@ -5,6 +5,8 @@
 // reset at :38; field at :50; destroyed at :41).  HIP only: there is no CPU path in this library.
 #include <hip/hip_runtime.h>
 
+#include "rsx_launch.hpp"
+
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
@@ -129,7 +131,9 @@ struct rsx_sim {
     // rsx_task_enable_capture: the step counter lives in device memory (one slot per workgroup behind the metrics vector,
     // rsx_kernels.hpp: step_tick) so that captured stepping launches advance it when a graph replays them
     bool tick_dev = false;
-    int tick_slots = 0;                       // workgroups of the handle's largest stepping launch
+    int tick_slots = 0;                       // workgroups of the handle's per-step launches: the slots every stepping call keeps in sync
+    int tick_slots_alloc = 0;                 // slots allocated (the largest grid any layout of this batch could launch): rsx_task_enable_capture and
+                                              // rsx_task_checkpoint_load write ALL of them, so that no grid ever reads a slot nobody has set
 };
 
 namespace {
@@ -188,7 +192,6 @@ Buffers buffers_of(const rsx_sim* h, const float* actions) {
 void pick_variant(rsx_sim* h) {
     const int N = h->P.n_robots;
     h->NR = 0;
-    if (std::getenv("RSX_GENERIC_KERNELS")) return;
     if (h->P.kind == RSX_KIND_VSS && N == 6 && (h->L == 8 || h->L == 16) && h->P.n_blue == 3) h->NR = 6;   // 16: RSX_LANES_PER_ENV=16 (four envs per wave)
     if (h->P.kind == RSX_KIND_VSS && N == 10 && h->L == 16 && h->P.n_blue == 5) h->NR = 10;   // 5v5 field
     if (h->P.kind == RSX_KIND_SSL && N == 7 && (h->L == 8 || h->L == 16)) h->NR = 7;
@@ -197,12 +200,12 @@ void pick_variant(rsx_sim* h) {
 }
 
 // hot arguments first (preloaded into SGPRs, see RSX_HOT_ARGS), then the by-value structs
-#define RSX_LAUNCH_SIM(kernel, P, b) hipLaunchKernelGGL((kernel), grid, dim3(64), 0, s, (b).state, state_out, (b).cmds, (b).flags, \
+#define RSX_LAUNCH_SIM(kernel, P, b) rsx_launch((kernel), grid, dim3(64), 0, s, (b).state, state_out, (b).cmds, (b).flags, \
                                                         (P).num_envs, RSX_HOT_DIM((P).state_dim, (P).row_stride, (P).num_envs), (int)(grid.x >> 3), rand_tick, (P), (b))
-#define RSX_LAUNCH(kernel, P, b, n) hipLaunchKernelGGL((kernel), grid, dim3(64), 0, s, (b).state, (b).aux, (b).actions, (b).flags, \
+#define RSX_LAUNCH(kernel, P, b, n) rsx_launch((kernel), grid, dim3(64), 0, s, (b).state, (b).aux, (b).actions, (b).flags, \
                                                        (P).num_envs, RSX_HOT_DIM((P).state_dim, (P).row_stride, (P).num_envs), (int)(grid.x >> 3), (n), (P), (b))
 // the same with `extra` helper workgroups behind the tile workgroups (the tile map still sees the tile grid)
-#define RSX_LAUNCH_X(kernel, P, b, n, extra) hipLaunchKernelGGL((kernel), dim3(grid.x + (unsigned)(extra)), dim3(64), 0, s, (b).state, (b).aux, (b).actions, \
+#define RSX_LAUNCH_X(kernel, P, b, n, extra) rsx_launch((kernel), dim3(grid.x + (unsigned)(extra)), dim3(64), 0, s, (b).state, (b).aux, (b).actions, \
                                                                 (b).flags, (P).num_envs, RSX_HOT_DIM((P).state_dim, (P).row_stride, (P).num_envs), (int)(grid.x >> 3), (n), (P), (b))
 
 template <int KIND>
@@ -369,7 +372,7 @@ __global__ void tick_fill_kernel(uint32_t* __restrict__ slots, int from, int to,
 }
 void tick_fill(const rsx_sim* h, int from, int to, uint32_t value, int copy, hipStream_t s) {
     if (to <= from) return;
-    hipLaunchKernelGGL(tick_fill_kernel, dim3((unsigned)((to - from + 255) / 256)), dim3(256), 0, s,
+    rsx_launch(tick_fill_kernel, dim3((unsigned)((to - from + 255) / 256)), dim3(256), 0, s,
                        tick_words(h) + TICK_SLOT_WORD0, from, to, value, copy);
 }
 
@@ -389,13 +392,13 @@ struct DeviceGuard {
     ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
 };
 
-// (the thread's last-error slot is cleared on the way in: the launch checks below report THIS call's errors, not one a caller's
-// other HIP work — e.g. torch ending an aborted stream capture — left behind)
+// (kernel launches report through rsx_launch's own record, rsx_launch.hpp — reset on the way in; the thread's HIP last-error slot, which
+// the caller's other HIP work shares, is neither read nor cleared here)
 #define RSX_ENTER(h)                                              \
     if (!(h)) return fail(RSX_ERR_ARG, "null handle");            \
     DeviceGuard _guard;                                           \
     if (int _rc = _guard.enter((h)->device)) return _rc;          \
-    (void)hipGetLastError()
+    (void)launch_status()
 
 #define RSX_ENTER_TASK(h)                                                                        \
     RSX_ENTER(h);                                                                                \
@@ -490,7 +493,7 @@ static int check_finite_impl(rsx_sim* h, int64_t* n_bad, hipStream_t s) {
     const size_t B = (size_t)h->P.num_envs, S = (size_t)h->P.row_stride;   // (the pad columns hold zeros)
     auto scan = [&](const float* p, size_t n) {
         const unsigned blocks = (unsigned)std::min<size_t>(2048, (n + 255) / 256);
-        hipLaunchKernelGGL(count_nonfinite_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, p, n, h->d_check);
+        rsx_launch(count_nonfinite_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, p, n, h->d_check);
     };
     scan(h->d_state, (size_t)(h->P.state_dim + X_ROWS) * S);
     if (h->P.task != RSX_TASK_NONE) {
@@ -498,7 +501,7 @@ static int check_finite_impl(rsx_sim* h, int64_t* n_bad, hipStream_t s) {
         scan(h->d_aux + (size_t)ROW_REWARD * S, B);
         scan(h->d_aux + (size_t)ROW_INFO * S, S * (size_t)h->M.info_dim);
     }
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_status());
     unsigned long long bad = 0;
     HIP_TRY(hipMemcpyAsync(&bad, h->d_check, sizeof(bad), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -648,11 +651,11 @@ static int step_wire_impl(rsx_sim* h, hipStream_t s) {
     const Params& P = h->P;
     const unsigned B = (unsigned)P.num_envs, S = (unsigned)P.row_stride, NC = (unsigned)(P.n_robots * h->M.cmd_dim), rows = (unsigned)(P.state_dim + X_ROWS);
     h->host_state_valid = false;
-    hipLaunchKernelGGL(wire_cmds_in_kernel, dim3((B * NC + 255) / 256), dim3(256), 0, s, h->wire_cmds_dev, h->d_cmds, B, NC, S);
+    rsx_launch(wire_cmds_in_kernel, dim3((B * NC + 255) / 256), dim3(256), 0, s, h->wire_cmds_dev, h->d_cmds, B, NC, S);
     launch_sim(h, s);
     if (h->host_state_cache)
-        hipLaunchKernelGGL(wire_state_out_kernel, dim3((B * rows + 255) / 256), dim3(256), 0, s, h->d_state, h->wire_state_dev, B, rows, S);
-    HIP_TRY(hipGetLastError());
+        rsx_launch(wire_state_out_kernel, dim3((B * rows + 255) / 256), dim3(256), 0, s, h->d_state, h->wire_state_dev, B, rows, S);
+    HIP_TRY(launch_status());
     HIP_TRY(hipStreamSynchronize(s));
     h->host_state_valid = h->host_state_cache;
     return RSX_OK;
@@ -693,11 +696,11 @@ int rsx_step(rsx_sim* h, const double* cmds, void* stream) {
     h->host_state_valid = false;
     if (h->pin_cmds_dev) {   // small batch: no copies, the kernel talks to the pinned buffers
         launch_sim(h, s, nullptr, -1, 0, h->pin_cmds_dev, h->host_state_cache ? h->pin_state_dev : nullptr);
-        HIP_TRY(hipGetLastError());
+        HIP_TRY(launch_status());
     } else {
         HIP_TRY(hipMemcpyAsync(h->d_cmds, h->pin_cmds, NC * S * sizeof(float), hipMemcpyHostToDevice, s));
         launch_sim(h, s);
-        HIP_TRY(hipGetLastError());
+        HIP_TRY(launch_status());
         if (h->host_state_cache)
             HIP_TRY(hipMemcpyAsync(h->pin_state, h->d_state, (size_t)(P.state_dim + X_ROWS) * S * sizeof(float), hipMemcpyDeviceToHost, s));
     }
@@ -711,8 +714,8 @@ static int get_state_impl(rsx_sim* h, double* out, int rows, hipStream_t s) {
     if (h->wire_state) {   // large batch: the wire-format copy is made on the device; what is left is a copy out of pinned memory
         const int all = h->P.state_dim + X_ROWS;
         if (!h->host_state_valid) {
-            hipLaunchKernelGGL(wire_state_out_kernel, dim3(((unsigned)B * all + 255) / 256), dim3(256), 0, s, h->d_state, h->wire_state_dev, (unsigned)B, (unsigned)all, (unsigned)S);
-            HIP_TRY(hipGetLastError());
+            rsx_launch(wire_state_out_kernel, dim3(((unsigned)B * all + 255) / 256), dim3(256), 0, s, h->d_state, h->wire_state_dev, (unsigned)B, (unsigned)all, (unsigned)S);
+            HIP_TRY(launch_status());
             HIP_TRY(hipStreamSynchronize(s));
             h->host_state_valid = h->host_state_cache;
         }
@@ -774,7 +777,7 @@ int rsx_step_dev(rsx_sim* h, void* stream) {
     RSX_ENTER(h);
     h->host_state_valid = false;
     launch_sim(h, (hipStream_t)stream);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_status());
     return debug_finite(h, (hipStream_t)stream, "rsx_step_dev");
 }
 
@@ -802,7 +805,7 @@ int rsx_step_dev_random(rsx_sim* h, int n, uint64_t seed, uint32_t first_tick, v
     if ((uint64_t)first_tick + (uint64_t)n > 0x7FFFFFFFull) return fail(RSX_ERR_ARG, "tick range exceeds 2^31");
     h->host_state_valid = false;
     for (int i = 0; i < n; ++i) launch_sim(h, (hipStream_t)stream, nullptr, (int)(first_tick + (uint32_t)i), seed);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_status());
     return debug_finite(h, (hipStream_t)stream, "rsx_step_dev_random");
 }
 
@@ -816,7 +819,7 @@ int rsx_step_dev_flip(rsx_sim* h, void* stream) {
     if (int rc = ensure_alt(h)) return rc;
     h->host_state_valid = false;
     launch_sim(h, (hipStream_t)stream, h->d_state_alt);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_status());
     std::swap(h->d_state, h->d_state_alt);
     return debug_finite(h, (hipStream_t)stream, "rsx_step_dev_flip");
 }
@@ -827,9 +830,9 @@ int rsx_reset_dev(rsx_sim* h, const float* ball_dev, const float* blue_dev, cons
     if (!ball_dev || (h->P.n_blue && !blue_dev) || (h->P.n_yellow && !yellow_dev)) return fail(RSX_ERR_ARG, "null placement array");
     h->host_state_valid = false;
     const int B = h->P.num_envs;
-    hipLaunchKernelGGL(reset_dev_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->d_state, ball_dev, blue_dev,
+    rsx_launch(reset_dev_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->d_state, ball_dev, blue_dev,
                        yellow_dev, env_mask_dev, B, h->P.row_stride, h->P.state_dim + X_ROWS, h->M.rs, h->P.n_blue, h->P.n_yellow, (float)h->M.field[6]);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_status());
     return RSX_OK;
 }
 
@@ -885,8 +888,7 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
     h->epl = false;
     h->big = false; h->quad = false;
     if ((task == RSX_TASK_SSL_SCRIMMAGE || task == RSX_TASK_SSL_SCRIMMAGE_CROWDED) && h->NR == 22 && h->L == 32) {
-        const char* bg = std::getenv("RSX_BIG");   // development override: 0 / 1
-        h->big = bg ? bg[0] == '1' : P.num_envs >= RSX_BIG_MIN_ENVS;
+        h->big = P.num_envs >= RSX_BIG_MIN_ENVS;
         // four lanes per env: 32-bit row offsets (arrays below 2 GB), a real time step (the infrared row is rewritten)
         const char* lay = std::getenv("RSX_LAYOUT");
         const size_t rows = (size_t)std::max(P.state_dim + X_ROWS, aux_rows(P.n_robots));
@@ -911,6 +913,7 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
     h->task_ready = false;
     h->tick_dev = false;
     h->tick_slots = step_grid(h, MODE_STEP);
+    h->tick_slots_alloc = std::max(h->tick_slots, (int)grid_for(h).x + (P.num_envs + 63) / 64);
     HIP_TRY(hipDeviceSynchronize());   // null-stream memsets done before any caller stream steps
     return RSX_OK;
 }
@@ -923,8 +926,8 @@ int rsx_task_enable_capture(rsx_sim* h, void* stream) {
     if (hipStreamIsCapturing(s, &cs) != hipSuccess) (void)hipGetLastError();
     else if (cs != hipStreamCaptureStatusNone)
         return fail(RSX_ERR_STATE, "rsx_task_enable_capture must be called BEFORE the capture begins (it writes the step counter once; a captured write would reset it on every replay)");
-    tick_fill(h, 0, h->tick_slots, h->tick, 0, s);
-    HIP_TRY(hipGetLastError());
+    tick_fill(h, 0, h->tick_slots_alloc, h->tick, 0, s);
+    HIP_TRY(launch_status());
     h->tick_dev = true;
     h->host_state_cache = false; h->host_state_valid = false;   // a replayed graph changes the state without passing through this API
     return RSX_OK;
@@ -983,7 +986,7 @@ int rsx_task_view_get(rsx_sim* h, rsx_task_view* out) {
 int rsx_task_reset(rsx_sim* h, void* stream) {
     RSX_ENTER_TASK(h);
     launch_task(h, nullptr, 1, MODE_RESET, (hipStream_t)stream);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_status());
     h->task_ready = true;
     return RSX_OK;
 }
@@ -998,7 +1001,7 @@ int rsx_task_reset_to(rsx_sim* h, const double* ball, const double* blue, const 
     if (env_mask) HIP_TRY(hipMemcpyAsync(h->d_flags + B, env_mask, B, hipMemcpyHostToDevice, s));
     else HIP_TRY(hipMemsetAsync(h->d_flags + B, 1, B, s));
     launch_task(h, nullptr, 1, MODE_REFRESH, s);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_status());
     HIP_TRY(hipMemsetAsync(h->d_flags + B, 0, B, s));
     HIP_TRY(hipStreamSynchronize(s));   // the host mask / placement arrays may be reused by the caller
     h->task_ready = true;
@@ -1034,7 +1037,7 @@ int rsx_task_step(rsx_sim* h, const float* actions_dev, void* stream) {
     if (int rc = step_prologue(h, (hipStream_t)stream, 1, &fl)) return rc;
     h->P.tick_base = h->tick++;
     launch_task(h, actions_dev, 1 | fl, MODE_STEP, (hipStream_t)stream);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_status());
     return debug_finite(h, (hipStream_t)stream, "rsx_task_step");
 }
 
@@ -1045,7 +1048,7 @@ int rsx_task_step_n(rsx_sim* h, int n, void* stream) {
     int fl = 0;
     if (int rc = step_prologue(h, (hipStream_t)stream, (uint64_t)n, &fl)) return rc;
     for (int i = 0; i < n; ++i) { h->P.tick_base = h->tick++; launch_task(h, nullptr, 1 | fl, MODE_STEP, (hipStream_t)stream); }
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_status());
     return debug_finite(h, (hipStream_t)stream, "rsx_task_step_n");
 }
 
@@ -1060,13 +1063,13 @@ int rsx_task_rollout(rsx_sim* h, int n, void* stream) {
         // 11v11 at large batches: n launches of the four-lanes-per-env kernel beat one launch of the 32-lane kernel
         // (262 144 envs, us per step: spread 182 vs 275, crowded 298 vs 340; crowded 131 072: 161 vs 164); same steps, same results
         for (int i = 0; i < n; ++i) { h->P.tick_base = h->tick++; launch_task(h, nullptr, 1 | fl, MODE_STEP, (hipStream_t)stream); }
-        HIP_TRY(hipGetLastError());
+        HIP_TRY(launch_status());
         return debug_finite(h, (hipStream_t)stream, "rsx_task_rollout");
     }
     h->P.tick_base = h->tick; h->tick += (uint32_t)n;
     launch_task(h, nullptr, n | fl, MODE_ROLLOUT, (hipStream_t)stream);
     tick_resync(h, MODE_ROLLOUT, (hipStream_t)stream);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_status());
     return debug_finite(h, (hipStream_t)stream, "rsx_task_rollout");
 }
 
@@ -1121,8 +1124,8 @@ int rsx_task_checkpoint_save(rsx_sim* h, void* blob, size_t bytes, void* stream)
     CkptHeader k = ckpt_header(h);
     if (bytes < ckpt_size(k)) return fail(RSX_ERR_ARG, "blob is smaller than rsx_task_checkpoint_size");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(fold_metrics_kernel, dim3(1), dim3(64), 0, s, h->d_metrics, h->d_mslots);
-    HIP_TRY(hipGetLastError());
+    rsx_launch(fold_metrics_kernel, dim3(1), dim3(64), 0, s, h->d_metrics, h->d_mslots);
+    HIP_TRY(launch_status());
     char* p = (char*)blob + sizeof(CkptHeader);
     // (the blob's rows are dense — B floats — whatever the row pad of this handle: it restores into any layout)
     const size_t rowb = (size_t)h->P.num_envs * sizeof(float), pitch = (size_t)h->P.row_stride * sizeof(float);
@@ -1186,8 +1189,8 @@ int rsx_task_checkpoint_load(rsx_sim* h, const void* blob, size_t bytes, void* s
     HIP_TRY(hipMemsetAsync(h->d_mslots, 0, (size_t)MSLOTS * RSX_METRICS * sizeof(unsigned long long), s));
     HIP_TRY(hipMemcpyAsync(h->d_metrics, k.metrics, sizeof(k.metrics), hipMemcpyHostToDevice, s));
     if (h->tick_dev) {   // device-keyed handle: every slot takes the blob's step counter; a refused-launch mark is cleared with it
-        tick_fill(h, 0, h->tick_slots, k.tick, 0, s);
-        HIP_TRY(hipGetLastError());
+        tick_fill(h, 0, h->tick_slots_alloc, k.tick, 0, s);
+        HIP_TRY(launch_status());
         HIP_TRY(hipMemsetAsync(tick_words(h) + TICK_ERR_WORD, 0, sizeof(uint32_t), s));
     }
     HIP_TRY(hipStreamSynchronize(s));
@@ -1201,8 +1204,8 @@ int rsx_task_checkpoint_load(rsx_sim* h, const void* blob, size_t bytes, void* s
 extern "C" {
 int rsx_metrics_fold(rsx_sim* h, void* stream) {
     RSX_ENTER_TASK(h);
-    hipLaunchKernelGGL(fold_metrics_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, h->d_metrics, h->d_mslots);
-    HIP_TRY(hipGetLastError());
+    rsx_launch(fold_metrics_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, h->d_metrics, h->d_mslots);
+    HIP_TRY(launch_status());
     return RSX_OK;
 }
 
@@ -1210,8 +1213,8 @@ int rsx_read_metrics(rsx_sim* h, int64_t out[RSX_METRICS], void* stream) {
     RSX_ENTER_TASK(h);
     if (!out) return fail(RSX_ERR_ARG, "out is null");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(fold_metrics_kernel, dim3(1), dim3(64), 0, s, h->d_metrics, h->d_mslots);
-    HIP_TRY(hipGetLastError());
+    rsx_launch(fold_metrics_kernel, dim3(1), dim3(64), 0, s, h->d_metrics, h->d_mslots);
+    HIP_TRY(launch_status());
     HIP_TRY(hipMemcpyAsync(out, h->d_metrics, RSX_METRICS * sizeof(int64_t), hipMemcpyDeviceToHost, s));
     uint32_t refused = 0;
     if (h->tick_dev) HIP_TRY(hipMemcpyAsync(&refused, tick_words(h) + TICK_ERR_WORD, sizeof(uint32_t), hipMemcpyDeviceToHost, s));

@@ -7,6 +7,8 @@
 // another symbol name, and the host picks by batch size (RSX_BIG_MIN_ENVS).  Same source, same results.
 #include <hip/hip_runtime.h>
 
+#include "rsx_launch.hpp"
+
 #define task_step_kernel task_step_kernel_big
 #include "rsx_kernels.hpp"
 
@@ -17,10 +19,10 @@ void launch_scrimmage_big(bool rollout, const Params& P, const Buffers& b, int n
     const int tiles = (P.num_envs + G - 1) / G;
     const dim3 grid((unsigned)(((tiles + 7) / 8) * 8));
     if (rollout)
-        hipLaunchKernelGGL((task_step_kernel_big<RSX_KIND_SSL, 32, RSX_TASK_SSL_SCRIMMAGE, 22, MODE_ROLLOUT>), grid, dim3(64), 0, s, b.state, b.aux,
+        rsx_launch((task_step_kernel_big<RSX_KIND_SSL, 32, RSX_TASK_SSL_SCRIMMAGE, 22, MODE_ROLLOUT>), grid, dim3(64), 0, s, b.state, b.aux,
                            b.actions, b.flags, P.num_envs, RSX_HOT_DIM(P.state_dim, P.row_stride, P.num_envs), (int)(grid.x >> 3), n_steps, P, b);
     else
-        hipLaunchKernelGGL((task_step_kernel_big<RSX_KIND_SSL, 32, RSX_TASK_SSL_SCRIMMAGE, 22, MODE_STEP>), grid, dim3(64), 0, s, b.state, b.aux,
+        rsx_launch((task_step_kernel_big<RSX_KIND_SSL, 32, RSX_TASK_SSL_SCRIMMAGE, 22, MODE_STEP>), grid, dim3(64), 0, s, b.state, b.aux,
                            b.actions, b.flags, P.num_envs, RSX_HOT_DIM(P.state_dim, P.row_stride, P.num_envs), (int)(grid.x >> 3), n_steps, P, b);
 }
 

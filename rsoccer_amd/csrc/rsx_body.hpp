@@ -140,9 +140,6 @@ __device__ __forceinline__ void walls(const Params& P, const float r, const floa
 template <int KIND>
 __device__ __forceinline__ bool near_walls(const Params& P, const float x, const float y) {
     using K = KC<KIND>;
-#ifdef RSX_NO_WALL_SKIP   // development A/B: always run the clamp
-    return true;
-#endif
     // one form for both classes (K::margin is 0 for VSS).  SSL: the strip of a robot's radius before the goal lines is there for the goal
     // posts only; testing |y| against the posts as well would be exact, but costs two more DEPENDENT instructions at the end of every
     // sub-step of every wave (measured: +1.3 % on the 1v6 and 11v11 steps at the latency-bound batches) to save a rare clamp

@@ -4,6 +4,8 @@
 // small batches but costs these a wave of occupancy.
 #include <hip/hip_runtime.h>
 
+#include "rsx_launch.hpp"
+
 #include <cstdlib>
 
 #include "rsx_epl.hpp"
@@ -40,10 +42,10 @@ void launch_vss_epl(bool rollout, const Params& P, const Buffers& b, int n_steps
     const int tiles = (P.num_envs + 63) / 64;
     const dim3 grid((unsigned)(((tiles + 7) / 8) * 8));
     if (rollout)
-        hipLaunchKernelGGL(vss_epl_rollout_kernel, grid, dim3(64), 0, s, b.state, b.aux, b.actions, b.flags,
+        rsx_launch(vss_epl_rollout_kernel, grid, dim3(64), 0, s, b.state, b.aux, b.actions, b.flags,
                            P.num_envs, RSX_HOT_DIM(P.state_dim, P.row_stride, P.num_envs), (int)(grid.x >> 3), n_steps, P, b);
     else
-        hipLaunchKernelGGL((vss_epl_kernel<MODE_STEP>), grid, dim3(64), epl_lds_pad(), s, b.state, b.aux, b.actions, b.flags,
+        rsx_launch((vss_epl_kernel<MODE_STEP>), grid, dim3(64), epl_lds_pad(), s, b.state, b.aux, b.actions, b.flags,
                            P.num_envs, RSX_HOT_DIM(P.state_dim, P.row_stride, P.num_envs), step_per_xcd(P, grid, n_steps), n_steps, P, b);
 }
 
@@ -52,7 +54,7 @@ static void launch_ssl_epl_t(bool rollout, const Params& P, const Buffers& b, in
     const int tiles = (P.num_envs + 63) / 64;
     const dim3 grid((unsigned)(((tiles + 7) / 8) * 8));
     if (rollout)
-        hipLaunchKernelGGL((ssl_epl_kernel<TASK, MODE_ROLLOUT>), grid, dim3(64), 0, s, b.state, b.aux, b.actions, b.flags,
+        rsx_launch((ssl_epl_kernel<TASK, MODE_ROLLOUT>), grid, dim3(64), 0, s, b.state, b.aux, b.actions, b.flags,
                            P.num_envs, RSX_HOT_DIM(P.state_dim, P.row_stride, P.num_envs), (int)(grid.x >> 3), n_steps, P, b);
     else {
         // the lean single-step form (rsx_epl_ssl.hpp): 1v6 below RSX_SD_LEAN_MAX_ENVS (occupancy-bound there: 262 144 envs 52 -> 47 us;
@@ -63,17 +65,17 @@ static void launch_ssl_epl_t(bool rollout, const Params& P, const Buffers& b, in
         const bool lean = force >= 0 ? force != 0
                                      : TASK == RSX_TASK_SSL_CONTESTED || (TASK == RSX_TASK_SSL_STATIC_DEFENDERS && P.num_envs < RSX_SD_LEAN_MAX_ENVS);
         if (lean && (TASK == RSX_TASK_SSL_CONTESTED || TASK == RSX_TASK_SSL_STATIC_DEFENDERS))
-            hipLaunchKernelGGL((ssl_epl_kernel<TASK, MODE_STEP, (TASK == RSX_TASK_SSL_CONTESTED || TASK == RSX_TASK_SSL_STATIC_DEFENDERS)>), grid, dim3(64), 0, s,
+            rsx_launch((ssl_epl_kernel<TASK, MODE_STEP, (TASK == RSX_TASK_SSL_CONTESTED || TASK == RSX_TASK_SSL_STATIC_DEFENDERS)>), grid, dim3(64), 0, s,
                                b.state, b.aux, b.actions, b.flags, P.num_envs, RSX_HOT_DIM(P.state_dim, P.row_stride, P.num_envs), step_per_xcd(P, grid, n_steps), n_steps, P, b);
         else
-            hipLaunchKernelGGL((ssl_epl_kernel<TASK, MODE_STEP>), grid, dim3(64), 0, s, b.state, b.aux, b.actions, b.flags,
+            rsx_launch((ssl_epl_kernel<TASK, MODE_STEP>), grid, dim3(64), 0, s, b.state, b.aux, b.actions, b.flags,
                                P.num_envs, RSX_HOT_DIM(P.state_dim, P.row_stride, P.num_envs), step_per_xcd(P, grid, n_steps), n_steps, P, b);
     }
 }
 
 void launch_ssl_quad(const Params& P, const Buffers& b, int n_steps, hipStream_t s) {   // SSL 11v11 scrimmage, four lanes per env, single-step launches (n_steps = 1 | flags)
     const dim3 grid((unsigned)ssl_quad_grid(P.num_envs));
-    hipLaunchKernelGGL((ssl_quad_kernel<MODE_STEP>), grid, dim3(64), 0, s, b.state, b.aux, b.actions, b.flags,
+    rsx_launch((ssl_quad_kernel<MODE_STEP>), grid, dim3(64), 0, s, b.state, b.aux, b.actions, b.flags,
                        P.num_envs, RSX_HOT_DIM(P.state_dim, P.row_stride, P.num_envs), step_per_xcd(P, grid, n_steps), n_steps, P, b);
 }
 

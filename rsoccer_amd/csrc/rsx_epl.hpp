@@ -19,9 +19,6 @@
 #include "rsx_epl_common.hpp"
 
 
-#ifndef RSX_EPL_SCHED_BARRIERS
-#define RSX_EPL_SCHED_BARRIERS 1   // development A/B: 0 lets the scheduler interleave the robots of a lane (more registers)
-#endif
 
 namespace rsx {
 
@@ -139,7 +136,7 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
         wdeg[k] = raw[k][5];
         r[k].om = raw[k][5] * K::deg2rad;
         sincos_f32(r[k].th * K::deg2rad, r[k].s, r[k].c);
-        if (STEP && RSX_EPL_SCHED_BARRIERS) __builtin_amdgcn_sched_barrier(0);
+        if (STEP) __builtin_amdgcn_sched_barrier(0);
     }
     ball.x = rawb[0]; ball.y = rawb[1]; ball.vx = rawb[3]; ball.vy = rawb[4];
     ball.z = rawb[2] - K::r_ball; ball.vz = rawb[5]; ball.om = rawb[6];
@@ -192,7 +189,7 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
             const float qq[2] = {q0[k], q1[k]};
             robot_targets<KIND>(P, r[k], qq);
             if (STEP && k >= 1 && live) { io.st(A, ROW_OU + 2 * k, ou[k][0]); io.st(A, ROW_OU + 2 * k + 1, ou[k][1]); }
-            if (STEP && RSX_EPL_SCHED_BARRIERS) __builtin_amdgcn_sched_barrier(0);   // one robot after the other: interleaving them for ILP costs a wave of occupancy
+            if (STEP) __builtin_amdgcn_sched_barrier(0);   // one robot after the other: interleaving them for ILP costs a wave of occupancy
         }
         float energy = -(fabsf(q0[0]) + fabsf(q1[0]));   // the agent's wheel commands: energy term of the reward
         asm volatile("" : "+v"(energy));   // computed HERE: one value across the physics instead of the two commands
@@ -277,7 +274,7 @@ __device__ __forceinline__ void vss_epl_body(RSX_HOT_ARGS, const Params& P_, con
             if (STEP && live) {   // wire format, robot by robot (an env that resets below writes its rows again)
                 io.st_robot(5 + 6 * k, r[k].x, r[k].y, r[k].th, r[k].vx, r[k].vy, wd);
             }
-            if (STEP && RSX_EPL_SCHED_BARRIERS) __builtin_amdgcn_sched_barrier(0);
+            if (STEP) __builtin_amdgcn_sched_barrier(0);
         }
         ball.z = (K::r_ball + ball.z) - K::r_ball;
         epl_obs_ball(P, ob, ball.x, ball.y, ball.vx, ball.vy);

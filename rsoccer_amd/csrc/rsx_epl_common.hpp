@@ -37,9 +37,6 @@ struct EplIO {
 // one observation row from registers ([B][OD] array, eo = 4 * env): 16-byte stores and a tail.  (Rows are OD * 4 bytes apart:
 // with an odd OD the pieces are only 4-byte aligned — fine for buffer / global accesses on gfx9; twenty-one separate
 // dword stores instead measured 20 % on the whole dribbling step.)
-#ifndef RSX_OBS_AUX
-#define RSX_OBS_AUX 0   // cache-policy bits of the observation stores (development A/B: 2 = nt)
-#endif
 template <int OD>
 __device__ __forceinline__ void epl_store_row(float* rows, const uint32_t eo, const float* ob) {
     const __amdgpu_buffer_rsrc_t O = __builtin_amdgcn_make_buffer_rsrc(rows, 0, -1, 0x00020000);
@@ -50,14 +47,14 @@ __device__ __forceinline__ void epl_store_row(float* rows, const uint32_t eo, co
     for (int i = 0; i < OD / 4; ++i) {
         const u4 v = {__builtin_bit_cast(unsigned, ob[4 * i]), __builtin_bit_cast(unsigned, ob[4 * i + 1]),
                       __builtin_bit_cast(unsigned, ob[4 * i + 2]), __builtin_bit_cast(unsigned, ob[4 * i + 3])};
-        __builtin_amdgcn_raw_buffer_store_b128(v, O, off, 16 * i, RSX_OBS_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(v, O, off, 16 * i, 0);
     }
     constexpr int T = OD / 4 * 4;
     if (OD - T >= 2) {
         const u2 v = {__builtin_bit_cast(unsigned, ob[T]), __builtin_bit_cast(unsigned, ob[T + 1])};
-        __builtin_amdgcn_raw_buffer_store_b64(v, O, off, 4 * T, RSX_OBS_AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(v, O, off, 4 * T, 0);
     }
-    if ((OD - T) & 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ob[OD - 1]), O, off, 4 * (OD - 1), RSX_OBS_AUX);
+    if ((OD - T) & 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ob[OD - 1]), O, off, 4 * (OD - 1), 0);
 }
 
 // contact sums of a sub-step (only when some lane touches something), column = lane; NB bodies (the ball last)

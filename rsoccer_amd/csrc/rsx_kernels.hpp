@@ -71,20 +71,9 @@ struct Buffers {
 #endif
 };
 
-// observation values go straight from the lane that owns them to the row in HBM (scattered 4-byte stores
-// inside the tile's contiguous run of rows) instead of through an LDS staging area + a coalesced copy-out
-// (measured: VSS-v0 4096 envs 10.01 -> 9.74 us per step, 65 536 envs 26.1 -> 25.2; the SSL tasks 0-1 %)
-#ifndef RSX_DIRECT_OBS
-#define RSX_DIRECT_OBS 1
-#endif
-#ifndef RSX_PK_SWEEP
-#define RSX_PK_SWEEP 1
-#endif
-#ifndef RSX_ZB_BALLOT
-#define RSX_ZB_BALLOT 1
-#endif
-#define RSX_DIRECT_OBS_STAGE(L) (RSX_DIRECT_OBS ? 1 : (64 / (L)) * 64)
-
+// (Observation values go straight from the lane that owns them to the row in HBM — scattered 4-byte stores inside the tile's contiguous
+// run of rows — not through an LDS staging area + a coalesced copy-out: measured, VSS-v0 4096 envs 10.01 -> 9.74 us per step,
+// 65 536 envs 26.1 -> 25.2; the SSL tasks 0-1 %.)
 template <int L>
 struct Shared {
     float4 A[64];   // x, y, vx, vy of every body (slot = lane)
@@ -93,12 +82,8 @@ struct Shared {
     float Dq[64];   // SSL robot -> ball record 2: spin change of the ball
     float W[64];    // robots: yaw rate, ball: spin (rad/s) — read on the contact path only
     float2 F[64];   // VSS: held axes of the body in this sweep's snapshot (rsx_body.hpp: held_axes) — read on the contact path only
-#if RSX_PK_SWEEP
     alignas(16) float X[64], Y[64];   // positions once more, [env slot][body]: four partners per 16-byte read for the packed overlap test
-#endif
-    float zb[64 / L];          // ball height per env
     float x0[64 / L][12];      // robot 0 -> reward lane exchange
-    float stage[RSX_DIRECT_OBS_STAGE(L)];  // obs staging, [env][obs_dim], obs_dim <= 64 (only without RSX_DIRECT_OBS)
     float2 draws[64 / L][L < 16 ? 16 : L];  // placement: speculative Philox draws of an ended env
     uint32_t ep[64];           // placement helper: the episode ids of the wave's 64 envs
 #ifdef RSX_TIMING
@@ -110,40 +95,24 @@ struct Shared {
 // pay off was measured per simulator class (single-step launch): SSL takes all three (static
 // defenders 10.7 -> 10.5 us, pass endurance 11.2 -> 10.85); VSS takes the contact sweep (2) and
 // the episode end (4) but not the airborne-ball test (1): 8.55 -> 8.47 us (all three: 8.62).
-#ifndef RSX_VSS_HINTS
-#define RSX_VSS_HINTS 6
-#endif
-#define RSX_RARE_B(KIND, bit, c) (((KIND) == RSX_KIND_SSL || (RSX_VSS_HINTS & (bit))) ? __builtin_expect(!!(c), 0) : !!(c))
+#define RSX_RARE_B(KIND, bit, c) (((KIND) == RSX_KIND_SSL || (6 & (bit))) ? __builtin_expect(!!(c), 0) : !!(c))
 
 // Addresses into the [rows][B] arrays on the hot paths: a uniform base pointer (scalar registers) + ONE 32-bit BYTE offset per
 // lane — the global_load / global_store "saddr" form, no 64-bit vector multiply-adds and shifts per access.  The host refuses
 // batches whose arrays would reach 4 GB (rsx_api.hip: RSX_ERR_ARG at create / attach).
-#ifndef RSX_LATE_PARAMS
-#define RSX_LATE_PARAMS 1   // development A/B
-#endif
-#ifndef RSX_IX32
-#define RSX_IX32 1   // development A/B: 0 = 64-bit offsets
-#endif
-#if RSX_IX32
 typedef uint32_t ix_t;
-#else
-typedef size_t ix_t;
-#endif
 __device__ __forceinline__ float& at_byte(float* base, const ix_t off) { return *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off); }
 __device__ __forceinline__ const float& at_byte(const float* base, const ix_t off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + off); }
 
 // Which lane holds body j of the wave's env g (and which LDS slot: slot = lane).  Body-major (lane = j * G + g: the G lanes
 // that own "body j" of neighbouring envs are adjacent, every row access is G * 4 contiguous bytes) for L >= 16; env-major
-// (lane = g * L + j: an env's eight bodies are eight adjacent lanes) for L == 8 — measured -1 % at 4096 envs, +2-3 % at 65 536
-// (RSX_ENV_MAJOR=0: body-major everywhere).  Partners are read through the LDS snapshot in every width (reading them through DPP
+// (lane = g * L + j: an env's eight bodies are eight adjacent lanes) for L == 8 — measured -1 % at 4096 envs, +2-3 % at 65 536.
+// Partners are read through the LDS snapshot in every width (reading them through DPP
 // row shifts was measured and dropped: profiles/LABBOOK.md).
-#ifndef RSX_ENV_MAJOR
-#define RSX_ENV_MAJOR 1
-#endif
 template <int L>
 struct LaneMap {
     static constexpr int G = 64 / L;
-    static constexpr bool EM = RSX_ENV_MAJOR != 0 && L == 8;
+    static constexpr bool EM = L == 8;
     static __device__ __forceinline__ int slot(const int j, const int g) { return EM ? g * L + j : j * G + g; }
     static __device__ __forceinline__ int body(const int lane) { return EM ? lane % L : lane / G; }
     static __device__ __forceinline__ int env(const int lane) { return EM ? lane / L : lane % G; }
@@ -209,7 +178,6 @@ __device__ __forceinline__ bool vss_sweep_loop(const Params& P, Body& o, const i
 // u[j] = bits(|p_j - p_o|^2) - 1 for the SLOTS bodies of the lane's env, two partners per packed-FP32 instruction
 // (v_pk_add / v_pk_mul / v_pk_fma are IEEE per component: the same bits as the scalar form), positions from the
 // [env][body] copies in LDS (one 16-byte read = four partners).
-#if RSX_PK_SWEEP
 struct NoFill { __device__ __forceinline__ void operator()() const {} };
 // `fill`: work that does not depend on the partners' positions, issued between the LDS reads and their first use (the reads take
 // ~100 cycles to come back and a lone wave has nothing else to run meanwhile)
@@ -240,7 +208,6 @@ __device__ __forceinline__ void overlap_keys_packed(const Shared<L>& sh, const i
         }
     }
 }
-#endif
 
 struct BallOverride { bool ovr, okick; float ovx, ovy, ovz; };
 
@@ -265,18 +232,7 @@ __device__ __forceinline__ bool ssl_sweep(const Params& P, Body& o, const int N,
         unsigned todo = 0;
         if (NRX) {
             uint32_t u[NRX ? NRX : 1];   // exact integer form of 0 < d2 < rs_rr^2, see the VSS sweep
-#if RSX_PK_SWEEP
             overlap_keys_packed<(NRX ? NRX : 1), L>(sh, g, o.x, o.y, u);
-#else
-            float4 oth[NRX ? NRX : 1];  // all reads in flight together, one wait
-#pragma unroll
-            for (int j = 0; j < NRX; ++j) oth[j] = sh.A[LaneMap<L>::slot(j, g)];
-#pragma unroll
-            for (int j = 0; j < NRX; ++j) {
-                float dx = oth[j].x - o.x, dy = oth[j].y - o.y;
-                u[j] = __float_as_uint(fma_(dx, dx, dy * dy)) - 1u;
-            }
-#endif
             uint32_t um = u[0];
 #pragma unroll
             for (int j = 1; j < NRX; ++j) um = min(um, u[j]);
@@ -464,15 +420,10 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
         // over the corrected snapshot for the envs in which some pair overlapped by more than pen2
         // (impacts at speed, jammed piles; resting contacts stay far below).  The second sweep is
         // the same loop body again: the instructions are in the cache (a separate copy never is) ----
-#if RSX_ZB_BALLOT
         // is the env's ball low enough to be touched?  One ballot of the ball lanes' answer, each lane picks its env's bit
         // (was: the height through LDS — a write, a dependent read and its wait in every sub-step)
         const unsigned long long lowm = __ballot(is_ball && o.z < K::robot_h);
         bool ball_low = ((lowm >> (LaneMap<L>::slot(N, g))) & 1ull) != 0;
-#else
-        if (is_ball) sh.zb[g] = o.z;
-        bool ball_low = true;
-#endif
         bool active = is_robot || is_ball;   // lanes whose env takes part in the current sweep
         BallOverride bo{false, false, 0.0f, 0.0f, 0.0f};
         for (int sweep = 0;; ++sweep) {
@@ -480,9 +431,7 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
             if (active) {
                 sh.A[lane] = make_float4(o.x, o.y, o.vx, o.vy);
                 sh.W[lane] = o.om;   // yaw rate / spin: read on the contact path only
-#if RSX_PK_SWEEP
                 sh.X[g * L + b] = o.x; sh.Y[g * L + b] = o.y;
-#endif
             }
             wave_sync();
             // VSS: the held axes of this snapshot are computed and published BEHIND the exchange — the arithmetic fills the wait for the
@@ -493,9 +442,6 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
             auto publish_held = [&]() {
                 if constexpr (K::held) { fo = held_axes<KIND>(P, o.x, o.y, is_robot); sh.F[lane] = fo; }
             };
-#if !RSX_ZB_BALLOT
-            if (sweep == 0) ball_low = sh.zb[g] < K::robot_h;
-#endif
             bool deep = false;   // this lane saw a deep contact
             bool wallp = false;  // ... a touching robot - robot pair with a wall-blocked axis (model v2: wall_shares)
 
@@ -503,11 +449,6 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                 // every pair is circle-circle; only the constants depend on the pair type
                 if (active) {
                     if (NR) {
-#if !RSX_PK_SWEEP
-                        float4 oth[NR + 1];  // all reads in flight together, one wait
-#pragma unroll
-                        for (int j = 0; j <= NR; ++j) oth[j] = sh.A[LaneMap<L>::slot(j, g)];
-#endif
                         // Overlap test of the whole sweep, exact and with ONE compare per partner class:
                         // d2 is a sum of squares (>= +0), and non-negative floats order like their bit
                         // patterns, so with u = bits(d2) - 1 (d2 == 0, the lane's own slot, wraps to
@@ -517,16 +458,8 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
                         constexpr uint32_t T_RR = __builtin_bit_cast(uint32_t, K::rs_rr2) - 1u;
                         constexpr uint32_t T_RB = __builtin_bit_cast(uint32_t, K::rs_rb2) - 1u;
                         uint32_t u[NR + 1];
-#if RSX_PK_SWEEP
                         if constexpr (K::held) overlap_keys_packed<NR + 1, L>(sh, g, o.x, o.y, u, publish_held);
                         else overlap_keys_packed<NR + 1, L>(sh, g, o.x, o.y, u);
-#else
-#pragma unroll
-                        for (int j = 0; j <= NR; ++j) {
-                            float dx = oth[j].x - o.x, dy = oth[j].y - o.y;
-                            u[j] = __float_as_uint(fma_(dx, dx, dy * dy)) - 1u;
-                        }
-#endif
                         uint32_t um = u[0];
 #pragma unroll
                         for (int j = 1; j < NR; ++j) um = min(um, u[j]);
@@ -599,11 +532,7 @@ __device__ __forceinline__ void physics(const Params& P, Body& o, const int b, c
             // second sweep for the envs in which some pair was deep: one ballot, usually no lane; a third and a fourth one for the
             // envs in which the last sweep also saw a wall pair (model v2: piles pressed against a wall)
             const unsigned long long dmask = __ballot(deep);
-#ifdef RSX_V2_TWO_SWEEPS
-            if (sweep == 1 || !RSX_RARE_B(KIND, 2, dmask != 0)) break;
-#else
             if (sweep == 3 || !RSX_RARE_B(KIND, 2, dmask != 0)) break;
-#endif
             bool again = (L == 64 ? dmask : (dmask & env_lane_mask<L>(g))) != 0;
             if (sweep >= 1) {
                 const unsigned long long wmask = __ballot(wallp);
@@ -1444,7 +1373,6 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
     // A multi-step launch is short of SGPRs, not of start-up latency: there the preloaded copies
     // are left dead and everything is fetched from the kernarg segment when it is needed.
     constexpr bool HOT = MODE != MODE_ROLLOUT;
-    constexpr bool DOBS = RSX_DIRECT_OBS != 0;
     Params P = P_;
     Buffers bufs = bufs_;
     if (HOT) {
@@ -1509,15 +1437,12 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
     // ---- load ----
     Body o; float od, wd, wheels[4];
     const RawBody raw = load_raw<KIND>(P, bufs.state, e, b, is_robot, is_ball);
-#ifndef RSX_CODE_PREFETCH
-#define RSX_CODE_PREFETCH 1   // development A/B
-#endif
     // Every launch starts with a cold instruction cache (the first pass through the code costs ~1 k cycles more than the later ones,
     // profiles/r04_timeline_4096.txt).  The VSS single-step kernels touch the 8 KB of their own code that follow the entry point with
     // ONE data load — a lane per 128-byte line; it lands with the state loads, long before the wave gets there — so that those
     // instruction fetches find their lines in the L2: VSS-v0 at 4096 envs 9.02 -> 8.88 us per step (three interleaved rounds).
     // Measured per kernel: later windows (+4, +8, +12 KB) or 16 / 24 KB gain nothing; the SSL kernels lose (11v11 +4 %, 1v6 +0.5 %).
-    constexpr bool CODE_PF = RSX_CODE_PREFETCH != 0 && KIND == RSX_KIND_VSS && MODE == MODE_STEP;
+    constexpr bool CODE_PF = KIND == RSX_KIND_VSS && MODE == MODE_STEP;
     uint32_t code_touch = 0;
     if (CODE_PF) {
         unsigned long long pc;
@@ -1610,7 +1535,7 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
                     ep_ret = 0.0f; prev_pot = 0.0f;
                 }
             }
-            write_obs<KIND, TASK>(P, DOBS ? bufs.obs + (size_t)e * OD : sh.stage + g * OD, b, is_robot, is_ball, o.x, o.y, o.vx, o.vy, o.s, o.c, wd, o.ir, prev_pot);
+            write_obs<KIND, TASK>(P, bufs.obs + (size_t)e * OD, b, is_robot, is_ball, o.x, o.y, o.vx, o.vy, o.s, o.c, wd, o.ir, prev_pot);
             wave_sync();
             ended = false;
         } else if (mode == 1) {
@@ -1671,8 +1596,7 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
             RSX_STAMP(2);
             physics<KIND, L, NR>(P, o, b, g, live, sh);
             RSX_STAMP(3);
-#if RSX_LATE_PARAMS
-            if (MODE == MODE_STEP && (KIND == RSX_KIND_SSL || RSX_LATE_PARAMS > 1)) {
+            if (MODE == MODE_STEP && KIND == RSX_KIND_SSL) {
                 // Single-step launches of the SSL tasks: what the rest of the step reads of the parameter block is fetched from the kernarg
                 // segment HERE, behind an opaque pointer, instead of being loaded at the kernel's entry and parked in VGPR lanes across
                 // the physics (these kernels run out of scalar registers: ~40 v_writelane at entry, ~60 v_readlane after the physics)
@@ -1687,7 +1611,6 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
                 P = __builtin_bit_cast(Params, raw);
                 RSX_UNPACK_HOT(P);
             }
-#endif
 
             // ---- wire-format values, observation, reward ----
             if (is_robot) {
@@ -1702,7 +1625,7 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
             } else if (is_ball) {
                 o.z = (K::r_ball + o.z) - K::r_ball;  // height goes through the wire format too
             }
-            write_obs<KIND, TASK>(P, DOBS ? bufs.obs + (size_t)e * OD : sh.stage + g * OD, b, is_robot, is_ball, o.x, o.y, o.vx, o.vy, o.s, o.c, wd, o.ir, obs_ts);
+            write_obs<KIND, TASK>(P, bufs.obs + (size_t)e * OD, b, is_robot, is_ball, o.x, o.y, o.vx, o.vy, o.s, o.c, wd, o.ir, obs_ts);
             // what the reward lane (the ball's) needs from the robots' lanes
             if (is_robot && b == 0) {
                 float* xr = sh.x0[g];
@@ -1746,8 +1669,7 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
         // ---- episode end: same-step auto-reset (or reset()) ----
         if (RSX_RARE_B(KIND, 4, __any(ended))) {
             if (ended && mode == 0) {  // terminal observation
-                if (DOBS) write_obs<KIND, TASK>(P, bufs.final_obs + (size_t)e * OD, b, is_robot, is_ball, o.x, o.y, o.vx, o.vy, o.s, o.c, wd, o.ir, obs_ts);
-                else for (int i = b; i < OD; i += L) bufs.final_obs[(size_t)e * OD + i] = sh.stage[g * OD + i];
+                write_obs<KIND, TASK>(P, bufs.final_obs + (size_t)e * OD, b, is_robot, is_ball, o.x, o.y, o.vx, o.vy, o.s, o.c, wd, o.ir, obs_ts);
             }
             if (ended && mode == 0) episode += 1;   // every lane of the env: the new episode's id
             if (KIND == RSX_KIND_VSS) {
@@ -1828,34 +1750,12 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
                     wheels[0] = wheels[1] = wheels[2] = wheels[3] = 0.0f;
                     if (is_robot) { o.th = od; sincos_f32(o.th * K::deg2rad, o.s, o.c); }
                 }
-                write_obs<KIND, TASK>(P, DOBS ? bufs.obs + (size_t)e * OD : sh.stage + g * OD, b, is_robot, is_ball, o.x, o.y, o.vx, o.vy, o.s, o.c, wd, 0, 0.0f);
+                write_obs<KIND, TASK>(P, bufs.obs + (size_t)e * OD, b, is_robot, is_ball, o.x, o.y, o.vx, o.vy, o.s, o.c, wd, 0, 0.0f);
             }
             wave_sync();
             RSX_STAMP(18);
         }
 
-        // ---- observation out, coalesced: the tile's G rows are one contiguous run ----
-        if (!DOBS) {
-            // single-step launches: 32-bit offsets (in floats: [B][OD] stays below 2^30 floats, host check); multi-step launches keep
-            // the 64-bit pointer they hoist out of the step loop (measured: the 32-bit form costs them 2-4 %)
-            typedef typename std::conditional<MODE == MODE_STEP, ix_t, size_t>::type ox_t;
-            const ox_t base = (ox_t)tile * (ox_t)(G * OD);
-            const ox_t lim = (ox_t)P.num_envs * (ox_t)OD;
-            if (OD_C) {  // all staging reads in flight together, then the stores
-                constexpr int NCH = (G * (OD_C ? OD_C : 1) + 63) / 64;
-                float v[NCH];
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) { const int i = lane + 64 * c; v[c] = i < G * OD_C ? sh.stage[i] : 0.0f; }
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    const int i = lane + 64 * c;
-                    if (i < G * OD_C && base + (ox_t)i < lim) *reinterpret_cast<float*>(reinterpret_cast<char*>(bufs.obs) + (ox_t)4 * (base + (ox_t)i)) = v[c];
-                }
-            } else {
-                for (int i = lane; i < G * OD; i += 64)
-                    if (base + (ox_t)i < lim) *reinterpret_cast<float*>(reinterpret_cast<char*>(bufs.obs) + (ox_t)4 * (base + (ox_t)i)) = sh.stage[i];
-            }
-        }
         wave_sync();
     }
 

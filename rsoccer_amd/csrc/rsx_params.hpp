@@ -106,11 +106,7 @@ struct KC {
     static constexpr float kw = (float)(2.0 / 7.0), spin_c = (float)(2.5 / D::r_ball);
     static constexpr float ope_wb = (float)(1.0 + D::e_wb), dck = (float)D::dck;
     // overlap beyond which an env gets the second contact sweep of a sub-step [build]
-#ifdef RSX_PEN2
-    static constexpr float pen2 = (float)(RSX_PEN2);   // model experiments only
-#else
     static constexpr float pen2 = 0.005f;
-#endif
 };
 
 // per-task literals

@@ -17,9 +17,6 @@
 #pragma once
 #include "rsx_kernels.hpp"
 
-#ifndef RSX_QUAD_LATE_PARAMS
-#define RSX_QUAD_LATE_PARAMS 1   // development A/B
-#endif
 #ifndef RSX_QUAD_WAVES
 #define RSX_QUAD_WAVES 3   // waves per SIMD the kernel is compiled for
 #endif
@@ -481,8 +478,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
         }
     }
 
-#if RSX_QUAD_LATE_PARAMS
-    {   // what the rest of the step reads of the parameter block: fetched from the kernarg segment here instead of parked in VGPR lanes across the physics (rsx_kernels.hpp, RSX_LATE_PARAMS)
+    {   // what the rest of the step reads of the parameter block: fetched from the kernarg segment here instead of parked in VGPR lanes across the physics (like the SSL lane-group kernels, rsx_kernels.hpp)
         typedef const __attribute__((address_space(4))) uint32_t* kw_t;
         constexpr size_t KOFF = RSX_PARAMS_KERNARG_OFFSET;   // rsx_kernels.hpp, tied to RSX_HOT_ARGS by a static_assert
         kw_t pk = (kw_t)__builtin_amdgcn_kernarg_segment_ptr() + KOFF / 4;
@@ -493,7 +489,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
         P = __builtin_bit_cast(Params, raww);
         RSX_UNPACK_HOT(P);
     }
-#endif
     // ---- wire-format values, state rows, observation ----
     if (bl) {   // episode bookkeeping: fetched now (nothing of it is live during the physics)
         steps = __float_as_int(ld(A, ROW_STEPS * B4, eo));
@@ -511,12 +506,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RSX_QUAD_WAV
             for (int m = 0; m < R; ++m) {
                 if (real(m)) {
                     const u2 v = {__builtin_bit_cast(unsigned, clampf(r[m].x * P.inv_max_pos, -1.2f, 1.2f)), __builtin_bit_cast(unsigned, clampf(r[m].y * P.inv_max_pos, -1.2f, 1.2f))};
-                    __builtin_amdgcn_raw_buffer_store_b64(v, rows, (int)oo, 8 * m, RSX_OBS_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b64(v, rows, (int)oo, 8 * m, 0);
                 }
             }
             if (bl) {
                 const u2 v = {__builtin_bit_cast(unsigned, clampf(ball.x * P.inv_max_pos, -1.2f, 1.2f)), __builtin_bit_cast(unsigned, clampf(ball.y * P.inv_max_pos, -1.2f, 1.2f))};
-                __builtin_amdgcn_raw_buffer_store_b64(v, rows, (int)((uint32_t)Q_OD * eo), 0, RSX_OBS_AUX);
+                __builtin_amdgcn_raw_buffer_store_b64(v, rows, (int)((uint32_t)Q_OD * eo), 0, 0);
             }
         }
     };
