@@ -297,8 +297,17 @@ int rsx_task_rollout(rsx_sim* h, int n, void* stream);
  *   - rsx_task_checkpoint_save / _load carry the counter in either mode;
  *   - RSX_DEBUG_FINITE=1 (a synchronous scan) makes captured stepping calls fail with RSX_ERR_STATE;
  *   - calls that keep host-side state stay uncapturable and say so: rsx_step_dev_flip (buffer roles).  The raw
- *     rsx_step_dev / rsx_reset_dev launches hold no host state and can be captured as they are. */
+ *     rsx_step_dev / rsx_reset_dev launches hold no host state and can be captured as they are;
+ *   - HIP's per-thread last-error slot: kernel launches of this library report through their own return values and never read or
+ *     clear the slot (a caller's pending error stays the caller's) — with ONE exception: rsx_task_enable_capture clears it.  A
+ *     capture that a stepping call refused is usually aborted by the caller's framework, and the aborted capture leaves
+ *     `invalid argument` behind for the next capture to trip over (torch.cuda.graph does); the call that prepares the next
+ *     attempt is where it is dropped. */
 int rsx_task_enable_capture(rsx_sim* h, void* stream);
+/* Reads AND clears the calling thread's pending HIP error; returns its hipError_t value (0 = none was pending).  For callers that
+ * recover from an aborted capture without going through rsx_task_enable_capture (e.g. hook-written envs on the raw step, whose
+ * rsx_step_dev_flip refused to be captured). */
+int rsx_drop_pending_hip_error(void);
 /* fused steps this handle has taken since attach (the counter above).  Device-keyed handles: synchronises `stream`. */
 int rsx_task_tick(rsx_sim* h, uint32_t* out, void* stream);
 

@@ -36,7 +36,7 @@ SYMBOLS = (
     "rsx_task_view_get", "rsx_task_layout", "rsx_task_placement_cache_stats", "rsx_task_reset", "rsx_task_reset_to", "rsx_task_step",
     "rsx_task_step_n", "rsx_task_rollout", "rsx_read_metrics", "rsx_metrics_fold", "rsx_check_finite",
     "rsx_task_checkpoint_size", "rsx_task_checkpoint_save", "rsx_task_checkpoint_load",
-    "rsx_task_enable_capture", "rsx_task_tick",
+    "rsx_task_enable_capture", "rsx_task_tick", "rsx_drop_pending_hip_error",
 )
 
 
@@ -112,10 +112,16 @@ def load():
     lib.rsx_check_finite.argtypes = [vp, C.POINTER(C.c_int64), vp]
     lib.rsx_task_enable_capture.argtypes = [vp, vp]
     lib.rsx_task_tick.argtypes = [vp, C.POINTER(C.c_uint32), vp]
+    lib.rsx_drop_pending_hip_error.argtypes = []
     if lib.rsx_abi_version() != 6:
         raise RsxError("librsx_hip.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+def drop_pending_hip_error():
+    """reads and clears the thread's pending HIP error (rsx_drop_pending_hip_error): what an aborted stream capture leaves behind"""
+    return int(load().rsx_drop_pending_hip_error())
 
 
 def _chk(rc):

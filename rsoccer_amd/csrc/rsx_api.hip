@@ -99,6 +99,7 @@ struct rsx_sim {
     char* arena_task = nullptr;  // aux | obs | final_obs | flags | actions | metrics
     float* d_state = nullptr;
     float* d_state_alt = nullptr;   // second state buffer of rsx_step_dev_flip (allocated on first use)
+    float* alt_alloc = nullptr;     // ... the allocation behind it: d_state and d_state_alt trade places at every flip, this is what is freed
     float* d_cmds = nullptr;
     float *d_aux = nullptr, *d_obs = nullptr, *d_final_obs = nullptr, *d_actions = nullptr;
     uint8_t* d_flags = nullptr;
@@ -452,8 +453,8 @@ void free_all(rsx_sim* h) {
     if (h->wire_cmds) (void)hipHostFree(h->wire_cmds);
     if (h->wire_state) (void)hipHostFree(h->wire_state);
     h->wire_cmds = h->wire_state = nullptr;
-    if (h->d_state_alt) (void)hipFree(h->d_state_alt);
-    h->d_state_alt = nullptr;
+    if (h->alt_alloc) (void)hipFree(h->alt_alloc);   // (not d_state_alt: after an odd number of flips that is a pointer INTO arena_sim)
+    h->alt_alloc = h->d_state_alt = nullptr;
     if (h->d_check) (void)hipFree(h->d_check);
     h->d_check = nullptr;
     if (h->arena_sim) (void)hipFree(h->arena_sim);
@@ -784,7 +785,8 @@ int rsx_step_dev(rsx_sim* h, void* stream) {
 static int ensure_alt(rsx_sim* h) {
     if (h->d_state_alt) return RSX_OK;
     const size_t sbytes = (size_t)(h->P.state_dim + X_ROWS) * h->P.row_stride * sizeof(float);
-    HIP_TRY(hipMalloc((void**)&h->d_state_alt, sbytes));
+    HIP_TRY(hipMalloc((void**)&h->alt_alloc, sbytes));
+    h->d_state_alt = h->alt_alloc;
     HIP_TRY(hipMemset(h->d_state_alt, 0, sbytes));
     HIP_TRY(hipDeviceSynchronize());
     return RSX_OK;
@@ -918,8 +920,14 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
     return RSX_OK;
 }
 
+int rsx_drop_pending_hip_error(void) { return (int)hipGetLastError(); }
+
 int rsx_task_enable_capture(rsx_sim* h, void* stream) {
     RSX_ENTER_TASK(h);
+    // The one place where the thread's pending HIP error is dropped: the usual way to get here is a capture attempt that this library
+    // refused (host-keyed handle) and that the caller's framework then aborted — which leaves `invalid argument` in the slot for the
+    // NEXT capture to trip over (torch.cuda.graph does).  A set-up call, not a stepping path; rsx.h says so.
+    (void)hipGetLastError();
     if (h->tick_dev) return RSX_OK;
     hipStream_t s = (hipStream_t)stream;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;

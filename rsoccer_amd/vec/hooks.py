@@ -107,6 +107,7 @@ class _VecBaseEnv:
             raise RuntimeError("enable_graph_capture() needs device-side placement: reset() first, with _get_initial_positions() returning "
                                "device tensors (host-array placement costs a synchronisation per episode end and cannot be captured)")
         self._graph_mode = True
+        _lib.drop_pending_hip_error()   # an earlier capture attempt that was refused and aborted leaves one behind (rsx.h)
         if self.keep_last_frame and self.last_frame is None:
             self.last_frame = self._other
             self._other.state.copy_(self.frame.state)

@@ -116,7 +116,11 @@ def test_create_destroy_cycles_leave_device_memory_unchanged():
             sim.task_step(None, s)
         if k % 11 == 0:
             sim.state_buffers()           # allocates the second state buffer
+            for _ in range(1 + k % 2):    # ... whose role the flips trade with the first one's: an odd number of flips leaves the
+                sim.step_dev_flip(s)      # handle's CURRENT buffer in the second allocation (rsx_destroy frees the allocations, not the roles)
+            torch.cuda.synchronize()
         sim.close()
+        assert L.drop_pending_hip_error() == 0, k     # nothing this library did left an error in the thread's HIP slot
 
     for k in range(20):                   # warm the allocator's pools
         cycle(k)
