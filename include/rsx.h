@@ -240,6 +240,13 @@ int rsx_step_dev_random(rsx_sim* h, int n, uint64_t seed, uint32_t first_tick, v
 int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base,
                     int max_episode_steps);
 int rsx_task_view_get(rsx_sim* h, rsx_task_view* out);
+/* Start over with another seed (ABI 6): afterwards the handle is what a fresh rsx_task_attach(task, seed, same env_id_base, same
+ * max_episode_steps) would have left — every random stream re-keyed, step counter 0, episode ids, per-env scalars, metrics and
+ * placement cache cleared; the buffers (and every pointer of rsx_task_view) stay where they are; a handle switched by
+ * rsx_task_enable_capture stays switched.  The next call must be rsx_task_reset / rsx_task_reset_to.  Stream-ordered; not
+ * capturable (it changes host state).  What `reset(seed=...)` of a gymnasium-style vector env maps to (README.md:116-133 seeds
+ * through `env.reset(seed=...)`; the reference's own tasks ignore it: SURVEY.md appendix D-1). */
+int rsx_task_reseed(rsx_sim* h, uint64_t seed, void* stream);
 /* Which tile layout steps this handle's envs (chosen at attach from task and batch size; results are identical in all):
  * "8-lanes-per-env" / "16-..." / "32-..." / "64-...", "32-lanes-per-env-large-batch", "one-lane-per-env",
  * "four-lanes-per-env".  NUL-terminated into out[n] — for profiles and benchmark lines, so that nothing outside the

@@ -33,7 +33,7 @@ SYMBOLS = (
     "rsx_get_field_params", "rsx_reset", "rsx_step", "rsx_get_state", "rsx_step_state", "rsx_wire_buffers", "rsx_step_wire", "rsx_set_state",
     "rsx_get_state_full", "rsx_dev_view_get", "rsx_step_dev", "rsx_step_dev_random", "rsx_step_dev_flip", "rsx_state_buffers",
     "rsx_reset_dev", "rsx_task_attach",
-    "rsx_task_view_get", "rsx_task_layout", "rsx_task_placement_cache_stats", "rsx_task_reset", "rsx_task_reset_to", "rsx_task_step",
+    "rsx_task_view_get", "rsx_task_reseed", "rsx_task_layout", "rsx_task_placement_cache_stats", "rsx_task_reset", "rsx_task_reset_to", "rsx_task_step",
     "rsx_task_step_n", "rsx_task_rollout", "rsx_read_metrics", "rsx_metrics_fold", "rsx_check_finite",
     "rsx_task_checkpoint_size", "rsx_task_checkpoint_save", "rsx_task_checkpoint_load",
     "rsx_task_enable_capture", "rsx_task_tick", "rsx_drop_pending_hip_error",
@@ -99,6 +99,7 @@ def load():
     lib.rsx_reset_dev.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.rsx_task_attach.argtypes = [vp, ip, C.c_uint64, C.c_uint64, ip]
     lib.rsx_task_view_get.argtypes = [vp, C.POINTER(TaskView)]
+    lib.rsx_task_reseed.argtypes = [vp, C.c_uint64, vp]
     lib.rsx_task_reset.argtypes = [vp, vp]
     lib.rsx_task_reset_to.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.rsx_task_step.argtypes = [vp, vp, vp]
@@ -360,6 +361,10 @@ class Sim:
             actions=self._tensor(t.actions, (B, t.act_dim), "<f4"),
             metrics=self._tensor(t.metrics, (N_METRICS,), "<i8"),
         )
+
+    def task_reseed(self, seed, stream=None):
+        """start over with another seed (rsx_task_reseed): the handle becomes what a fresh attach with that seed would be; reset next"""
+        _chk(self._lib.rsx_task_reseed(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF, self._stream(stream)))
 
     def task_reset(self, stream=None):
         _chk(self._lib.rsx_task_reset(self._h, self._stream(stream)))

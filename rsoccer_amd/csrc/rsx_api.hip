@@ -128,6 +128,7 @@ struct rsx_sim {
     bool host_state_valid = false;
     bool host_state_cache = true;
     bool task_ready = false;   // a reset has opened the first episode
+    size_t arena_task_bytes = 0, pcache_bytes = 0;   // sizes of arena_task and of the placement cache inside it (rsx_task_reseed re-initialises them)
     uint32_t tick = 0;                        // fused steps taken since attach (key of the per-step draws); stale once tick_dev is set
     // rsx_task_enable_capture: the step counter lives in device memory (one slot per workgroup behind the metrics vector,
     // rsx_kernels.hpp: step_tick) so that captured stepping launches advance it when a graph replays them
@@ -869,6 +870,7 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
     const size_t total = n_aux + 2 * n_obs + n_flags + n_act + n_met + n_slots + n_pc + n_pcs;
     HIP_TRY(hipMalloc((void**)&h->arena_task, total));
     HIP_TRY(hipMemset(h->arena_task, 0, total));
+    h->arena_task_bytes = total; h->pcache_bytes = n_pc;
     char* p = h->arena_task;
     h->d_aux = (float*)p; p += n_aux;
     h->d_obs = (float*)p; p += n_obs;
@@ -921,6 +923,23 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
 }
 
 int rsx_drop_pending_hip_error(void) { return (int)hipGetLastError(); }
+
+int rsx_task_reseed(rsx_sim* h, uint64_t seed, void* stream) {
+    RSX_ENTER_TASK(h);
+    hipStream_t s = (hipStream_t)stream;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) (void)hipGetLastError();
+    else if (cs != hipStreamCaptureStatusNone) return fail(RSX_ERR_STATE, "rsx_task_reseed changes host state (seed, step counter) and cannot be captured");
+    // what rsx_task_attach leaves behind, with the new key: every per-env buffer and counter cleared, episode ids at 0xFFFFFFFF,
+    // placement cache empty, step counter 0 (device-keyed handles: every slot), no episode open
+    HIP_TRY(hipMemsetAsync(h->arena_task, 0, h->arena_task_bytes, s));
+    if (h->d_pcache) HIP_TRY(hipMemsetAsync(h->d_pcache, 0xFF, h->pcache_bytes, s));
+    HIP_TRY(hipMemsetAsync(h->d_aux + (size_t)ROW_EPISODE * h->P.row_stride, 0xFF, (size_t)h->P.num_envs * sizeof(uint32_t), s));
+    h->P.key0 = (uint32_t)seed; h->P.key1 = (uint32_t)(seed >> 32);
+    h->tick = 0; h->P.tick_base = 0;
+    h->task_ready = false;
+    return RSX_OK;
+}
 
 int rsx_task_enable_capture(rsx_sim* h, void* stream) {
     RSX_ENTER_TASK(h);

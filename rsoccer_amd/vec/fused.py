@@ -80,8 +80,12 @@ class VecFusedEnv:
         return dict(self._info_views)
 
     def reset(self, *, seed=None, options=None):
-        """New random placement for every env.  ``seed`` is accepted for API compatibility; the
-        random streams are fixed by the constructor's ``seed`` (episode counters advance)."""
+        """New random placement for every env.  ``seed=None`` (the usual call): the random streams chosen at construction go on
+        (episode counters advance).  ``seed=<int>``: start over — every random stream (placements, OU noise, random actions) is
+        re-keyed and all counters cleared, exactly as if the env had just been constructed with that seed
+        (``rsx_task_reseed``; env ``i`` keeps its global id ``env_id_base + i``, which distinguishes the envs' streams)."""
+        if seed is not None:
+            self.sim.task_reseed(int(seed), self._stream())
         self.sim.task_reset(self._stream())
         return self._t["obs"], {}
 

@@ -436,3 +436,42 @@ def test_vec_env_checkpoint_restore_continues_the_same_run():
             assert torch.equal(x, y), t
     assert b.metrics() == ma and ma["episodes"] >= 48 * 2
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("name,capture", [("VecVSSEnv", False), ("VecSSLStaticDefendersEnv", False), ("VecSSLContestedPossessionEnv", True)])
+def test_vec_env_reset_with_a_seed_starts_over_like_a_fresh_env(name, capture):
+    """``reset(seed=s)`` of a fused vector env (gymnasium's way of seeding, README.md:116-133): the handle starts over as if it had just
+    been constructed with seed ``s`` (rsx_task_reseed) — placements, OU noise, random actions, counters, metrics; ``reset()`` without a
+    seed goes on with the streams it has.  Also on a handle switched to device-keyed stepping (graph capture)."""
+    import torch
+    from rsoccer_amd import vec
+    cls = getattr(vec, name)
+    B = 300
+    used = cls(B, seed=5)
+    if capture:
+        used.enable_graph_capture()
+    used.reset()
+    used.step_random(37)                                  # some history under another seed
+    torch.cuda.synchronize()
+    assert used.metrics()["env_steps"] == B * 37
+    o_used, _ = used.reset(seed=11)
+    fresh = cls(B, seed=11)
+    if capture:
+        fresh.enable_graph_capture()
+    o_fresh, _ = fresh.reset()
+    assert torch.equal(o_used, o_fresh)
+    for _ in range(3):
+        used.step_random(20); fresh.step_random(20)
+        a = torch.rand(B, used.sim.act_dim, device="cuda") * 2 - 1
+        ou, ru, tu, tru, _ = used.step(a)
+        of, rf, tf, trf, _ = fresh.step(a)
+        assert torch.equal(ou, of) and torch.equal(ru, rf) and torch.equal(tu, tf) and torch.equal(tru, trf)
+    torch.cuda.synchronize()
+    assert np.array_equal(used.sim.get_state_full(), fresh.sim.get_state_full())
+    assert used.metrics() == fresh.metrics()
+    assert used.sim.task_tick() == fresh.sim.task_tick() == 63
+    # without a seed the run goes on: a second env on the same seed that is reset() twice differs from one reset(seed=) twice
+    o2, _ = used.reset()
+    o3, _ = fresh.reset(seed=11)
+    assert not torch.equal(o2, o3) or name == "VecSSLDribblingEnv"
+    used.close(); fresh.close()
