@@ -170,3 +170,48 @@ def test_bench_eight_rank_rehearsal_with_the_drivers_flags(fail):
     assert steps_taken >= 25
     m = _single_handle_metrics(8 * 4096, steps_taken, 0)
     assert counted == int(m[0]) and line["episodes"] == int(m[1])
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_torchrun(n, args, env=None, timeout=900):
+    """the command line the driver uses for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`"""
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), BENCH, "--gpus", str(n)] + args
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=e, cwd=ROOT)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    return res, (json.loads(lines[-1]) if lines else None)
+
+
+def test_the_drivers_torchrun_command_line_dry_run():
+    """CPU: the driver's own launch form for N > 1 (torch.distributed.run around bench.py, not bench.py's self-launch) brings up the
+    ranks, shards the env ids and prints ONE line from rank 0"""
+    res, line = _run_torchrun(4, ["--steps", "6", "--warmup", "2", "--envs", "17", "--dry-run"])
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    assert sum(ln.startswith("{") for ln in res.stdout.splitlines()) == 1
+    assert line["n_gpus"] == 4 and line["env_steps_counted"] == 4 * 17 * 6 and line["env_id_bases_sum"] == 17 * (0 + 1 + 2 + 3)
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_under_the_drivers_torchrun_command_line():
+    """GPU: the same eight-rank rehearsal as above, launched exactly as the driver launches N > 1 (torch.distributed.run)"""
+    import torch
+    env = {"RSX_BENCH_SHARE_DEVICE": "1"} if torch.cuda.device_count() < 8 else {}
+    res, line = _run_torchrun(8, ["--steps", "20", "--warmup", "5"], env=env, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert sum(ln.startswith("{") for ln in res.stdout.splitlines()) == 1
+    assert line["n_gpus"] == 8 and line["collective"]["ranks"] == 8 and len(line["collective"]["per_rank_ms_per_step"]) == 8
+    counted = line["env_steps_counted"]
+    assert counted % (8 * 4096) == 0 and counted // (8 * 4096) >= 25
+    m = _single_handle_metrics(8 * 4096, counted // (8 * 4096), 0)
+    assert counted == int(m[0]) and line["episodes"] == int(m[1])
