@@ -675,6 +675,27 @@ def python_layer(torch, dev, B=4096, n=2000):
                     "vec_api_note": "VecVSSEnv.step(actions) with a device-resident [B, 2] action tensor, host-asynchronous"})
     except Exception as ex:
         out["vec_api_error"] = repr(ex)
+    # the robosim-shaped pair step(cmds) + get_state() for a batch in the reference's float64 wire format, PCIe both ways included
+    # (ABI 6: pinned wire buffers, conversion on the device; never `value`)
+    try:
+        import numpy as np
+        from rsoccer_amd import _lib as L
+        sim = L.Sim(L.KIND_VSS, 0, 3, 3, 25, B, dev)
+        wire = sim.wire_buffers()
+        wire[0][...] = np.random.default_rng(0).uniform(-30, 30, wire[0].shape)
+        for _ in range(20):
+            sim.step_wire()
+        m = 300
+        t0 = time.perf_counter()
+        for _ in range(m):
+            sim.step_wire()
+        dt = (time.perf_counter() - t0) / m
+        sim.close()
+        out.update({"host_wire_format_us_per_step": dt * 1e6, "host_wire_format_env_steps_per_s": B / dt,
+                    "host_wire_format_note": f"raw VSS 3v3, {B} envs: rsx_step_wire — float64 commands in / float64 state out through pinned "
+                                             "buffers, conversion on the device, one synchronisation per step (rsim.py:102,105 for a batch)"})
+    except Exception as ex:
+        out["host_wire_format_error"] = repr(ex)
     # policy in the loop (the reference's training loop, README.md:116-133, with a 40-64-2 tanh MLP on the GPU): eager, and
     # policy(obs) -> env.step(actions) captured into a hipGraph and replayed (rsx_task_enable_capture: the step counter that
     # keys the random draws lives on the device, every replay advances it; tests/test_gpu_graph.py is the parity proof)
