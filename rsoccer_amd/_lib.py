@@ -221,10 +221,21 @@ class Sim:
         cmds = _f64(cmds, (self.num_envs, self.n_robots, self.cmd_dim))
         _chk(self._lib.rsx_step(self._h, _ptr(cmds), self._stream(stream)))
 
-    def step_state(self, cmds):
+    def step_state(self, cmds, copy=True):
         """step(cmds) + get_state() in one crossing (rsx_step_state, null stream): returns the [B, state_dim] float64
         state.  ``cmds`` must be a C-contiguous float64 array of B * n_robots * cmd_dim values — the lean path of the
-        robosim-shaped single-env objects (no conversions, no per-call stream object)."""
+        robosim-shaped single-env objects (no conversions, no per-call stream object).  ``copy=False`` on a handle with
+        wire buffers (more than 64 envs): the commands are copied into the pinned command buffer, the step runs through
+        ``rsx_step_wire`` and the result is a VIEW of the pinned state buffer — valid until the next step, no pass over
+        the 8 * B * state_dim bytes on the host."""
+        if not copy:
+            wire = self.wire_buffers()
+            if wire is not None:
+                np.copyto(wire[0], np.asarray(cmds).reshape(wire[0].shape))
+                rc = self._lib.rsx_step_wire(self._h, None)
+                if rc:
+                    _chk(rc)
+                return wire[1][:, :self.state_dim]
         out = np.empty((self.num_envs, self.state_dim), dtype=np.float64)
         rc = self._lib.rsx_step_state(self._h, cmds.ctypes.data, out.ctypes.data, None)
         if rc:

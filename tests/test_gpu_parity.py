@@ -1544,7 +1544,7 @@ for t in range(24):
         got_full = wire[1].copy()
         got = got_full[:, :sim.state_dim]
     elif t % 3 == 1:
-        got = sim.step_state(np.ascontiguousarray(cm)); got_full = sim.get_state_full()
+        got = sim.step_state(np.ascontiguousarray(cm), copy=(t % 2 == 0)); got_full = sim.get_state_full()   # copy=False: a view of the pinned buffer
     else:
         sim.step(cm); got = sim.get_state(); got_full = sim.get_state_full()
     assert np.array_equal(got_full, want), t
