@@ -856,7 +856,7 @@ int rsx_task_attach(rsx_sim* h, int task, uint64_t seed, uint64_t env_id_base, i
     if (n_aux >= ((size_t)1 << 32) || B * (size_t)P.obs_dim * sizeof(float) >= ((size_t)1 << 32))
         return fail(RSX_ERR_ARG, "num_envs too large for a fused task: the per-env scalar arena or the observation array would reach 4 GB (see rsx.h, limits)");
     const size_t n_obs = align_up(B * P.obs_dim * sizeof(float));
-    const size_t n_flags = align_up(2 * B);
+    const size_t n_flags = align_up(3 * B);   // terminated | truncated | the env mask of rsx_task_reset_to (read by the MODE_REFRESH launch only)
     const size_t n_act = align_up(B * h->M.act_dim * sizeof(float));
     // metrics[8] | error word | (256 bytes in) one step-counter slot per workgroup of the largest stepping launch any layout
     // of this batch could use (rsx_kernels.hpp: step_tick; only the first tick_slots are kept in sync)
@@ -1024,12 +1024,13 @@ int rsx_task_reset_to(rsx_sim* h, const double* ball, const double* blue, const 
     if (int rc = rsx_reset(h, ball, blue, yellow, env_mask, stream)) return rc;
     hipStream_t s = (hipStream_t)stream;
     const size_t B = (size_t)h->P.num_envs;
-    // the kernel takes the env mask through the `truncated` buffer (cleared again below)
-    if (env_mask) HIP_TRY(hipMemcpyAsync(h->d_flags + B, env_mask, B, hipMemcpyHostToDevice, s));
-    else HIP_TRY(hipMemsetAsync(h->d_flags + B, 1, B, s));
+    // the kernel takes the env mask through the third row of the flags array: `terminated` / `truncated` of the envs the mask leaves
+    // alone stay what their last step made them (until round 6 the mask travelled through the `truncated` row, which was cleared
+    // afterwards — for EVERY env: found by tests/test_gpu_api_fuzz.py)
+    if (env_mask) HIP_TRY(hipMemcpyAsync(h->d_flags + 2 * B, env_mask, B, hipMemcpyHostToDevice, s));
+    else HIP_TRY(hipMemsetAsync(h->d_flags + 2 * B, 1, B, s));
     launch_task(h, nullptr, 1, MODE_REFRESH, s);
     HIP_TRY(launch_status());
-    HIP_TRY(hipMemsetAsync(h->d_flags + B, 0, B, s));
     HIP_TRY(hipStreamSynchronize(s));   // the host mask / placement arrays may be reused by the caller
     h->task_ready = true;
     return RSX_OK;

@@ -59,7 +59,7 @@ struct Buffers {
     float* aux;            // [aux_rows][B]   reward, prev_pot, ep_ret, steps, episode, info, ou
     float* obs;            // [B][obs_dim]
     float* final_obs;      // [B][obs_dim]
-    uint8_t* flags;        // [2][B]          terminated, truncated
+    uint8_t* flags;        // [3][B]          terminated, truncated, env mask of reset_to (MODE_REFRESH)
     const float* cmds;     // [N*C][B]        (raw simulator path)
     const float* actions;  // [B][act_dim] or nullptr = random
     unsigned long long* metrics;  // [RSX_METRICS]
@@ -1362,7 +1362,7 @@ __device__ __forceinline__ void placement_helper(const Params& P, const Buffers&
 //   MODE_ROLLOUT n_steps random-action steps per launch (state stays in registers)
 //   MODE_RESET   reset() with random placement
 //   MODE_REFRESH open a new episode on the state already in the buffers for the envs flagged in
-//                the `truncated` bytes (reset_to); observations recomputed, state untouched
+//                the third row of the flags array (reset_to); observations recomputed, state untouched
 constexpr int MODE_STEP = 0, MODE_RESET = 1, MODE_REFRESH = 2, MODE_ROLLOUT = 3;
 
 #ifndef RSX_TASK_KERNEL_ATTR
@@ -1524,7 +1524,7 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
         bool ended;
         const float obs_ts = prev_pot;   // the task scalar as this step's observation sees it (before the reward moves it)
         if (mode == 2) {
-            const bool flagged = live && bufs.flags[B + e] != 0;
+            const bool flagged = live && bufs.flags[2 * B + e] != 0;   // third row of the flags array: the env mask of rsx_task_reset_to
             if (flagged) {
                 episode += 1; steps = 0; ou0 = 0.0f; ou1 = 0.0f;
                 if (is_ball) {
@@ -1545,6 +1545,8 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
             if (is_ball) {
 #pragma unroll
                 for (int i = 0; i < 10; ++i) info[i] = 0.0f;
+#pragma unroll
+                for (int i = 0; i < ID; ++i) auxe(ROW_INFO + i) = 0.0f;   // like reset_to above: the info rows of a fresh episode read zero
                 ep_ret = 0.0f; prev_pot = 0.0f;
             }
         } else {

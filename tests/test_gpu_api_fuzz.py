@@ -1,0 +1,493 @@
+"""Differential fuzzing of the C-ABI's CALL SEQUENCES against the CPU oracle.
+
+The parity tests of test_gpu_parity.py exercise one feature at a time (fed / random actions, step_n, rollout, masked reset_to,
+checkpoints, graphs, reseed).  A caller of the reference-shaped API interleaves them freely — the trainer of
+rsoccer_gym's README.md:116-133 resets in the middle of an episode, the adapters of Simulators/rsim.py:36-110 mix reset / step /
+get_state — so this file draws RANDOM interleavings of every stepping, resetting and state-carrying call of a fused handle
+(rsx_task_step with fed and with device-drawn actions, _step_n, _rollout, _reset, masked _reset_to, checkpoint save -> load into a
+NEW handle of another kernel layout, rsx_task_enable_capture, rsx_task_reseed, rsx_read_metrics, rsx_task_tick) and checks after
+EVERY call that observations, rewards, flags, info rows, step counters, terminal observations, the full simulator state and the
+device-side metrics equal what one oracle env per env id produces for the same sequence — bit for bit.
+
+`python tests/test_gpu_api_fuzz.py [--seeds N] [--ops M]` runs a longer campaign on the GPU box (what profiles/r06_api_fuzz.txt holds).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from helpers import f32_equal, mismatch_report, random_placement  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+# task, kind, field type, n_blue, n_yellow, batch, TimeLimit, layouts the handle may be stepped by
+CONFIGS = {
+    "VSS-v0": (1, 0, 0, 3, 3, 70, 23, ("lanes", "epl")),
+    "VSS-v0-5v5": (1, 0, 1, 5, 5, 19, 17, ("lanes",)),
+    "SSLStaticDefenders-v0": (2, 1, 2, 1, 6, 66, 19, ("lanes", "epl")),
+    "SSLDribbling-v0": (3, 1, 2, 1, 4, 37, 29, ("lanes", "epl")),
+    "SSLContestedPossession-v0": (4, 1, 2, 1, 1, 45, 13, ("lanes", "epl")),
+    "SSLPassEndurance-v0": (5, 1, 2, 2, 0, 33, 11, ("lanes", "epl")),
+    "scrimmage-11v11-crowded": (7, 1, 1, 11, 11, 9, 15, ("lanes", "quad")),
+    "scrimmage-3v2": (6, 1, 2, 3, 2, 21, 9, ("lanes",)),
+}
+
+
+class _Mirror:
+    """One fused handle of the library and one oracle env per env id, driven through the same calls."""
+
+    def __init__(self, L, O, name, seed, rng, log):
+        self.L, self.O, self.rng, self.log = L, O, rng, log
+        (self.task, self.kind, self.ft, self.nb, self.ny, self.B, self.max_steps, self.layouts) = CONFIGS[name]
+        self.seed, self.base = seed, int(rng.integers(0, 1 << 20))
+        self.layout = None
+        self.captured = False
+        self.sim = self._handle(self.layouts[int(rng.integers(len(self.layouts)))])
+        self.refs = self._oracles(self.seed)
+        self.fp = self.sim.get_field_params()
+        self.steps_taken = 0
+        self.fresh = np.ones(self.B, dtype=bool)   # envs reset since their last step: reward / flags / info rows are those of the NEXT step
+
+    def _handle(self, layout):
+        os.environ["RSX_LAYOUT"] = layout
+        try:
+            sim = self.L.Sim(self.kind, self.ft, self.nb, self.ny, 25, self.B)
+            sim.task_attach(self.task, self.seed, self.base, self.max_steps)
+        finally:
+            del os.environ["RSX_LAYOUT"]
+        self.layout = layout
+        self.tens = sim.task_tensors()
+        return sim
+
+    def _oracles(self, seed):
+        refs = [self.O.OracleEnv(self.kind, self.ft, self.nb, self.ny, 25, "f32") for _ in range(self.B)]
+        for e, r in enumerate(refs):
+            r.task_attach(self.task, seed, self.base + e, self.max_steps)
+        return refs
+
+    # ---- the calls ----
+    def op_reset(self):
+        self.sim.task_reset()
+        for r in self.refs:
+            r.task_reset()
+        self.fresh[:] = True
+
+    def op_reset_to(self):
+        f = self.fp
+        ball, blue, yellow = random_placement(self.rng, self.B, self.nb, self.ny, f["length"] / 2 - 3 * f["rbt_radius"],
+                                              f["width"] / 2 - 3 * f["rbt_radius"], 2.3 * f["rbt_radius"], 0.9)
+        mask = (self.rng.random(self.B) < 0.4).astype(np.uint8) if self.rng.random() < 0.8 else None
+        self.sim.task_reset_to(ball, blue, yellow if self.ny else None, mask)
+        for e, r in enumerate(self.refs):
+            if mask is None or mask[e]:
+                r.task_reset_to(ball[e], blue[e], yellow[e] if self.ny else np.zeros(0))
+                self.fresh[e] = True
+
+    def op_step_fed(self):
+        import torch
+        a = self.rng.uniform(-1, 1, (self.B, self.sim.act_dim)).astype(np.float32)
+        self.tens["actions"].copy_(torch.from_numpy(a))
+        self.sim.task_step(self.tens["actions"].data_ptr())
+        for e, r in enumerate(self.refs):
+            r.task_step(a[e])
+        self.steps_taken += 1
+        self.fresh[:] = False
+
+    def _random_steps(self, n):
+        for r in self.refs:
+            for _ in range(n):
+                r.task_step(None)
+        self.steps_taken += n
+        self.fresh[:] = False
+
+    def op_step_random(self):
+        self.sim.task_step(None)
+        self._random_steps(1)
+
+    def op_step_n(self):
+        n = int(self.rng.integers(1, 8))
+        self.sim.task_step_n(n)
+        self._random_steps(n)
+
+    def op_rollout(self):
+        n = int(self.rng.integers(1, 8))
+        self.sim.task_rollout(n)
+        self._random_steps(n)
+
+    def op_checkpoint_to_new_handle(self):
+        """save, destroy, create a handle stepped by another layout (never reset), load: the run continues there"""
+        blob = self.sim.task_checkpoint()
+        was_captured = self.captured
+        self.sim.close()
+        self.sim = self._handle(self.layouts[int(self.rng.integers(len(self.layouts)))])
+        if was_captured and self.rng.random() < 0.5:    # the counter's home (host / device) is a property of the handle, not of the run
+            self.sim.task_enable_capture()
+        else:
+            self.captured = False
+        self.sim.task_restore(blob)
+
+    def op_enable_capture(self):
+        self.sim.task_enable_capture()
+        self.captured = True
+
+    def op_reseed(self):
+        self.seed = int(self.rng.integers(0, 1 << 62))
+        self.sim.task_reseed(self.seed)
+        self.refs = self._oracles(self.seed)
+        self.steps_taken = 0
+        self.op_reset() if self.rng.random() < 0.5 else self.op_reset_to_all()
+
+    def op_reset_to_all(self):
+        f = self.fp
+        ball, blue, yellow = random_placement(self.rng, self.B, self.nb, self.ny, f["length"] / 2 - 3 * f["rbt_radius"],
+                                              f["width"] / 2 - 3 * f["rbt_radius"], 2.3 * f["rbt_radius"], 0.9)
+        self.sim.task_reset_to(ball, blue, yellow if self.ny else None, None)
+        for e, r in enumerate(self.refs):
+            r.task_reset_to(ball[e], blue[e], yellow[e] if self.ny else np.zeros(0))
+        self.fresh[:] = True
+
+    def op_graph_replays(self):
+        """capture one fed-action step into a hipGraph and replay it a few times (only device-keyed handles may)"""
+        import torch
+        if not self.captured:
+            self.op_enable_capture()
+        a = self.rng.uniform(-1, 1, (self.B, self.sim.act_dim)).astype(np.float32)
+        self.tens["actions"].copy_(torch.from_numpy(a))
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):   # (captures on a side stream of its own)
+            self.sim.task_step(self.tens["actions"].data_ptr(), torch.cuda.current_stream().cuda_stream)
+        n = int(self.rng.integers(1, 5))
+        for _ in range(n):
+            g.replay()
+        torch.cuda.synchronize()
+        for e, r in enumerate(self.refs):
+            for _ in range(n):
+                r.task_step(a[e])
+        self.steps_taken += n
+        self.fresh[:] = False
+
+    # ---- the check ----
+    def compare(self, what):
+        import torch
+        torch.cuda.synchronize()
+        t = self.tens
+        obs, rew = t["obs"].cpu().numpy(), t["reward"].cpu().numpy()
+        term, trunc = t["terminated"].cpu().numpy(), t["truncated"].cpu().numpy()
+        info, steps, fin = t["info"].cpu().numpy(), t["steps"].cpu().numpy(), t["final_obs"].cpu().numpy()
+        state = self.sim.get_state_full()
+        ctx = f"{what} [{self.layout}{', device-keyed' if self.captured else ''}] after: " + " ".join(self.log[-12:])
+        for e, r in enumerate(self.refs):
+            o = r.task_out()
+            w = r.get_state_full()
+            assert f32_equal(state[e], w), mismatch_report(state[e], w, f"state env {e}: {ctx}")
+            assert f32_equal(obs[e], o["obs"]), mismatch_report(obs[e], o["obs"], f"obs env {e}: {ctx}")
+            assert steps[e] == o["steps"], f"steps env {e}: {steps[e]} vs {o['steps']}: {ctx}"
+            # (a reset writes the state and the observation and clears the step count and the info rows; reward and flags stay those of the
+            # env's last step — on both sides — until its next one: reset() returns (obs, {}), vss_gym_base.py:92-106)
+            assert f32_equal(rew[e], o["reward"]), f"reward env {e}: {rew[e]} vs {o['reward']}: {ctx}"
+            assert term[e] == o["terminated"] and trunc[e] == o["truncated"], f"flags env {e}: {ctx}"
+            assert f32_equal(info[:, e], o["info"]), mismatch_report(info[:, e], o["info"], f"info env {e}: {ctx}")
+            if o["terminated"] or o["truncated"]:
+                assert f32_equal(fin[e], o["final_obs"]), f"final_obs env {e}: {ctx}"
+
+    def compare_metrics(self):
+        got = self.sim.read_metrics()
+        want = sum(r.task_out()["metrics"] for r in self.refs)
+        assert np.array_equal(got, want), (got, want, self.log[-12:])
+        assert self.sim.task_tick() == self.steps_taken, (self.sim.task_tick(), self.steps_taken, self.log[-12:])
+
+
+OPS = [("step_fed", 5), ("step_random", 4), ("step_n", 3), ("rollout", 3), ("reset", 1), ("reset_to", 2),
+       ("checkpoint_to_new_handle", 2), ("enable_capture", 1), ("reseed", 1), ("graph_replays", 1), ("metrics", 2)]
+
+
+def run_sequence(L, O, name, seed, n_ops):
+    rng = np.random.default_rng(seed)
+    log = []
+    m = _Mirror(L, O, name, int(rng.integers(0, 1 << 62)), rng, log)
+    names = [o for o, _ in OPS]
+    p = np.array([w for _, w in OPS], dtype=np.float64)
+    p /= p.sum()
+    try:
+        m.op_reset() if rng.random() < 0.5 else m.op_reset_to_all()
+        log.append("reset")
+        m.compare("reset")
+        for _ in range(n_ops):
+            op = names[int(rng.choice(len(names), p=p))]
+            if op == "enable_capture" and m.captured:
+                continue
+            log.append(op)
+            if op == "metrics":
+                m.compare_metrics()
+                continue
+            getattr(m, "op_" + op)()
+            m.compare(op)
+        m.compare_metrics()
+    finally:
+        m.sim.close()
+    return log
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the simulator surface without a task: what replaces robosim.{VSS,SSL} (rsim.py:38,102,105,116,155,158,169), batched, in its host
+# (float64 wire format) and device (SoA float32) forms — the calls a caller may mix on one handle
+# ---------------------------------------------------------------------------------------------------------------------------
+RAW_CONFIGS = {
+    # kind, field type, n_blue, n_yellow, batch (<= 64: the zero-copy host path; above: the pinned wire buffers)
+    "VSS-3v3-small": (0, 0, 3, 3, 5),
+    "VSS-3v3": (0, 0, 3, 3, 70),
+    "SSL-1v6-small": (1, 2, 1, 6, 3),
+    "SSL-1v6": (1, 2, 1, 6, 67),
+    "SSL-2v0": (1, 0, 2, 0, 66),
+    "SSL-11v11": (1, 1, 11, 11, 9),
+}
+
+
+class _RawMirror:
+    def __init__(self, L, O, name, rng, log):
+        import torch
+        self.torch, self.L, self.rng, self.log = torch, L, rng, log
+        self.kind, self.ft, self.nb, self.ny, self.B = RAW_CONFIGS[name]
+        self.N = self.nb + self.ny
+        knobs = {}
+        if rng.random() < 0.25:
+            knobs["RSX_NO_ZERO_COPY" if self.B <= 64 else "RSX_NO_WIRE_PATH"] = "1"
+        os.environ.update(knobs)
+        try:
+            self.sim = L.Sim(self.kind, self.ft, self.nb, self.ny, 25, self.B)
+        finally:
+            for k in knobs:
+                del os.environ[k]
+        self.knobs = ",".join(knobs) or "default"
+        self.refs = [O.OracleEnv(self.kind, self.ft, self.nb, self.ny, 25, "f32") for _ in range(self.B)]
+        self.fp = self.sim.get_field_params()
+        self.C = self.sim.cmd_dim
+
+    def _cmds(self):
+        rng, B, N = self.rng, self.B, self.N
+        if self.kind == 0:
+            return rng.uniform(-60, 60, (B, N, 2))
+        c = np.zeros((B, N, 8))
+        wheels = rng.random((B, N)) < 0.3
+        c[..., 0] = wheels
+        c[..., 1:5] = np.where(wheels[..., None], rng.uniform(-120, 120, (B, N, 4)),
+                               np.concatenate([rng.uniform(-3, 3, (B, N, 2)), rng.uniform(-12, 12, (B, N, 1)), np.zeros((B, N, 1))], -1))
+        c[..., 5] = np.where(rng.random((B, N)) < 0.3, 4.0, 0.0)
+        c[..., 6] = np.where(rng.random((B, N)) < 0.1, 2.0, 0.0)
+        c[..., 7] = rng.random((B, N)) < 0.5
+        return c
+
+    def _placement(self):
+        f = self.fp
+        return random_placement(self.rng, self.B, self.nb, self.ny, f["length"] / 2 - 2 * f["rbt_radius"], f["width"] / 2 - 2 * f["rbt_radius"],
+                                2.2 * f["rbt_radius"], float(self.rng.choice([0.3, 0.6, 1.0])))
+
+    def _mask(self):
+        return (self.rng.random(self.B) < 0.5).astype(np.uint8) if self.rng.random() < 0.6 else None
+
+    def _mirror_reset(self, ball, blue, yellow, mask):
+        for e, r in enumerate(self.refs):
+            if mask is None or mask[e]:
+                r.reset(ball[e], blue[e], yellow[e] if self.ny else np.zeros(0))
+
+    def _mirror_step(self, cmds):
+        for e, r in enumerate(self.refs):
+            r.step(cmds[e])
+
+    # ---- host-format calls ----
+    def op_reset(self):
+        ball, blue, yellow = self._placement()
+        mask = self._mask()
+        self.sim.reset(ball, blue, yellow if self.ny else None, mask)
+        self._mirror_reset(ball, blue, yellow, mask)
+
+    def op_step(self):
+        c = self._cmds()
+        self.sim.step(c)
+        self._mirror_step(c)
+
+    def op_step_state(self):
+        c = np.ascontiguousarray(self._cmds())
+        got = self.sim.step_state(c, copy=bool(self.rng.random() < 0.5))
+        self._mirror_step(c)
+        for e, r in enumerate(self.refs):
+            assert f32_equal(got[e], r.get_state()), mismatch_report(got[e], r.get_state(), f"step_state env {e}: " + " ".join(self.log[-10:]))
+
+    def op_step_wire(self):
+        w = self.sim.wire_buffers()
+        if w is None:
+            return self.op_step()
+        c = self._cmds()
+        np.copyto(w[0], c)
+        self.sim.step_wire()
+        self._mirror_step(c)
+        for e, r in enumerate(self.refs):
+            assert f32_equal(w[1][e], r.get_state_full()), mismatch_report(w[1][e], r.get_state_full(), f"wire state env {e}: " + " ".join(self.log[-10:]))
+
+    def op_set_state(self):
+        s = self.sim.get_state_full()
+        k = self.rng.integers(0, s.shape[1], 6)
+        s[:, k] = (s[:, k] + self.rng.normal(0, 0.05, (self.B, 6))).astype(np.float32)
+        self.sim.set_state(s)
+        for e, r in enumerate(self.refs):
+            r.set_state_full(s[e])
+
+    # ---- device-resident calls ----
+    def op_step_dev(self, flip=False):
+        torch = self.torch
+        c = self._cmds().astype(np.float32)
+        self.sim.cmds_tensor().copy_(torch.from_numpy(np.ascontiguousarray(c.reshape(self.B, -1).T)))
+        (self.sim.step_dev_flip if flip else self.sim.step_dev)()
+        self._mirror_step(c)
+
+    def op_step_dev_flip(self):
+        self.op_step_dev(flip=True)
+        cur, oth = self.sim.state_buffers()
+        torch = self.torch
+        torch.cuda.synchronize()
+        got = cur.cpu().numpy().T.astype(np.float64)
+        for e, r in enumerate(self.refs):
+            assert f32_equal(got[e], r.get_state_full()), mismatch_report(got[e], r.get_state_full(), f"current buffer env {e}: " + " ".join(self.log[-10:]))
+
+    def op_step_dev_random(self):
+        n, seed, t0 = int(self.rng.integers(1, 6)), int(self.rng.integers(0, 1 << 40)), int(self.rng.integers(0, 1000))
+        self.sim.step_dev_random(n, seed, t0)
+        for e, r in enumerate(self.refs):
+            for t in range(n):
+                r.step_random(seed, e, t0 + t)
+
+    def op_reset_dev(self):
+        torch = self.torch
+        ball, blue, yellow = (a.astype(np.float32) for a in self._placement())
+        mask = self._mask()
+        d = lambda a: torch.from_numpy(a).cuda()
+        self.sim.reset_dev(d(ball), d(blue) if self.nb else None, d(yellow) if self.ny else None, None if mask is None else d(mask))
+        self._mirror_reset(ball, blue, yellow, mask)
+
+    def op_device_write(self):
+        """a caller's own kernel writes the state array (here: torch): the next host-format read must see it"""
+        torch = self.torch
+        row = int(self.rng.integers(0, 5))
+        v = self.rng.uniform(-0.3, 0.3, self.B).astype(np.float32)
+        cur = self.sim.state_buffers()[0]   # (after rsx_step_dev_flip calls the buffer that holds the current frame)
+        cur[row].copy_(torch.from_numpy(v))
+        for e, r in enumerate(self.refs):
+            s = r.get_state_full()
+            s[row] = v[e]
+            r.set_state_full(s)
+
+    def compare(self, what):
+        self.torch.cuda.synchronize()
+        ctx = f"{what} [{self.knobs}] after: " + " ".join(self.log[-12:])
+        if self.rng.random() < 0.3:
+            got = self.sim.get_state()
+            for e, r in enumerate(self.refs):
+                assert f32_equal(got[e], r.get_state()), mismatch_report(got[e], r.get_state(), f"get_state env {e}: {ctx}")
+        got = self.sim.get_state_full()
+        for e, r in enumerate(self.refs):
+            w = r.get_state_full()
+            assert f32_equal(got[e], w), mismatch_report(got[e], w, f"state env {e}: {ctx}")
+
+
+RAW_OPS = [("reset", 2), ("step", 3), ("step_state", 3), ("step_wire", 2), ("set_state", 1), ("step_dev", 3), ("step_dev_flip", 3),
+           ("step_dev_random", 2), ("reset_dev", 2), ("device_write", 1)]
+
+
+def run_raw_sequence(L, O, name, seed, n_ops):
+    rng = np.random.default_rng(seed)
+    log = []
+    m = _RawMirror(L, O, name, rng, log)
+    names = [o for o, _ in RAW_OPS]
+    p = np.array([w for _, w in RAW_OPS], dtype=np.float64)
+    p /= p.sum()
+    try:
+        m.compare("create")   # the adapter's dummy line-up, rsim.py:20-24
+        for _ in range(n_ops):
+            op = names[int(rng.choice(len(names), p=p))]
+            log.append(op)
+            getattr(m, "op_" + op)()
+            m.compare(op)
+    finally:
+        m.sim.close()
+    return log
+
+
+@pytest.mark.parametrize("name", list(RAW_CONFIGS))
+def test_random_call_sequences_of_the_simulator_surface_match_the_oracle(oracle_mod, name):
+    from rsoccer_amd import _lib as L
+    for seed in (21, 22):
+        run_raw_sequence(L, oracle_mod, name, seed * 1000 + sorted(RAW_CONFIGS).index(name), 40)
+
+
+def test_masked_reset_to_leaves_the_other_envs_flags_alone(oracle_mod):
+    """the defect this file found: rsx_task_reset_to carried its env mask through the `truncated` row and cleared the row afterwards —
+    for every env, also those the mask left alone"""
+    import torch
+    from rsoccer_amd import _lib as L
+    B = 24
+    sim = L.Sim(1, 2, 2, 0, 25, B)
+    sim.task_attach(5, 1, 0, 3)            # pass endurance, TimeLimit 3: the third step truncates every env
+    sim.task_reset()
+    sim.task_step_n(3)
+    t = sim.task_tensors()
+    torch.cuda.synchronize()
+    trunc = t["truncated"].cpu().numpy().copy()
+    assert trunc.sum() > B // 2
+    term = t["terminated"].cpu().numpy().copy()
+    rng = np.random.default_rng(0)
+    f = sim.get_field_params()
+    ball, blue, _ = random_placement(rng, B, 2, 0, f["length"] / 2 - 0.5, f["width"] / 2 - 0.5, 0.3)
+    mask = (np.arange(B) % 3 == 0).astype(np.uint8)
+    sim.task_reset_to(ball, blue, None, mask)
+    torch.cuda.synchronize()
+    assert np.array_equal(t["truncated"].cpu().numpy(), trunc) and np.array_equal(t["terminated"].cpu().numpy(), term)
+    sim.close()
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_random_call_sequences_match_the_oracle(oracle_mod, name):
+    from rsoccer_amd import _lib as L
+    for seed in (11, 12):
+        run_sequence(L, oracle_mod, name, seed * 1000 + sorted(CONFIGS).index(name), 45)
+
+
+if __name__ == "__main__":
+    import argparse
+    import time
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", type=int, default=20)
+    ap.add_argument("--ops", type=int, default=120)
+    ap.add_argument("--first-seed", type=int, default=100000)
+    ap.add_argument("--configs", default=",".join(CONFIGS))
+    a = ap.parse_args()
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import __graft_entry__ as g
+    g.build()
+    from oracle import oracle as O
+    from rsoccer_amd import _lib as L
+    O.build()
+    bad = 0
+    for name in RAW_CONFIGS if a.configs == ",".join(CONFIGS) else []:
+        t0 = time.time()
+        n_calls = 0
+        for sd in range(a.first_seed, a.first_seed + a.seeds):
+            try:
+                n_calls += len(run_raw_sequence(L, O, name, sd, a.ops))
+            except AssertionError as ex:
+                bad += 1
+                print(f"FAIL raw {name} seed {sd}: {str(ex)[:1500]}", flush=True)
+        print(f"simulator surface {name}: {a.seeds} sequences, {n_calls} calls compared call by call, {time.time() - t0:.0f} s, failures so far {bad}", flush=True)
+    for name in a.configs.split(","):
+        t0 = time.time()
+        n_calls = 0
+        for s in range(a.first_seed, a.first_seed + a.seeds):
+            try:
+                n_calls += len(run_sequence(L, O, name, s, a.ops))
+            except AssertionError as ex:
+                bad += 1
+                print(f"FAIL {name} seed {s}: {str(ex)[:1500]}", flush=True)
+        print(f"{name}: {a.seeds} sequences, {n_calls} calls compared call by call, {time.time() - t0:.0f} s, failures so far {bad}", flush=True)
+    sys.exit(1 if bad else 0)
