@@ -35,6 +35,26 @@ CONFIGS = {
 }
 
 
+def wild_placement(rng, B, nb, ny, f):
+    """poses no task would place: anywhere up to half a metre outside the field (behind walls, inside and beside the goals) or crowded into
+    a goal mouth / a corner, robots on top of each other (also EXACTLY: d2 == 0), the ball inside a robot, the ball at speed"""
+    N = nb + ny
+    hx, hy = f["length"] / 2 + 0.5, f["width"] / 2 + 0.5
+    if rng.random() < 0.5:
+        cx = rng.choice([-1, 1]) * f["length"] / 2
+        cy = rng.choice([0.0, f["goal_width"] / 2, f["width"] / 2, -f["width"] / 2])
+        pos = np.stack([cx + rng.normal(0, 0.12, (B, N + 1)), cy + rng.normal(0, 0.12, (B, N + 1))], -1)
+    else:
+        pos = np.stack([rng.uniform(-hx, hx, (B, N + 1)), rng.uniform(-hy, hy, (B, N + 1))], -1)
+    for e in range(B):
+        if rng.random() < 0.3:
+            i, j = rng.integers(0, N + 1, 2)
+            pos[e, i] = pos[e, j]
+    ball = np.concatenate([pos[:, 0], rng.uniform(-6, 6, (B, 2))], -1)
+    rob = np.concatenate([pos[:, 1:], rng.uniform(-180, 180, (B, N, 1))], -1)
+    return ball, rob[:, :nb].copy(), rob[:, nb:].copy()
+
+
 class _Mirror:
     """One fused handle of the library and one oracle env per env id, driven through the same calls."""
 
@@ -76,8 +96,11 @@ class _Mirror:
 
     def op_reset_to(self):
         f = self.fp
-        ball, blue, yellow = random_placement(self.rng, self.B, self.nb, self.ny, f["length"] / 2 - 3 * f["rbt_radius"],
-                                              f["width"] / 2 - 3 * f["rbt_radius"], 2.3 * f["rbt_radius"], 0.9)
+        if self.rng.random() < 0.3:
+            ball, blue, yellow = wild_placement(self.rng, self.B, self.nb, self.ny, f)
+        else:
+            ball, blue, yellow = random_placement(self.rng, self.B, self.nb, self.ny, f["length"] / 2 - 3 * f["rbt_radius"],
+                                                  f["width"] / 2 - 3 * f["rbt_radius"], 2.3 * f["rbt_radius"], 0.9)
         mask = (self.rng.random(self.B) < 0.4).astype(np.uint8) if self.rng.random() < 0.8 else None
         self.sim.task_reset_to(ball, blue, yellow if self.ny else None, mask)
         for e, r in enumerate(self.refs):
@@ -304,8 +327,32 @@ class _RawMirror:
         self.sim.reset(ball, blue, yellow if self.ny else None, mask)
         self._mirror_reset(ball, blue, yellow, mask)
 
+    def op_reset_wild(self):
+        ball, blue, yellow = wild_placement(self.rng, self.B, self.nb, self.ny, self.fp)
+        mask = self._mask()
+        self.sim.reset(ball, blue, yellow if self.ny else None, mask)
+        self._mirror_reset(ball, blue, yellow, mask)
+
+    def op_set_state_wild(self):
+        """velocities far beyond what the actuation reaches, the ball in flight"""
+        s = self.sim.get_state_full()
+        rs = 6 if self.kind == 0 else 11
+        for k in range(self.N):
+            s[:, 5 + rs * k + 3: 5 + rs * k + 5] = self.rng.uniform(-8, 8, (self.B, 2)).astype(np.float32)
+            s[:, 5 + rs * k + 5] = self.rng.uniform(-2000, 2000, self.B).astype(np.float32)
+        s[:, 3:5] = self.rng.uniform(-12, 12, (self.B, 2)).astype(np.float32)
+        s[:, 2] = (s[:, 2] + np.where(self.rng.random(self.B) < 0.5, self.rng.uniform(0, 0.4, self.B), 0.0)).astype(np.float32)
+        s[:, -2] = self.rng.uniform(-3, 3, self.B).astype(np.float32)      # vz
+        s[:, -1] = self.rng.uniform(-200, 200, self.B).astype(np.float32)  # spin
+        self.sim.set_state(s)
+        for e, r in enumerate(self.refs):
+            r.set_state_full(s[e])
+
     def op_step(self):
         c = self._cmds()
+        if self.rng.random() < 0.15:   # commands far beyond the motors' range (clamped on both sides, rsim.py:92-101 sets no limit)
+            c[..., -2 if self.kind == 0 else 1:] *= 1e6 if self.kind == 0 else 1.0
+            c = c * (1e4 if self.kind == 0 else 1.0)
         self.sim.step(c)
         self._mirror_step(c)
 
@@ -392,7 +439,7 @@ class _RawMirror:
             assert f32_equal(got[e], w), mismatch_report(got[e], w, f"state env {e}: {ctx}")
 
 
-RAW_OPS = [("reset", 2), ("step", 3), ("step_state", 3), ("step_wire", 2), ("set_state", 1), ("step_dev", 3), ("step_dev_flip", 3),
+RAW_OPS = [("reset", 2), ("reset_wild", 2), ("set_state_wild", 1), ("step", 3), ("step_state", 3), ("step_wire", 2), ("set_state", 1), ("step_dev", 3), ("step_dev_flip", 3),
            ("step_dev_random", 2), ("reset_dev", 2), ("device_write", 1)]
 
 
