@@ -1204,6 +1204,10 @@ int rsx_task_checkpoint_load(rsx_sim* h, const void* blob, size_t bytes, void* s
         return fail(RSX_ERR_ARG, "the checkpoint was taken with another max_episode_steps (TimeLimit)");
     if (k.key0 != want.key0 || k.key1 != want.key1 || k.env_id_base != want.env_id_base)
         return fail(RSX_ERR_ARG, "the checkpoint was taken with another seed or env_id_base: attach the task with the same ones");
+    // the section sizes follow from the configuration checked above; they are used for pointer arithmetic and as copy lengths below,
+    // so a header that disagrees (a damaged file) is refused instead of being trusted
+    if (k.state_bytes != want.state_bytes || k.aux_bytes != want.aux_bytes || k.obs_bytes != want.obs_bytes || k.flag_bytes != want.flag_bytes)
+        return fail(RSX_ERR_ARG, "the checkpoint header is damaged (section sizes do not match its configuration)");
     if (bytes < ckpt_size(k)) return fail(RSX_ERR_ARG, "blob is truncated");
     hipStream_t s = (hipStream_t)stream;
     const char* p = (const char*)blob + sizeof(CkptHeader);

@@ -1315,6 +1315,12 @@ def test_checkpoint_resume_is_bit_identical_across_handles_and_layouts(monkeypat
     other[off:off + 4] = np.array([1], dtype=np.int32).view(np.uint8)
     with pytest.raises(L.RsxError, match="physics model"):
         m.task_restore(other)
+    # ... and a header whose section sizes (used as copy lengths) disagree with its configuration: a damaged file
+    for word in range(4):                    # state_bytes, aux_bytes, obs_bytes, flag_bytes: uint64 at 80, 88, 96, 104
+        bad = np.array(blob, copy=True)
+        bad[80 + 8 * word: 88 + 8 * word].view(np.uint64)[0] += np.uint64(4096)
+        with pytest.raises(L.RsxError, match="damaged"):
+            m.task_restore(np.concatenate([bad, np.zeros(8192, dtype=np.uint8)]))
     m.close()
 
 
