@@ -263,7 +263,12 @@ int rsx_task_placement_cache_stats(rsx_sim* h, int64_t out[2], void* stream);
 /* reset(): new random placement for every env (vss_gym.py:194-233, static_defenders.py:214-254),
  * episode counters cleared, obs written. */
 int rsx_task_reset(rsx_sim* h, void* stream);
-/* reset() onto an explicit placement (same arrays as rsx_reset); obs written. */
+/* reset() onto an explicit placement (same arrays as rsx_reset); obs written.  env_mask (host, num_envs bytes, or NULL = all): only
+ * the envs with a non-zero byte are touched.
+ * Both resets open a new episode for the envs they touch: observation written, step count 0, info rows and episode sums zero, noise
+ * state cleared.  `reward`, `terminated` and `truncated` are outputs of step(): they keep what each env's LAST step wrote — for the
+ * envs a mask leaves alone and for the re-placed ones alike — until that env's next step (reset() returns (obs, {}):
+ * vss_gym_base.py:92-106). */
 int rsx_task_reset_to(rsx_sim* h, const double* ball, const double* blue, const double* yellow,
                       const uint8_t* env_mask, void* stream);
 
