@@ -1362,7 +1362,7 @@ __device__ __forceinline__ void placement_helper(const Params& P, const Buffers&
 //   MODE_ROLLOUT n_steps random-action steps per launch (state stays in registers)
 //   MODE_RESET   reset() with random placement
 //   MODE_REFRESH open a new episode on the state already in the buffers for the envs flagged in
-//                the third row of the flags array (reset_to); observations recomputed, state untouched
+//                the third row of the flags array (reset_to); their observations recomputed, state untouched
 constexpr int MODE_STEP = 0, MODE_RESET = 1, MODE_REFRESH = 2, MODE_ROLLOUT = 3;
 
 #ifndef RSX_TASK_KERNEL_ATTR
@@ -1535,7 +1535,10 @@ __global__ __launch_bounds__(64) RSX_TASK_KERNEL_ATTR void task_step_kernel(RSX_
                     ep_ret = 0.0f; prev_pot = 0.0f;
                 }
             }
-            write_obs<KIND, TASK>(P, bufs.obs + (size_t)e * OD, b, is_robot, is_ball, o.x, o.y, o.vx, o.vy, o.s, o.c, wd, o.ir, prev_pot);
+            // (only the re-placed envs: the observation of an env the mask leaves alone stays the one its last step wrote — recomputed here
+            // it would see the task scalar AFTER that step's reward moved it, e.g. the checkpoint count of SSLDribbling; found by
+            // tests/test_gpu_api_fuzz.py in 3 of 500 sequences)
+            if (flagged) write_obs<KIND, TASK>(P, bufs.obs + (size_t)e * OD, b, is_robot, is_ball, o.x, o.y, o.vx, o.vy, o.s, o.c, wd, o.ir, prev_pot);
             wave_sync();
             ended = false;
         } else if (mode == 1) {
