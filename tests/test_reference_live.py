@@ -1,0 +1,237 @@
+"""The Python host layer against THE REFERENCE ITSELF, live, over random episodes — in the build container only.
+
+tests/golden/ pins this project's restatement of the reference's Python-side arithmetic (commands, observations, rewards, done, info,
+placement, OU noise) to vectors recorded from scripted episodes.  Where /root/reference is present (the build container; it does
+not exist on the GPU box, where this test skips) the same comparison can be made LIVE and on trajectories nobody scripted: a child
+process imports the reference's own env classes (rsoccer_gym/vss/env_vss/vss_gym.py:13, rsoccer_gym/ssl/ssl_hw_challenge/*.py) and
+this project's classes of the same names, gives BOTH the same simulator — tests/fake_robosim.py, the float64 oracle behind the
+`robosim` surface (rsoccer_gym/Simulators/rsim.py:2) — seeds the global `random` / `numpy.random` streams the reference draws from
+(vss_gym.py:194-233, Utils/Utils.py:5-29) identically, feeds both the same random actions and requires every observation, reward,
+flag and info value of every step to be EQUAL (float equality, no tolerance), across resets.  Nothing of the reference is copied or
+committed: it is imported from where it lies, and only here.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import gymnasium_stub
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference"
+
+CHILD = r'''
+import importlib, json, random, sys
+import numpy as np
+import fake_robosim
+
+TASKS = {
+    "VSS-v0": ("vss.env_vss.vss_gym", "VSSEnv", 2),
+    "SSLStaticDefenders-v0": ("ssl.ssl_hw_challenge.static_defenders", "SSLHWStaticDefendersEnv", 5),
+    "SSLDribbling-v0": ("ssl.ssl_hw_challenge.dribbling", "SSLHWDribblingEnv", 4),
+    "SSLContestedPossession-v0": ("ssl.ssl_hw_challenge.contested_possession", "SSLContestedPossessionEnv", 5),
+    "SSLPassEndurance-v0": ("ssl.ssl_hw_challenge.pass_endurance", "SSLPassEnduranceEnv", 3),
+}
+
+
+def rollout(pkg, mod, cls, act_dim, seed, n_steps, kw):
+    """what a caller sees: (obs, reward, terminated, truncated, info) of every step, resets included"""
+    C = getattr(importlib.import_module(pkg + "." + mod), cls)
+    random.seed(seed); np.random.seed(seed)          # the streams the reference's placement and OU noise draw from
+    # every ~40 steps the simulator's state is overwritten behind both sides' backs (fake_robosim.INJECT, as the golden episodes were
+    # scripted): the ball anywhere up to 0.2 m beyond the field's lines (goals, balls out), at speed, or onto the agent's kicker; the
+    # agent robot anywhere (robot-out-of-field and distance branches) — so the terminal branches are reached on random episodes too
+    irng = np.random.default_rng(seed + 2000)
+    f = (fake_robosim.VSS if mod.startswith("vss") else fake_robosim.SSL)(kw.get("field_type", 0 if mod.startswith("vss") else 2), 1, 0, 25,
+                                                                          [0, 0, 0, 0], [[0, 0, 0]], []).get_field_params()
+    hx, hy = f["length"] / 2, f["width"] / 2
+    inject, t = {}, 0
+    while t < n_steps:
+        t += int(irng.integers(15, 70))
+        what = int(irng.integers(0, 4))
+        e = {}
+        if what in (0, 1):
+            e.update({0: float(irng.uniform(-hx - 0.2, hx + 0.2)), 1: float(irng.uniform(-hy - 0.2, hy + 0.2)),
+                      3: float(irng.uniform(-3, 3)), 4: float(irng.uniform(-3, 3))})
+            if what == 1:
+                e[1] = float(irng.uniform(-f["goal_width"] / 2, f["goal_width"] / 2)); e[0] = float(irng.choice([-1, 1]) * (hx + 0.05))   # into a goal
+        elif what == 2:
+            e.update({5: float(irng.uniform(-hx - 0.3, hx + 0.3)), 6: float(irng.uniform(-hy - 0.3, hy + 0.3))})
+        else:
+            e.update({3: 0.0, 4: 0.0})     # the ball stops dead (stalled-ball counters)
+        inject[t] = e
+    fake_robosim.arm(inject)
+    del SIMLOG[:]
+    env = C(**kw)
+    del SIMLOG[:]                                     # (the constructor's dummy line-up, rsim.py:20-24)
+    rng = np.random.default_rng(seed + 1000)         # the actions: a stream neither side touches
+    trace = []
+    obs, info = env.reset()
+    trace.append(("reset", np.asarray(obs).copy(), dict(info)))
+    episodes = 0
+    for t in range(n_steps):
+        style = rng.integers(0, 4)
+        a = rng.uniform(-1, 1, act_dim)
+        if style == 1:
+            a = np.sign(a)                            # bang-bang: saturated commands, kicks, dribbler on
+        elif style == 2:
+            a = a * 0.04                              # inside the dead zone of the VSS wheel map (vss_gym.py:73)
+        a = a.astype(np.float32)
+        obs, rew, term, trunc, info = env.step(a)
+        trace.append(("step", np.asarray(obs).copy(), float(rew), bool(term), bool(trunc),
+                      {k: (float(v) if np.ndim(v) == 0 else np.asarray(v).tolist()) for k, v in info.items()}, a.copy()))
+        if term or trunc or (t % 97 == 96):          # also reset in the middle of an episode
+            obs, info = env.reset()
+            trace.append(("reset", np.asarray(obs).copy(), dict(info)))
+            episodes += 1
+    env.close()
+    return trace, episodes, list(SIMLOG)
+
+
+# what crossed the `robosim` boundary (rsim.py:38,102,105): one record per env.reset() / env.step()
+SIMLOG = []
+_step0, _reset0 = fake_robosim._Sim.step, fake_robosim._Sim.reset
+def _step(self, cmds):
+    _step0(self, cmds)
+    SIMLOG.append(("step", np.array(cmds, dtype=np.float64).copy(), self.o.get_state().copy()))
+def _reset(self, ball, blue, yellow):
+    _reset0(self, ball, blue, yellow)
+    SIMLOG.append(("reset", self.o.get_state().copy()))
+fake_robosim._Sim.step, fake_robosim._Sim.reset = _step, _reset
+
+INFO_KEYS = {
+    1: ("goal_score", "move", "ball_grad", "energy", "goals_blue", "goals_yellow"),
+    2: ("goal", "rbt_in_gk_area", "done_ball_out", "done_ball_out_right", "done_rbt_out", "ball_dist", "ball_grad", "energy"),
+    3: None,
+    4: ("goal", "rbt_in_gk_area", "done_ball_out", "done_ball_out_right", "done_rbt_out", "ball_dist", "ball_grad", "energy", "collision"),
+    5: ("reversed_dist", "ball_grad"),
+}
+KINDS = {1: (0, 0, 3, 3), 2: (1, 2, 1, 6), 3: (1, 2, 1, 4), 4: (1, 2, 1, 1), 5: (1, 2, 2, 0)}
+
+
+def replay_through_the_oracle(task, trace, simlog, prec):
+    """the protocol (and the tolerances) of tests/test_oracle_golden.py on the episodes the reference just played: the oracle's task
+    arithmetic — what the fused kernels are bit-identical to — evaluates every transition the reference evaluated"""
+    from oracle import oracle as O
+    otol = 2e-7 if prec == "f64" else 3e-6
+    assert len(trace) == len(simlog)
+    e = last = None
+    first = True
+    worst = dict(obs=0.0, reward=0.0, info=0.0, cmds=0.0)
+    for i, (tr, sl) in enumerate(zip(trace, simlog)):
+        assert tr[0] == sl[0]
+        if tr[0] == "reset":
+            e = O.OracleEnv(*KINDS[task], 25, prec)
+            e.task_attach(task, 0, 0, 0)
+            e.set_state_full(np.append(sl[1], [0.0, 0.0]))
+            if task >= 3:
+                e.set_scalar(0)
+            d = float(np.max(np.abs(e.obs_eval() - tr[1]))); worst["obs"] = max(worst["obs"], d)
+            assert d <= otol, (task, prec, i, "reset obs", d)
+            last, first = sl[1], True
+            continue
+        _, obs, rew, term, trunc, info, act = tr
+        _, cmds, state = sl
+        if task == 1:
+            a6 = np.zeros((6, 2)); a6[0] = act
+            cm, want = e.cmds_eval(a6)[0], cmds[0]
+            ok = np.allclose(cm, want, rtol=3e-7 if prec == "f64" else 3e-6, atol=1e-6 if prec == "f64" else 2e-5)
+        elif task == 2:
+            cm, want = e.cmds_eval(act, last[7])[0], cmds[0]
+            ok = np.allclose(cm, want, rtol=0, atol=2e-6 if prec == "f64" else 3e-5)
+        else:
+            cm, want = e.cmds_eval(act, last[7]), cmds
+            ok = np.allclose(cm, want, rtol=0, atol=3e-6 if prec == "f64" else 3e-5)
+        worst["cmds"] = max(worst["cmds"], float(np.max(np.abs(np.asarray(cm) - np.asarray(want)))))
+        assert ok, (task, prec, i, "cmds", cm, want)
+        e.set_state_full(np.append(state, [0.0, 0.0]))
+        d = float(np.max(np.abs(e.obs_eval() - obs))); worst["obs"] = max(worst["obs"], d)
+        assert d <= otol, (task, prec, i, "obs", d)
+        r, dn = e.reward_eval(last, cmds, first)
+        assert dn == term, (task, prec, i, "done", dn, term)
+        worst["reward"] = max(worst["reward"], abs(r - rew))
+        assert abs(r - rew) <= (5e-5 if prec == "f32" else (2e-8 if task == 1 else 1e-7)), (task, prec, i, "reward", r, rew)
+        if INFO_KEYS[task]:
+            got, want = e.task_out()["info"], np.array([info[k] for k in INFO_KEYS[task]], dtype=np.float64)
+            worst["info"] = max(worst["info"], float(np.max(np.abs(got - want))))
+            assert np.allclose(got, want, rtol=0, atol=(3e-4 if prec == "f32" else 1e-6)), (task, prec, i, "info", got, want)
+        last, first = state, False
+    return worst
+
+
+def same(a, b, where):
+    assert a[0] == b[0], where
+    if a[0] == "reset":
+        assert a[1].dtype == b[1].dtype and np.array_equal(a[1], b[1]), (where, a[1], b[1])
+        assert a[2] == b[2], (where, a[2], b[2])
+        return
+    assert a[1].dtype == b[1].dtype and a[1].shape == b[1].shape and np.array_equal(a[1], b[1]), (where, "obs", a[1] - b[1])
+    assert a[2] == b[2], (where, "reward", a[2], b[2])
+    assert a[3] == b[3] and a[4] == b[4], (where, "flags", a[3:5], b[3:5])
+    assert a[5] == b[5], (where, "info", a[5], b[5])
+    assert np.array_equal(a[6], b[6])
+
+
+out = {}
+worst = {}
+n_steps, seeds = int(sys.argv[1]), [int(s) for s in sys.argv[2].split(",")]
+for env_id, (mod, cls, ad) in TASKS.items():
+    total = ended = 0
+    for seed in seeds:
+        ref, ep, simlog = rollout("rsoccer_gym", mod, cls, ad, seed, n_steps, {})
+        mine, ep2, simlog2 = rollout("rsoccer_amd", mod, cls, ad, seed, n_steps, dict(sim_backend=fake_robosim))
+        assert len(ref) == len(mine) and ep == ep2, (env_id, seed, len(ref), len(mine))
+        for i, (a, b) in enumerate(zip(ref, mine)):
+            same(a, b, f"{env_id} seed {seed} record {i}")
+        for i, (a, b) in enumerate(zip(simlog, simlog2)):     # ... and the same traffic crossed the robosim boundary (commands, placements)
+            assert a[0] == b[0] and all(np.array_equal(x, y) for x, y in zip(a[1:], b[1:])), (env_id, seed, "boundary record", i)
+        task = list(TASKS).index(env_id) + 1
+        for prec in ("f64", "f32"):
+            w = replay_through_the_oracle(task, ref, simlog, prec)
+            for k, v in w.items():
+                worst[(env_id, prec, k)] = max(worst.get((env_id, prec, k), 0.0), v)
+        total += sum(1 for r in ref if r[0] == "step")
+        ended += sum(1 for r in ref if r[0] == "step" and (r[3] or r[4]))
+    out[env_id] = [total, ended]
+out["worst"] = {" ".join(k): v for k, v in worst.items()}
+print("REFERENCE_LIVE_OK", json.dumps(out))
+'''
+
+
+def _run(tmp_path, n_steps, seeds):
+    stub_root = gymnasium_stub.write(str(tmp_path / "site"))
+    os.makedirs(os.path.join(stub_root, "pygame"), exist_ok=True)          # the reference's renderer imports it (rsoccer_gym/Render)
+    open(os.path.join(stub_root, "pygame", "__init__.py"), "w").close()
+    os.makedirs(os.path.join(stub_root, "robosim"), exist_ok=True)         # rsim.py:2 `import robosim`: the oracle-backed stand-in
+    with open(os.path.join(stub_root, "robosim", "__init__.py"), "w") as f:
+        f.write("from fake_robosim import VSS, SSL\n")
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([stub_root, REF, ROOT, HERE] + ([env["PYTHONPATH"]] if env.get("PYTHONPATH") else []))
+    r = subprocess.run([sys.executable, "-c", CHILD, str(n_steps), ",".join(str(s) for s in seeds)], env=env, capture_output=True, text=True,
+                       timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("REFERENCE_LIVE_OK")]
+    assert line, r.stdout[-2000:]
+    return json.loads(line[0].split(" ", 1)[1])
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "rsoccer_gym")), reason="the reference tree is only present in the build container")
+def test_host_layer_equals_the_reference_on_random_episodes(tmp_path, oracle_mod):
+    res = _run(tmp_path, 700, (3, 14, 159))
+    worst = res.pop("worst")
+    assert set(res) == {"VSS-v0", "SSLStaticDefenders-v0", "SSLDribbling-v0", "SSLContestedPossession-v0", "SSLPassEndurance-v0"}
+    assert len(worst) == 5 * 2 * 4    # the oracle's task arithmetic was replayed in both precisions (obs / reward / info / cmds)
+    for env_id, (steps, ended) in res.items():
+        assert steps == 3 * 700, (env_id, steps)
+    # the short-episode tasks did end episodes on their own (terminal branches were compared, not only shaping terms)
+    assert res["SSLStaticDefenders-v0"][1] > 0 and res["SSLContestedPossession-v0"][1] > 0 and res["SSLPassEndurance-v0"][1] > 0, res
+
+
+if __name__ == "__main__":
+    import pathlib
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        print(_run(pathlib.Path(d), int(sys.argv[1]) if len(sys.argv) > 1 else 3000, tuple(range(20, 30))))
