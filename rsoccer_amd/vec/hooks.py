@@ -180,7 +180,10 @@ class _VecBaseEnv:
             self.steps.zero_()
         else:
             self.steps.masked_fill_(self._torch.as_tensor(env_mask, device=self.device).to(self._torch.bool), 0)
-        self.last_frame = None
+        # no frame precedes a reset — except in graph mode, where the two buffers keep their roles for good (enable_graph_capture): a
+        # replayed step() refreshes the previous frame on the device, and the attribute a caller reads must not depend on whether a
+        # reset() happened to come between the capture and the replay
+        self.last_frame = self._other if (self._graph_mode and self.keep_last_frame) else None
         return self._frame_to_observations(), {}
 
     def close(self):
