@@ -13,7 +13,8 @@ sees exactly the reference's object graph.
 """
 from typing import Dict
 
-from rsoccer_amd.Entities.records import Ball, Robot
+from rsoccer_amd.Entities.Ball import Ball
+from rsoccer_amd.Entities.Robot import Robot
 
 _VSS_BLOCK = ("x", "y", "theta", "v_x", "v_y", "v_theta")
 _SSL_BLOCK = _VSS_BLOCK + ("infrared", "v_wheel0", "v_wheel1", "v_wheel2", "v_wheel3")
