@@ -75,19 +75,23 @@ def test_make_vss_v0_runs_1200_steps():
 
 
 def test_fused_observation_matches_reference_arithmetic():
-    """The device-side observation of arbitrary states equals the reference's (golden vectors)."""
+    """The device-side observation of arbitrary states equals the reference's (golden vectors).  The states are written behind the
+    task's back (rsx_set_state) into a handle with time step 0 — a step() there is commands -> observation without physics — and one
+    step brings the observation out (`final_obs` for the states that end an episode: their `obs` is already the next episode's)."""
     import torch
     from rsoccer_amd import _lib as L
     for task, kind, ft, nb, ny, key in ((1, 0, 0, 3, 3, "vss"), (2, 1, 2, 1, 6, "sd")):
         states = G[f"{key}_obs_states"]
         B = len(states)
-        sim = L.Sim(kind, ft, nb, ny, 25, B)
+        sim = L.Sim(kind, ft, nb, ny, 0, B)
         sim.task_attach(task, 0, 0, 0)
+        sim.task_reset()
         sim.set_state(np.concatenate([states, np.zeros((B, 2))], 1))
-        dummy = (np.zeros((B, 4)), np.zeros((B, nb, 3)), np.zeros((B, ny, 3)))
-        sim.task_reset_to(*dummy, env_mask=np.zeros(B, dtype=np.uint8))   # nothing teleported: obs refresh only
+        sim.task_step(None)
         torch.cuda.synchronize()
-        obs = sim.task_tensors()["obs"].cpu().numpy()
+        t = sim.task_tensors()
+        ended = (t["terminated"].cpu().numpy() | t["truncated"].cpu().numpy()).astype(bool)
+        obs = np.where(ended[:, None], t["final_obs"].cpu().numpy(), t["obs"].cpu().numpy())
         assert np.max(np.abs(obs - G[f"{key}_obs"])) <= 3e-6
         sim.close()
 
