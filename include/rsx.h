@@ -194,7 +194,12 @@ int rsx_step_wire(rsx_sim* h, void* stream);
 
 /* full-state restore (checkpoint/resume, also used by parity tests): state
  * [B][state_dim + RSX_STATE_EXTRA_ROWS] host f64 = get_state() layout + ball vertical velocity
- * + ball spin. rsx_get_state_full is its inverse. */
+ * + ball spin. rsx_get_state_full is its inverse.
+ * On a handle with a task attached this overwrites the SIMULATOR state only: observations, episode bookkeeping and the per-episode
+ * task scalars (previous ball potential, checkpoint / stalled-step counters) are left as the last step wrote them, so the shaping
+ * terms of the next step's reward refer to a frame that no longer exists — and how they do differs between kernel layouts (the
+ * one-lane-per-env VSS kernel derives the previous potential from the ball position it finds).  To move envs of a fused run use
+ * rsx_task_reset_to (new episode) or rsx_task_checkpoint_load (everything). */
 int rsx_set_state(rsx_sim* h, const double* state, void* stream);
 int rsx_get_state_full(rsx_sim* h, double* out, void* stream);
 
