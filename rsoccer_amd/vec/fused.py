@@ -181,7 +181,9 @@ class VecFusedEnv:
 
     @property
     def state(self):
-        """[state_dim + 2, num_envs] float32 view of the SoA simulator state."""
+        """[state_dim + 2, num_envs] float32 view of the SoA simulator state — for READING (frames for logging, rendering, analysis).
+        Writing it moves bodies behind the task's back: observations and per-episode task scalars are not refreshed (include/rsx.h:
+        rsx_set_state); to re-place envs use ``reset_to``."""
         return self.sim.state_tensor()
 
     def close(self):
