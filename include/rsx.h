@@ -194,7 +194,9 @@ int rsx_step_wire(rsx_sim* h, void* stream);
 
 /* full-state restore (checkpoint/resume, also used by parity tests): state
  * [B][state_dim + RSX_STATE_EXTRA_ROWS] host f64 = get_state() layout + ball vertical velocity
- * + ball spin. rsx_get_state_full is its inverse.
+ * + ball spin. rsx_get_state_full is its inverse.  (The infrared entry of an SSL robot is a flag, Entities/Frame.py:86: give 0 or 1.
+ * Any other non-zero value reads as "on"; a step WITH physics rewrites the entry as 0 / 1, a step of a handle with time_step_ms 0
+ * leaves what it finds when it steps in place and writes 1 when it writes another buffer, rsx_step_dev_flip.)
  * On a handle with a task attached this overwrites the SIMULATOR state only: observations, episode bookkeeping and the per-episode
  * task scalars (previous ball potential, checkpoint / stalled-step counters) are left as the last step wrote them, so the shaping
  * terms of the next step's reward refer to a frame that no longer exists — and how they do differs between kernel layouts (the

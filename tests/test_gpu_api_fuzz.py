@@ -60,7 +60,8 @@ class _Mirror:
 
     def __init__(self, L, O, name, seed, rng, log):
         self.L, self.O, self.rng, self.log = L, O, rng, log
-        (self.task, self.kind, self.ft, self.nb, self.ny, self.B, self.max_steps, self.layouts) = CONFIGS[name]
+        (self.task, self.kind, self.ft, self.nb, self.ny, self.B, self.max_steps, self.layouts) = CONFIGS[name] if isinstance(name, str) else name[:8]
+        self.ts = 25 if isinstance(name, str) else name[8]
         self.seed, self.base = seed, int(rng.integers(0, 1 << 20))
         self.layout = None
         self.captured = False
@@ -72,7 +73,7 @@ class _Mirror:
     def _handle(self, layout):
         os.environ["RSX_LAYOUT"] = layout
         try:
-            sim = self.L.Sim(self.kind, self.ft, self.nb, self.ny, 25, self.B)
+            sim = self.L.Sim(self.kind, self.ft, self.nb, self.ny, self.ts, self.B)
             sim.task_attach(self.task, self.seed, self.base, self.max_steps)
         finally:
             del os.environ["RSX_LAYOUT"]
@@ -81,7 +82,7 @@ class _Mirror:
         return sim
 
     def _oracles(self, seed):
-        refs = [self.O.OracleEnv(self.kind, self.ft, self.nb, self.ny, 25, "f32") for _ in range(self.B)]
+        refs = [self.O.OracleEnv(self.kind, self.ft, self.nb, self.ny, self.ts, "f32") for _ in range(self.B)]
         for e, r in enumerate(refs):
             r.task_attach(self.task, seed, self.base + e, self.max_steps)
         return refs
@@ -402,19 +403,20 @@ class _RawMirror:
     def __init__(self, L, O, name, rng, log):
         import torch
         self.torch, self.L, self.rng, self.log = torch, L, rng, log
-        self.kind, self.ft, self.nb, self.ny, self.B = RAW_CONFIGS[name]
+        self.kind, self.ft, self.nb, self.ny, self.B = RAW_CONFIGS[name] if isinstance(name, str) else name[:5]
+        self.ts = 25 if isinstance(name, str) else name[5]
         self.N = self.nb + self.ny
         knobs = {}
         if rng.random() < 0.25:
             knobs["RSX_NO_ZERO_COPY" if self.B <= 64 else "RSX_NO_WIRE_PATH"] = "1"
         os.environ.update(knobs)
         try:
-            self.sim = L.Sim(self.kind, self.ft, self.nb, self.ny, 25, self.B)
+            self.sim = L.Sim(self.kind, self.ft, self.nb, self.ny, self.ts, self.B)
         finally:
             for k in knobs:
                 del os.environ[k]
         self.knobs = ",".join(knobs) or "default"
-        self.refs = [O.OracleEnv(self.kind, self.ft, self.nb, self.ny, 25, "f32") for _ in range(self.B)]
+        self.refs = [O.OracleEnv(self.kind, self.ft, self.nb, self.ny, self.ts, "f32") for _ in range(self.B)]
         self.fp = self.sim.get_field_params()
         self.C = self.sim.cmd_dim
 
@@ -506,7 +508,9 @@ class _RawMirror:
     def op_set_state(self):
         s = self.sim.get_state_full()
         k = self.rng.integers(0, s.shape[1], 6)
-        s[:, k] = (s[:, k] + self.rng.normal(0, 0.05, (self.B, 6))).astype(np.float32)
+        if self.kind == 1:   # the infrared column of an SSL robot is a flag (Frame.py:86 reads it with bool()): 0 or 1 stays 0 or 1
+            k = np.array([c for c in k if not (c >= 5 and c < 5 + 11 * self.N and (c - 5) % 11 == 6)], dtype=int)
+        s[:, k] = (s[:, k] + self.rng.normal(0, 0.05, (self.B, len(k)))).astype(np.float32)
         self.sim.set_state(s)
         for e, r in enumerate(self.refs):
             r.set_state_full(s[e])
@@ -646,6 +650,34 @@ def test_random_call_sequences_through_the_vector_envs_match_the_oracle(oracle_m
         run_sequence(L, oracle_mod, name, seed * 1000 + sorted(CONFIGS).index(name), 45, through_vec=True)
 
 
+def random_task_config(rng):
+    """team sizes, fields, time steps and TimeLimits no registered id uses: the run-time-robot-count kernel variants of every lane-group width"""
+    ts = int(rng.choice([0, 5, 7, 16, 25, 33, 50]))
+    B, ms = int(rng.choice([1, 7, 33, 65])), int(rng.integers(1, 30))
+    what = int(rng.integers(0, 3))
+    if what == 0:      # VSS-v0 arithmetic on any VSS line-up whose observation fits (4 + 7 nb + 5 ny <= 64)
+        while True:
+            nb, ny = int(rng.integers(1, 6)), int(rng.integers(0, 6))
+            if 4 + 7 * nb + 5 * ny <= 64:
+                break
+        return (1, 0, int(rng.integers(0, 2)), nb, ny, B, ms, ("lanes",), ts)
+    if what == 1:      # static defenders 1 v N
+        return (2, 1, int(rng.integers(0, 3)), 1, int(rng.integers(0, 11)), B, ms, ("lanes",), ts)
+    nb, ny = int(rng.integers(0, 12)), int(rng.integers(0, 12))
+    if nb + ny == 0:
+        nb = 1
+    return (int(rng.choice([6, 7])), 1, int(rng.integers(0, 3)), nb, ny, B, ms, ("lanes",), ts)
+
+
+def random_raw_config(rng):
+    kind = int(rng.integers(0, 2))
+    hi = 6 if kind == 0 else 12
+    nb, ny = int(rng.integers(0, hi)), int(rng.integers(0, hi))
+    if nb + ny == 0:
+        ny = 1
+    return (kind, int(rng.integers(0, 2 if kind == 0 else 3)), nb, ny, int(rng.choice([1, 9, 64, 65, 100])), int(rng.choice([0, 5, 7, 16, 25, 33, 50])))
+
+
 if __name__ == "__main__":
     import argparse
     import time
@@ -654,6 +686,7 @@ if __name__ == "__main__":
     ap.add_argument("--ops", type=int, default=120)
     ap.add_argument("--first-seed", type=int, default=100000)
     ap.add_argument("--configs", default=",".join(CONFIGS))
+    ap.add_argument("--random-configs", type=int, default=0, help="that many random team sizes / fields / time steps instead of the named configurations")
     a = ap.parse_args()
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import __graft_entry__ as g
@@ -662,6 +695,21 @@ if __name__ == "__main__":
     from rsoccer_amd import _lib as L
     O.build()
     bad = 0
+    if a.random_configs:
+        crng = np.random.default_rng(a.first_seed)
+        t0, n_calls = time.time(), 0
+        for i in range(a.random_configs):
+            raw, cfg = random_raw_config(crng), random_task_config(crng)
+            for what, c, run in (("raw", raw, run_raw_sequence), ("task", cfg, run_sequence)):
+                try:
+                    n_calls += len(run(L, O, c, a.first_seed + i, a.ops))
+                except AssertionError as ex:
+                    bad += 1
+                    print(f"FAIL {what} {c} seed {a.first_seed + i}: {str(ex)[:1500]}", flush=True)
+                except L.RsxError as ex:
+                    print(f"refused {what} {c}: {ex}", flush=True)
+        print(f"random configurations: {a.random_configs} x (simulator surface + fused task), {n_calls} calls compared call by call, {time.time() - t0:.0f} s, failures {bad}", flush=True)
+        sys.exit(1 if bad else 0)
     for name in RAW_CONFIGS if a.configs == ",".join(CONFIGS) else []:
         t0 = time.time()
         n_calls = 0
