@@ -555,6 +555,8 @@ def evidence(line):
     if "graph_policy_loop_env_steps_per_s" in pl:
         ev["graph_loop"] = float("%.3g" % pl["graph_policy_loop_env_steps_per_s"])
         ev["eager_loop"] = float("%.3g" % pl.get("eager_policy_loop_env_steps_per_s", 0.0))
+        if "fused_policy_loop_env_steps_per_s" in pl:
+            ev["fused_policy_loop"] = float("%.3g" % pl["fused_policy_loop_env_steps_per_s"])
     return ev
 
 
@@ -730,6 +732,32 @@ def python_layer(torch, dev, B=4096, n=2000):
                 best = max(best, v)
                 del g
             out["graph_policy_loop_env_steps_per_s"] = best
+            try:   # the same MLP as ONE hand-written kernel (examples/fused_policy.hip): what the loop costs when the policy is one launch
+                fpol = VPL.make_fused_policy(env.sim.obs_dim, env.sim.act_dim, env.device)
+                VPL.run_eager(env, fpol, actions, 50)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                VPL.run_eager(env, fpol, actions, 2000)
+                torch.cuda.synchronize()
+                out["eager_fused_policy_loop_env_steps_per_s"] = B * 2000 / (time.perf_counter() - t0)   # two launches per iteration: eager is not host-bound
+                for iters in (1, 8):
+                    g = VPL.build_graph(env, fpol, actions, iters)
+                    for _ in range(5):
+                        g.replay()
+                    torch.cuda.synchronize()
+                    reps = 3000 // iters
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        g.replay()
+                    torch.cuda.synchronize()
+                    out[f"graph_fused_policy_loop_env_steps_per_s_{iters}_per_graph"] = B * reps * iters / (time.perf_counter() - t0)
+                    del g
+                out["fused_policy_loop_env_steps_per_s"] = max(out["eager_fused_policy_loop_env_steps_per_s"],
+                                                               out["graph_fused_policy_loop_env_steps_per_s_1_per_graph"], out["graph_fused_policy_loop_env_steps_per_s_8_per_graph"])
+                out["fused_policy_loop_note"] = ("the same 40-64-2 MLP as ONE hand-written kernel (examples/fused_policy.hip) -> VecVSSEnv.step(actions): two launches "
+                                                 "per iteration; eager and replayed from a graph")
+            except Exception as ex:
+                out["fused_policy_loop_error"] = repr(ex)
             out["policy_loop_note"] = (f"{B} envs, 40-64-2 tanh MLP (two addmm + two tanh kernels) -> VecVSSEnv.step(actions); graph = "
                                        "torch.cuda.CUDAGraph replay of 1 or 8 iterations per graph, five kernel nodes per iteration")
             env.close()

@@ -2,6 +2,7 @@
 reference-shaped single-env tasks, the fused batched envs and the batched-hook base classes."""
 import os
 import random
+import sys
 
 import numpy as np
 import pytest
@@ -479,3 +480,37 @@ def test_vec_env_reset_with_a_seed_starts_over_like_a_fresh_env(name, capture):
     o3, _ = fresh.reset(seed=11)
     assert not torch.equal(o2, o3) or name == "VecSSLDribblingEnv"
     used.close(); fresh.close()
+
+
+def test_fused_policy_example_kernel_matches_the_torch_policy_and_replays_from_a_graph():
+    """examples/fused_policy.hip (the 40-64-2 tanh MLP of examples/vec_policy_loop.py as ONE hand-written kernel): same actions as the
+    four-kernel torch form, also for a batch that is not a multiple of the envs a wave serves and for the SSLStaticDefenders shapes;
+    policy -> env.step captured into a hipGraph replays like the eager calls."""
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import vec_policy_loop as VPL
+    from rsoccer_amd import vec
+    for od, ad, B in ((40, 2, 4096), (40, 2, 1023), (24, 5, 770)):
+        ref, fused = VPL.make_policy(od, ad, torch.device("cuda", 0)), VPL.make_fused_policy(od, ad, torch.device("cuda", 0))
+        obs = torch.empty(B, od, device="cuda").uniform_(-1.2, 1.2)
+        want, got = ref(obs, torch.empty(B, ad, device="cuda")), fused(obs, torch.full((B, ad), 7.0, device="cuda"))
+        torch.cuda.synchronize()
+        assert float((got - want).abs().max()) <= 2e-5 and float(got.abs().max()) <= 1.0
+    def run(graph):
+        env = vec.VecVSSEnv(512, device=0, seed=5)
+        env.reset()
+        pol = VPL.make_fused_policy(env.sim.obs_dim, env.sim.act_dim, env.device)
+        actions = torch.zeros(512, 2, device="cuda")
+        with torch.no_grad():
+            if graph:
+                g = VPL.build_graph(env, pol, actions, 4)     # (takes one eager step itself: torch's warm-up convention)
+                for _ in range(10):
+                    g.replay()
+            else:
+                VPL.run_eager(env, pol, actions, 41)
+        torch.cuda.synchronize()
+        out = (env.sim.get_state_full(), env._t["obs"].cpu().numpy().copy(), env.metrics())
+        env.close()
+        return out
+    a, b = run(False), run(True)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
