@@ -9,7 +9,12 @@ NEW handle of another kernel layout, rsx_task_enable_capture, rsx_task_reseed, r
 EVERY call that observations, rewards, flags, info rows, step counters, terminal observations, the full simulator state and the
 device-side metrics equal what one oracle env per env id produces for the same sequence — bit for bit.
 
-`python tests/test_gpu_api_fuzz.py [--seeds N] [--ops M]` runs a longer campaign on the GPU box (what profiles/r06_api_fuzz.txt holds).
+The same for the simulator surface without a task (what replaces robosim.{VSS,SSL}: host float64 and device SoA forms, zero-copy and
+wire-buffer paths, poses and states far outside what a task produces), for the sequences driven through rsoccer_amd.vec, and — in the
+campaign form — for random configurations (team sizes, field types, time steps, batch sizes).
+
+`python tests/test_gpu_api_fuzz.py [--seeds N] [--ops M] [--random-configs K]` runs a longer campaign on the GPU box (what
+profiles/r06_api_fuzz.txt holds).
 """
 import os
 import sys
@@ -481,9 +486,11 @@ class _RawMirror:
 
     def op_step(self):
         c = self._cmds()
-        if self.rng.random() < 0.15:   # commands far beyond the motors' range (clamped on both sides, rsim.py:92-101 sets no limit)
-            c[..., -2 if self.kind == 0 else 1:] *= 1e6 if self.kind == 0 else 1.0
-            c = c * (1e4 if self.kind == 0 else 1.0)
+        if self.rng.random() < 0.15:   # commands far beyond the motors' range (clamped on both sides; rsim.py:92-101 / :129-153 set no limit)
+            if self.kind == 0:
+                c = c * 1e6                      # wheel speeds, rad/s
+            else:
+                c[..., 1:5] = c[..., 1:5] * 1e4  # wheel speeds or local velocities; the flag and the kick / dribbler columns stay what they are
         self.sim.step(c)
         self._mirror_step(c)
 
