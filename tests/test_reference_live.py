@@ -63,6 +63,19 @@ def rollout(pkg, mod, cls, act_dim, seed, n_steps, kw):
         else:
             e.update({3: 0.0, 4: 0.0})     # the ball stops dead (stalled-ball counters)
         inject[t] = e
+    if cls == "SSLHWDribblingEnv":
+        # the dribbling course (dribbling.py:155-183): the ball carried across y = 0 inside the x band of each checkpoint in turn, the
+        # robot kept inside its bounds — whole courses (seven checkpoints -> done), and now and then a crossing the wrong way round
+        bands = [(-0.75, 1), (-1.25, -1), (-1.75, 1), (-2.5, -1), (-1.75, 1), (-2.5, -1), (-1.75, 1)]
+        t = 5
+        while t + 16 < n_steps:
+            wrong = irng.random() < 0.2
+            for k, (x, side) in enumerate(bands):
+                if wrong and k == 3:
+                    side = -side
+                for half, y in enumerate((0.1 * side, -0.1 * side)):
+                    inject[t + 2 * k + half] = {0: x, 1: y, 3: 0.0, 4: 0.0, 5: -1.0, 6: 0.5, 8: 0.0, 9: 0.0}
+            t += int(irng.integers(25, 60))
     fake_robosim.arm(inject)
     del SIMLOG[:]
     env = C(**kw)
@@ -179,7 +192,7 @@ out = {}
 worst = {}
 n_steps, seeds = int(sys.argv[1]), [int(s) for s in sys.argv[2].split(",")]
 for env_id, (mod, cls, ad) in TASKS.items():
-    total = ended = 0
+    total = ended = rewarded = 0
     for seed in seeds:
         ref, ep, simlog = rollout("rsoccer_gym", mod, cls, ad, seed, n_steps, {})
         mine, ep2, simlog2 = rollout("rsoccer_amd", mod, cls, ad, seed, n_steps, dict(sim_backend=fake_robosim))
@@ -195,7 +208,8 @@ for env_id, (mod, cls, ad) in TASKS.items():
                 worst[(env_id, prec, k)] = max(worst.get((env_id, prec, k), 0.0), v)
         total += sum(1 for r in ref if r[0] == "step")
         ended += sum(1 for r in ref if r[0] == "step" and (r[3] or r[4]))
-    out[env_id] = [total, ended]
+        rewarded += sum(1 for r in ref if r[0] == "step" and r[2] != 0.0)
+    out[env_id] = [total, ended, rewarded]
 out["worst"] = {" ".join(k): v for k, v in worst.items()}
 print("REFERENCE_LIVE_OK", json.dumps(out))
 '''
@@ -224,8 +238,8 @@ def test_host_layer_equals_the_reference_on_random_episodes(tmp_path, oracle_mod
     worst = res.pop("worst")
     assert set(res) == {"VSS-v0", "SSLStaticDefenders-v0", "SSLDribbling-v0", "SSLContestedPossession-v0", "SSLPassEndurance-v0"}
     assert len(worst) == 5 * 2 * 4    # the oracle's task arithmetic was replayed in both precisions (obs / reward / info / cmds)
-    for env_id, (steps, ended) in res.items():
-        assert steps == 3 * 700, (env_id, steps)
+    for env_id, (steps, ended, rewarded) in res.items():
+        assert steps == 3 * 700 and rewarded > 0, (env_id, steps, rewarded)
     # the short-episode tasks did end episodes on their own (terminal branches were compared, not only shaping terms)
     assert res["SSLStaticDefenders-v0"][1] > 0 and res["SSLContestedPossession-v0"][1] > 0 and res["SSLPassEndurance-v0"][1] > 0, res
 
