@@ -171,6 +171,52 @@ class _Mirror:
         for e, r in enumerate(self.refs):
             r.task_reset_to(ball[e], blue[e], yellow[e] if self.ny else np.zeros(0))
 
+    def _teleport(self, cols):
+        """overwrite state entries of every env behind the task's back (rsx_set_state on a fused handle: the simulator state only —
+        include/rsx.h); mirrored into the oracle.  SSL tasks only: the one-lane VSS-v0 kernel derives its task scalar from the ball it
+        finds (documented there), so the layouts agree after such a write for the SSL tasks and are not asked to for VSS-v0"""
+        s = self.sim.get_state_full()
+        for c, v in cols.items():
+            s[:, c] = np.float32(v)
+        self.sim.set_state(s)
+        for e, r in enumerate(self.refs):
+            r.set_state_full(s[e])
+
+    def op_teleport(self):
+        if self.task == 1:
+            return self.op_step_random()
+        f = self.fp
+        hx, hy = f["length"] / 2 + 0.2, f["width"] / 2 + 0.2
+        what = int(self.rng.integers(0, 3))
+        if what == 0:      # the ball anywhere, also beyond the lines and in the goals, at speed
+            self._teleport({0: self.rng.uniform(-hx, hx), 1: self.rng.uniform(-hy, hy), 3: self.rng.uniform(-3, 3), 4: self.rng.uniform(-3, 3)})
+        elif what == 1:    # the agent robot anywhere (out-of-bounds and distance branches)
+            self._teleport({5: self.rng.uniform(-hx, hx), 6: self.rng.uniform(-hy, hy)})
+        else:              # the ball stops dead
+            self._teleport({3: 0.0, 4: 0.0})
+
+    def op_course(self):
+        """SSLDribbling: the ball carried across y = 0 inside the x band of each checkpoint in turn (dribbling.py:155-183), one step after
+        each move — the checkpoint counter, its observation entry, the reward and the end after seven on the device, in both layouts"""
+        if self.task != 3:
+            return self.op_step_random()
+        import torch
+        bands = [(-0.75, 1), (-1.25, -1), (-1.75, 1), (-2.5, -1), (-1.75, 1), (-2.5, -1), (-1.75, 1)]
+        wrong = self.rng.random() < 0.25
+        for k, (x, side) in enumerate(bands[: int(self.rng.integers(2, 8))]):
+            if wrong and k == 3:
+                side = -side
+            # 2 cm on one side of the line, moving across it at 2 m/s: the step itself carries the ball over (the reward compares the
+            # ball before and after a step); the agent parked away from it, inside its bounds
+            self._teleport({0: x, 1: 0.02 * side, 3: 0.0, 4: -2.0 * side, 5: -1.0, 6: 0.5, 8: 0.0, 9: 0.0})
+            a = np.zeros((self.B, self.sim.act_dim), dtype=np.float32)
+            self.tens["actions"].copy_(torch.from_numpy(a))
+            self.sim.task_step(self.tens["actions"].data_ptr())
+            for e, r in enumerate(self.refs):
+                r.task_step(a[e])
+            self.steps_taken += 1
+            self.compare("course")
+
     def op_graph_replays(self):
         """capture one fed-action step into a hipGraph and replay it a few times (only device-keyed handles may)"""
         import torch
@@ -359,7 +405,7 @@ class _VecMirror(_Mirror):
 
 
 OPS = [("step_fed", 5), ("step_random", 4), ("step_n", 3), ("rollout", 3), ("reset", 1), ("reset_to", 2),
-       ("checkpoint_to_new_handle", 2), ("enable_capture", 1), ("reseed", 1), ("graph_replays", 1), ("metrics", 2)]
+       ("checkpoint_to_new_handle", 2), ("enable_capture", 1), ("reseed", 1), ("graph_replays", 1), ("metrics", 2), ("teleport", 2), ("course", 1)]
 
 
 def run_sequence(L, O, name, seed, n_ops, through_vec=False):
@@ -616,6 +662,26 @@ def test_masked_reset_to_leaves_the_other_envs_observations_alone(oracle_mod, se
     count AFTER the step's reward moved it, not the one the step's observation saw (dribbling.py: observation before reward)"""
     from rsoccer_amd import _lib as L
     run_sequence(L, oracle_mod, "SSLDribbling-v0", seed, 150)
+
+
+@pytest.mark.parametrize("layout", ["lanes", "epl"])
+def test_dribbling_course_earns_its_checkpoints_on_the_device(oracle_mod, layout):
+    """the course op of the fuzzer really walks SSLDribbling's checkpoint logic (dribbling.py:155-183) on the device: counters move, the
+    seventh checkpoint ends the episode as a success — compared with the oracle after every step, in both kernel layouts"""
+    from rsoccer_amd import _lib as L
+    CONFIGS["_course"] = (3, 1, 2, 1, 4, 37, 400, (layout,))
+    try:
+        m = _Mirror(L, oracle_mod, "_course", 5, np.random.default_rng(3), [])
+        m.op_reset()
+        m.compare("reset")
+        for _ in range(8):
+            m.op_course()
+        got = m.sim.read_metrics()
+        assert got[1] > 0 and got[2] > 0, got          # episodes ended, some of them by completing the course
+        m.compare_metrics()
+        m.sim.close()
+    finally:
+        del CONFIGS["_course"]
 
 
 def test_masked_reset_to_leaves_the_other_envs_flags_alone(oracle_mod):
