@@ -35,6 +35,7 @@ CONFIGS = {
     "SSLDribbling-v0": (3, 1, 2, 1, 4, 37, 29, ("lanes", "epl")),
     "SSLContestedPossession-v0": (4, 1, 2, 1, 1, 45, 13, ("lanes", "epl")),
     "SSLPassEndurance-v0": (5, 1, 2, 2, 0, 33, 11, ("lanes", "epl")),
+    "SSLPassEndurance-v0-long-episodes": (5, 1, 2, 2, 0, 17, 70, ("lanes", "epl")),   # long enough for the stalled-ball end (pass_endurance.py:205-214)
     "scrimmage-11v11-crowded": (7, 1, 1, 11, 11, 9, 15, ("lanes", "quad")),
     "scrimmage-3v2": (6, 1, 2, 3, 2, 21, 9, ("lanes",)),
 }
@@ -183,7 +184,7 @@ class _Mirror:
             r.set_state_full(s[e])
 
     def op_teleport(self):
-        if self.task == 1:
+        if self.task == 1:   # (VSS-v0: also a checkpoint re-derives the previous potential from the ball it saves — rsx.h: rsx_set_state)
             return self.op_step_random()
         f = self.fp
         hx, hy = f["length"] / 2 + 0.2, f["width"] / 2 + 0.2
