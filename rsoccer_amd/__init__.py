@@ -10,7 +10,8 @@ Importing the package registers the environment ids of the reference registry
     SSLPassEndurance-v0        SSLPassEnduranceEnv          1200 steps
 
 ``rsoccer_amd.make(id)`` returns the single-environment, reference-shaped object (hooks in
-Python, physics on the GPU).  ``rsoccer_amd.vec`` holds the batched, fully fused versions.
+Python, physics on the GPU).  ``rsoccer_amd.make_vec(id, num_envs)`` returns the batched, fully fused version (the classes of
+``rsoccer_amd.vec``).
 """
 __version__ = "0.1.0"
 
@@ -28,4 +29,25 @@ register(id="SSLContestedPossession-v0",
 register(id="SSLPassEndurance-v0", entry_point="rsoccer_amd.ssl.ssl_hw_challenge:SSLPassEnduranceEnv",
          max_episode_steps=1200)
 
-__all__ = ["make", "register", "registry", "__version__"]
+# registered id -> the fused batched class of rsoccer_amd.vec that steps it (one kernel launch per step for the whole batch)
+VECTOR_CLASSES = {
+    "VSS-v0": "VecVSSEnv",
+    "SSLStaticDefenders-v0": "VecSSLStaticDefendersEnv",
+    "SSLDribbling-v0": "VecSSLDribblingEnv",
+    "SSLContestedPossession-v0": "VecSSLContestedPossessionEnv",
+    "SSLPassEndurance-v0": "VecSSLPassEnduranceEnv",
+}
+
+
+def make_vec(id, num_envs, **kwargs):
+    """``num_envs`` copies of a registered task on one GPU — the batched counterpart of ``make(id)`` (the shape of
+    ``gymnasium.make_vec(id, num_envs=...)``): the fused class of :mod:`rsoccer_amd.vec` for that id, with the registry's episode
+    limit unless ``max_episode_steps`` says otherwise.  Further keywords go to the class: ``device``, ``seed``, ``env_id_base``
+    (global id of env 0: shards of one population over several GPUs), ``max_episode_steps``."""
+    if id not in VECTOR_CLASSES:
+        raise KeyError(f"no batched environment for id {id!r}; registered: {sorted(VECTOR_CLASSES)}")
+    from rsoccer_amd import vec
+    return getattr(vec, VECTOR_CLASSES[id])(int(num_envs), **kwargs)
+
+
+__all__ = ["make", "make_vec", "register", "registry", "VECTOR_CLASSES", "__version__"]

@@ -514,3 +514,23 @@ def test_fused_policy_example_kernel_matches_the_torch_policy_and_replays_from_a
         return out
     a, b = run(False), run(True)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+
+
+def test_make_vec_builds_the_fused_env_of_every_registered_id():
+    """rsoccer_amd.make_vec(id, num_envs): the registry's episode limit by default, keywords reach the class, the env steps"""
+    import json
+    import torch
+    import rsoccer_amd
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "registry.json")))
+    for env_id, spec in ref.items():
+        env = rsoccer_amd.make_vec(env_id, 96, seed=3, env_id_base=1000)
+        assert env.num_envs == 96 and env.max_episode_steps == spec["max_episode_steps"]
+        obs, info = env.reset()
+        assert obs.shape == (96, env.single_observation_space.shape[0]) and info == {}
+        obs, rew, term, trunc, info = env.step(None)
+        torch.cuda.synchronize()
+        assert torch.isfinite(obs).all() and rew.shape == (96,)
+        env.close()
+    env = rsoccer_amd.make_vec("VSS-v0", 8, max_episode_steps=5)
+    assert env.max_episode_steps == 5
+    env.close()

@@ -313,6 +313,23 @@ def test_all_five_reference_ids_are_registered():
         assert rsoccer_amd.registry[env_id]["entry_point"].split(":")[1] == spec["entry_point"].split(":")[1]
 
 
+def test_every_registered_id_has_a_batched_class_behind_make_vec():
+    """`rsoccer_amd.make_vec(id, num_envs)` — the batched counterpart of the registry's make(): every id maps to a class of rsoccer_amd.vec
+    with the registry's episode limit, unknown ids are refused by name (no GPU needed for the mapping)"""
+    import json
+    import rsoccer_amd
+    from rsoccer_amd import _lib, vec
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "registry.json")))
+    assert set(rsoccer_amd.VECTOR_CLASSES) == set(ref)
+    limits = {_lib.TASK_VSS_V0: 1200, _lib.TASK_SSL_STATIC_DEFENDERS: 1000, _lib.TASK_SSL_DRIBBLING: 4800, _lib.TASK_SSL_CONTESTED: 1200,
+              _lib.TASK_SSL_PASS_ENDURANCE: 1200}
+    for env_id, name in rsoccer_amd.VECTOR_CLASSES.items():
+        cls = getattr(vec, name)
+        assert issubclass(cls, vec.VecFusedEnv) and limits[cls.TASK] == ref[env_id]["max_episode_steps"]   # (the engine's default for the task)
+    with pytest.raises(KeyError, match="VSS-v0"):
+        rsoccer_amd.make_vec("VSS-v1", 8)
+
+
 def test_rgb_array_render_has_the_reference_window_geometry(oracle_mod):
     """render_mode='rgb_array' (numpy rasteriser): the frame shapes of the reference's pygame
     surfaces (Render/field.py:189-264 -> VSS 750 x 850, SSL 670 x 970), robots and ball drawn
